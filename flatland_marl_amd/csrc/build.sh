@@ -1,0 +1,15 @@
+#!/usr/bin/env bash
+# Builds the C-ABI shared library for gfx950 in-tree (travels to the GPU box with the snapshot).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/libflatland_hip.so"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+SRCS=("$HERE/fl_host.hip" "$HERE/fl_step.hip" "$HERE/fl_dmap.hip" "$HERE/fl_obs.hip")
+newest=0
+for f in "${SRCS[@]}" "$HERE"/*.h "$HERE/../../include/flatland_hip.h"; do
+  m=$(stat -c %Y "$f"); [ "$m" -gt "$newest" ] && newest=$m
+done
+if [ -f "$OUT" ] && [ "$(stat -c %Y "$OUT")" -ge "$newest" ] && [ -z "${FORCE:-}" ]; then echo "up to date: $OUT"; exit 0; fi
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
+  -Wno-unused-result ${EXTRA_HIPCC_FLAGS:-} "${SRCS[@]}" -o "$OUT"
+echo "built $OUT"

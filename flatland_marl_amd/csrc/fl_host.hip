@@ -1,0 +1,412 @@
+// fl_host.hip -- host side of the C-ABI (include/flatland_hip.h): device-resident SoA state, env hand-over,
+// kernel launches on the handle's HIP stream.  No torch types; plain pointers and sizes.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/flatland_hip.h"
+#include "fl_internal.h"
+#include "fl_obs.h"
+
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *fl_last_error(void) { return g_err; }
+int fl_version(void) { return 100; }
+int fl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FL_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+struct fl_batch {
+    int B, A, H, W, device;
+    FlDev d;
+    hipStream_t own_stream, stream;
+    bool committed;
+    std::vector<void *> allocs;
+    // host staging (filled by fl_load_env, uploaded by fl_commit)
+    std::vector<uint16_t> h_grid;
+    std::vector<int> h_init_pos, h_target, h_earliest, h_latest, h_tslot, h_ut, h_U, h_T, h_mt_pos, h_malf_min, h_malf_max;
+    std::vector<uint32_t> h_spk, h_mt;
+    std::vector<double> h_speed;
+    std::vector<uint64_t> h_thr;
+    std::vector<uint8_t> h_loaded;
+    FlObsScratch obs;
+};
+
+template <typename T>
+static int dev_alloc(fl_batch *h, T **p, size_t n) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, n * sizeof(T) + 16));
+    HIPCHK(hipMemsetAsync(q, 0, n * sizeof(T) + 16, h->stream));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return FL_OK;
+}
+#define DALLOC(ptr, n)                                   \
+    do {                                                 \
+        int rc_ = dev_alloc(h, &(ptr), (size_t)(n));     \
+        if (rc_ != FL_OK) return rc_;                    \
+    } while (0)
+
+int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
+    if (!out || B <= 0 || A <= 0 || H <= 0 || W <= 0) { set_err("fl_create: bad sizes"); return FL_ERR_ARG; }
+    if (A > 1024) { set_err("fl_create: at most 1024 agents per env (one lane per agent), got %d", A); return FL_ERR_ARG; }
+    if ((long long)H * W * 4 >= (1ll << 30)) { set_err("fl_create: map too large"); return FL_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err("fl_create: no HIP device visible (the HIP path has no CPU fallback)");
+        return FL_ERR_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    fl_batch *h = new fl_batch();
+    h->B = B; h->A = A; h->H = H; h->W = W; h->device = device;
+    h->committed = false;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        set_err("hipStreamCreate failed");
+        return FL_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    memset(&h->d, 0, sizeof h->d);
+    h->d.B = B; h->d.A = A; h->d.H = H; h->d.W = W; h->d.Umax = 0;
+    const size_t BA = (size_t)B * A, HW = (size_t)H * W;
+    h->h_grid.assign(B * HW, 0);
+    h->h_init_pos.assign(BA, 0); h->h_target.assign(BA, 0); h->h_earliest.assign(BA, 0); h->h_latest.assign(BA, 0);
+    h->h_tslot.assign(BA, 0); h->h_spk.assign(BA, 0); h->h_speed.assign(BA, 1.0);
+    h->h_ut.assign(BA, 0); h->h_U.assign(B, 0); h->h_T.assign(B, 0); h->h_mt_pos.assign(B, 624);
+    h->h_malf_min.assign(B, 0); h->h_malf_max.assign(B, 0); h->h_thr.assign(B, 0);
+    h->h_mt.assign((size_t)B * 624, 0);
+    h->h_loaded.assign(B, 0);
+    memset(&h->obs, 0, sizeof h->obs);
+    *out = h;
+    return FL_OK;
+}
+
+void fl_destroy(fl_batch *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int fl_set_stream(fl_batch *h, void *hip_stream) {
+    if (!h) return FL_ERR_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return FL_OK;
+}
+
+int fl_sync(fl_batch *h) {
+    if (!h) return FL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_pos, const int32_t *init_dir,
+                const int32_t *target, const double *speed, const int32_t *earliest, const int32_t *latest,
+                int max_episode_steps, uint64_t malf_threshold, int malf_min, int malf_max, const uint32_t *mt_key,
+                int mt_pos) {
+    if (!h || b < 0 || b >= h->B) { set_err("fl_load_env: env index out of range"); return FL_ERR_ARG; }
+    const int A = h->A, H = h->H, W = h->W;
+    const size_t HW = (size_t)H * W;
+    if (mt_pos < 0 || mt_pos > 624) { set_err("fl_load_env: mt_pos out of range"); return FL_ERR_ARG; }
+    if (malf_max < malf_min || malf_min < 0 || malf_max > 60000) { set_err("fl_load_env: bad malfunction duration range"); return FL_ERR_ARG; }
+    size_t rail_cells = 0;
+    for (size_t c = 0; c < HW; c++) rail_cells += grid[c] != 0;
+    if (rail_cells * 4 >= 65534) { set_err("fl_load_env: %zu rail cells exceed the u16 distance-map range", rail_cells); return FL_ERR_ARG; }
+    memcpy(&h->h_grid[b * HW], grid, HW * 2);
+    int U = 0;
+    for (int i = 0; i < A; i++) {
+        const size_t g = (size_t)b * A + i;
+        const int ir = init_pos[2 * i], ic = init_pos[2 * i + 1], tr = target[2 * i], tc = target[2 * i + 1];
+        if (ir < 0 || ir >= H || ic < 0 || ic >= W || tr < 0 || tr >= H || tc < 0 || tc >= W || init_dir[i] < 0 || init_dir[i] > 3) {
+            set_err("fl_load_env: agent %d position/direction out of range", i);
+            return FL_ERR_ARG;
+        }
+        if (!(speed[i] > 0.0) || speed[i] > 1.0) { set_err("fl_load_env: agent %d speed %g not in (0, 1]", i, speed[i]); return FL_ERR_ARG; }
+        const int max_count = (int)(1.0 / speed[i]) - 1;  // SpeedCounter.max_count (step_utils/speed_counter.py:39-41)
+        if (max_count < 0 || max_count > 15) { set_err("fl_load_env: agent %d speed %g unsupported (max_count %d)", i, speed[i], max_count); return FL_ERR_ARG; }
+        h->h_init_pos[g] = ir * W + ic;
+        h->h_target[g] = tr * W + tc;
+        h->h_earliest[g] = earliest[i];
+        h->h_latest[g] = latest[i];
+        h->h_speed[g] = speed[i];
+        h->h_spk[g] = (uint32_t)init_dir[i] | ((uint32_t)max_count << 2);
+        // unique targets in first-seen order (distance_map.py:71-79)
+        int u = 0;
+        for (; u < U; u++)
+            if (h->h_ut[(size_t)b * A + u] == h->h_target[g]) break;
+        if (u == U) h->h_ut[(size_t)b * A + U++] = h->h_target[g];
+        h->h_tslot[g] = u;
+    }
+    h->h_U[b] = U;
+    h->h_T[b] = max_episode_steps;
+    h->h_thr[b] = malf_threshold;
+    h->h_malf_min[b] = malf_min;
+    h->h_malf_max[b] = malf_max;
+    memcpy(&h->h_mt[(size_t)b * 624], mt_key, 624 * 4);
+    h->h_mt_pos[b] = mt_pos;
+    h->h_loaded[b] = 1;
+    return FL_OK;
+}
+
+template <typename T>
+static int upload(fl_batch *h, T *dst, const std::vector<T> &src) {
+    HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return FL_OK;
+}
+#define UPLOAD(dst, src)                    \
+    do {                                    \
+        int rc_ = upload(h, dst, src);      \
+        if (rc_ != FL_OK) return rc_;       \
+    } while (0)
+
+int fl_commit(fl_batch *h) {
+    if (!h) return FL_ERR_ARG;
+    if (h->committed) { set_err("fl_commit: already committed"); return FL_ERR_ARG; }
+    for (int b = 0; b < h->B; b++)
+        if (!h->h_loaded[b]) { set_err("fl_commit: env %d was never loaded", b); return FL_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    const int B = h->B, A = h->A;
+    const size_t BA = (size_t)B * A, HW = (size_t)h->H * h->W;
+    int Umax = 1;
+    for (int b = 0; b < B; b++) Umax = h->h_U[b] > Umax ? h->h_U[b] : Umax;
+    FlDev &d = h->d;
+    d.Umax = Umax;
+    DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
+    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B);
+    DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
+    DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
+    DALLOC(d.spk, BA); DALLOC(d.speed, BA);
+    DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
+    std::vector<int> ut((size_t)B * Umax, 0);
+    for (int b = 0; b < B; b++)
+        for (int u = 0; u < h->h_U[b]; u++) ut[(size_t)b * Umax + u] = h->h_ut[(size_t)b * A + u];
+    UPLOAD(d.T, h->h_T); UPLOAD(d.mt_pos, h->h_mt_pos); UPLOAD(d.mt, h->h_mt); UPLOAD(d.malf_thr, h->h_thr);
+    UPLOAD(d.malf_min, h->h_malf_min); UPLOAD(d.malf_max, h->h_malf_max); UPLOAD(d.U, h->h_U);
+    UPLOAD(d.grid, h->h_grid); UPLOAD(d.ut, ut);
+    UPLOAD(d.init_pos, h->h_init_pos); UPLOAD(d.target, h->h_target); UPLOAD(d.earliest, h->h_earliest);
+    UPLOAD(d.latest, h->h_latest); UPLOAD(d.tslot, h->h_tslot); UPLOAD(d.spk, h->h_spk); UPLOAD(d.speed, h->h_speed);
+    HIPCHK(hipStreamSynchronize(h->stream));  // `ut` is a local
+    fl_launch_distance_maps(d, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_reset(d, nullptr, 1, h->stream);
+    HIPCHK(hipGetLastError());
+    int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
+    if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->committed = true;
+    // host staging is no longer needed
+    h->h_grid.clear(); h->h_grid.shrink_to_fit();
+    h->h_mt.clear(); h->h_mt.shrink_to_fit();
+    return fl_check(h);
+}
+
+#define NEED_COMMIT(h)                                                         \
+    do {                                                                       \
+        if (!(h) || !(h)->committed) { set_err("handle not committed"); return FL_ERR_ARG; } \
+        HIPCHK(hipSetDevice((h)->device));                                     \
+    } while (0)
+
+int fl_set_rng(fl_batch *h, const uint32_t *mt_key, const int32_t *mt_pos) {
+    NEED_COMMIT(h);
+    for (int b = 0; b < h->B; b++)
+        if (mt_pos[b] < 0 || mt_pos[b] > 624) { set_err("fl_set_rng: mt_pos out of range"); return FL_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(h->d.mt, mt_key, (size_t)h->B * 624 * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d.mt_pos, mt_pos, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+int fl_get_rng(fl_batch *h, uint32_t *mt_key, int32_t *mt_pos) {
+    NEED_COMMIT(h);
+    HIPCHK(hipMemcpyAsync(mt_key, h->d.mt, (size_t)h->B * 624 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(mt_pos, h->d.mt_pos, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+int fl_reset(fl_batch *h, const uint8_t *mask, int fresh) {
+    NEED_COMMIT(h);
+    uint8_t *mask_dev = nullptr;
+    if (mask) {
+        HIPCHK(hipMalloc((void **)&mask_dev, h->B));
+        HIPCHK(hipMemcpyAsync(mask_dev, mask, h->B, hipMemcpyHostToDevice, h->stream));
+    }
+    fl_launch_reset(h->d, mask_dev, fresh, h->stream);
+    fl_obs_reset(h->obs, h->d, mask_dev, h->stream);
+    HIPCHK(hipGetLastError());
+    if (mask_dev) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(mask_dev));
+    }
+    return FL_OK;
+}
+
+int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8_t *dones_dev, uint8_t *done_all_dev,
+            int auto_reset) {
+    NEED_COMMIT(h);
+    if (!actions_dev || !rewards_dev || !dones_dev || !done_all_dev) { set_err("fl_step: null buffer"); return FL_ERR_ARG; }
+    fl_launch_step(h->d, actions_dev, 0, 0, 0, rewards_dev, dones_dev, done_all_dev, auto_reset, h->stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev, uint8_t *dones_dev,
+                  uint8_t *done_all_dev, int auto_reset) {
+    NEED_COMMIT(h);
+    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 1) { set_err("fl_step_synth: bad argument"); return FL_ERR_ARG; }
+    fl_launch_step(h->d, nullptr, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, auto_reset, h->stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_check(fl_batch *h) {
+    NEED_COMMIT(h);
+    std::vector<int> err(h->B);
+    HIPCHK(hipMemcpyAsync(err.data(), h->d.err, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->B; b++) {
+        if (err[b]) {
+            const int e = err[b];
+            HIPCHK(hipMemsetAsync(h->d.err, 0, (size_t)h->B * 4, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const char *msg = e == FL_ERR_EPISODE_DONE ? "Episode is done, cannot call step()"
+                              : e == FL_ERR_STATE_SYNC ? "agent state / position desync"
+                              : e == FL_ERR_ZERO_TRANSITION ? "WRONG CELL TYPE detected in tree-search (0 transitions possible)"
+                              : e == FL_ERR_CAPACITY ? "internal capacity exceeded" : "kernel error";
+            set_err("env %d: %s", b, msg);
+            return e;
+        }
+    }
+    return FL_OK;
+}
+
+int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed) {
+    NEED_COMMIT(h);
+    const size_t BA = (size_t)h->B * h->A;
+    std::vector<int> pos(BA), old_pos(BA), arrival(BA);
+    std::vector<uint32_t> malf(BA), pk(BA);
+    HIPCHK(hipMemcpyAsync(pos.data(), h->d.pos, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(old_pos.data(), h->d.old_pos, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(arrival.data(), h->d.arrival, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(malf.data(), h->d.malf, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pk.data(), h->d.pk, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    if (elapsed) HIPCHK(hipMemcpyAsync(elapsed, h->d.t, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int W = h->W;
+    if (state) {
+        for (size_t g = 0; g < BA; g++) {
+            int32_t *o = state + g * FL_STATE_COLS;
+            const uint32_t p = pk[g];
+            o[0] = pos[g] < 0 ? -1 : pos[g] / W;
+            o[1] = pos[g] < 0 ? -1 : pos[g] % W;
+            o[2] = (int)PK_DIR(p);
+            o[3] = (int)PK_STATE(p);
+            o[4] = (int)(malf[g] & 0xFFFF);
+            o[5] = (int)(malf[g] >> 16);
+            o[6] = (int)PK_SCOUNT(p);
+            o[7] = (int)PK_SAVED(p);
+            o[8] = arrival[g];
+            o[9] = old_pos[g] < 0 ? -1 : old_pos[g] / W;
+            o[10] = old_pos[g] < 0 ? -1 : old_pos[g] % W;
+            o[11] = PK_OLD_DIR(p) == 4 ? -1 : (int)PK_OLD_DIR(p);
+        }
+    }
+    return FL_OK;
+}
+
+int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot) {
+    NEED_COMMIT(h);
+    if (b < 0 || b >= h->B || !n_targets) { set_err("fl_distance_map: bad argument"); return FL_ERR_ARG; }
+    *n_targets = h->h_U[b];
+    const size_t HW = (size_t)h->H * h->W;
+    if (dm)
+        HIPCHK(hipMemcpyAsync(dm, h->d.dm + (size_t)b * h->d.Umax * HW * 4, (size_t)h->h_U[b] * HW * 4 * 2,
+                              hipMemcpyDeviceToHost, h->stream));
+    if (target_slot) memcpy(target_slot, &h->h_tslot[(size_t)b * h->A], (size_t)h->A * 4);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
+int fl_positions_map(fl_batch *h, int b, int32_t *out) {
+    NEED_COMMIT(h);
+    if (b < 0 || b >= h->B || !out) { set_err("fl_positions_map: bad argument"); return FL_ERR_ARG; }
+    // RailEnv._update_agent_positions_map (rail_env.py:360-367): later agents overwrite earlier ones on a shared cell
+    const int A = h->A;
+    std::vector<int> pos(A);
+    HIPCHK(hipMemcpyAsync(pos.data(), h->d.pos + (size_t)b * A, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t c = 0; c < (size_t)h->H * h->W; c++) out[c] = -1;
+    for (int i = 0; i < A; i++)
+        if (pos[i] >= 0) out[pos[i]] = i;
+    return FL_OK;
+}
+
+int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev, int32_t *adjacency_dev,
+                  int32_t *node_order_dev, int32_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev) {
+    NEED_COMMIT(h);
+    if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED) {
+        set_err("fl_obs_cutils: max_nodes must be in [4,%d] and pred_depth in [1,%d]", FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev) {
+        set_err("fl_obs_cutils: null output buffer");
+        return FL_ERR_ARG;
+    }
+    int rc = fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
+                                  edge_order_dev, valid_actions_dev, props_dev, h->stream);
+    if (rc != FL_OK) { set_err("fl_obs_cutils: launch failed"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
+    NEED_COMMIT(h);
+    if (max_depth < 1 || max_depth > 4 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
+        set_err("fl_obs_tree: max_depth must be in [1,4], pred_depth <= %d", FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    int rc = fl_launch_obs_tree(h->obs, h->d, max_depth, pred_depth, out_dev, h->stream);
+    if (rc != FL_OK) { set_err("fl_obs_tree: launch failed"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {
+    if (!h) return 0.0;
+    // DESIGN.md "algorithmic bytes": compulsory HBM traffic per agent-step with this SoA.
+    //   dynamics: 20 B state read + 20 B state write + 16 B static read (init_pos, target, earliest, spk; latest/speed/tslot
+    //             only on the terminal step) + 1 B action + 5 B reward/done + 8 B RNG words + MT block write amortised
+    //             (2496 B / 312 agent-steps = 8 B)
+    //   per env amortised over A: rail grid 2*H*W read once per obs build
+    //   cutils obs out: 31*12*4 + 30*3*4 + 31*4 + 30*4 + 83*4 + 5 = 2429 B; depth-d tree out: 12*8*N(d) (f64)
+    double bytes = 20 + 20 + 16 + 1 + 5 + 8 + 8;
+    if (with_cutils_obs || tree_depth > 0) bytes += 2.0 * h->H * h->W / h->A;
+    if (with_cutils_obs) bytes += 2429.0 + 20 + 36 + 2 * 31;  // + state/static re-read by the obs kernel + 31 distance-map gathers
+    if (tree_depth > 0) {
+        int n = 1, p = 1;
+        for (int k = 0; k < tree_depth; k++) { p *= 4; n += p; }
+        bytes += 96.0 * n + 2.0 * n;
+    }
+    return bytes;
+}

@@ -1,0 +1,108 @@
+// fl_internal.h -- device-side data layout and helpers shared by the HIP kernels (gfx950 only).
+//
+// HBM layout: struct-of-arrays over (env b, agent i), g = b * A + i.
+//   dynamic (20 B/agent): pos i32, old_pos i32, arrival i32, malf u32 (lo16 down counter, hi16 num_malfunctions),
+//                         pk u32 (packed small fields, see PK_* below)
+//   static  (36 B/agent): init_pos i32, target i32, earliest i32, latest i32, spk u32, tslot i32, speed f64
+//   per env: t, T, done_all, mt_pos, mt[624], malf_thr u64, malf_min/max, U, grid u16[H*W],
+//            dm u16[Umax][H*W][4] (0xFFFF = unreachable)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FL_INF16 0xFFFFu
+
+enum { ST_WAITING = 0, ST_READY = 1, ST_MALF_OFF = 2, ST_MOVING = 3, ST_STOPPED = 4, ST_MALF = 5, ST_DONE = 6 };
+enum { ACT_NOTHING = 0, ACT_LEFT = 1, ACT_FORWARD = 2, ACT_RIGHT = 3, ACT_STOP = 4 };
+
+// pk bit fields
+#define PK_DIR(pk) ((pk)&3u)
+#define PK_OLD_DIR(pk) (((pk) >> 2) & 7u) /* 4 = None */
+#define PK_STATE(pk) (((pk) >> 5) & 7u)
+#define PK_PREV(pk) (((pk) >> 8) & 7u) /* 7 = None */
+#define PK_SAVED(pk) (((pk) >> 11) & 3u)
+#define PK_SCOUNT(pk) (((pk) >> 13) & 15u)
+#define PK_SIGMALF(pk) (((pk) >> 17) & 1u)
+#define PK_DEADLOCK(pk) (((pk) >> 18) & 1u)
+#define PK_DONE(pk) (((pk) >> 19) & 1u)
+__host__ __device__ inline uint32_t pk_make(uint32_t dir, uint32_t old_dir, uint32_t state, uint32_t prev, uint32_t saved,
+                                            uint32_t scount, uint32_t sig, uint32_t dead, uint32_t done) {
+    return dir | (old_dir << 2) | (state << 5) | (prev << 8) | (saved << 11) | (scount << 13) | (sig << 17) | (dead << 18) |
+           (done << 19);
+}
+// spk: init_dir bits 0-1, max_count bits 2-5
+#define SPK_INIT_DIR(s) ((s)&3u)
+#define SPK_MAX_COUNT(s) (((s) >> 2) & 15u)
+
+struct FlDev {
+    int B, A, H, W, Umax;
+    // per env
+    int *t;
+    int *T;
+    uint8_t *done_all;
+    int *mt_pos;
+    uint32_t *mt;  // [B][624]
+    uint64_t *malf_thr;
+    int *malf_min, *malf_max;
+    int *U;
+    int *err;  // [B] first error code raised by a kernel for env b (0 = none)
+    uint16_t *grid;  // [B][H*W]
+    uint16_t *dm;    // [B][Umax][H*W][4]
+    int *ut;         // [B][Umax] unique target cells
+    // static per agent
+    int *init_pos, *target, *earliest, *latest, *tslot;
+    uint32_t *spk;
+    double *speed;
+    // dynamic per agent
+    int *pos, *old_pos, *arrival;
+    uint32_t *malf, *pk;
+};
+
+__device__ __forceinline__ bool is_off_map(uint32_t s) { return s <= ST_MALF_OFF; }
+__device__ __forceinline__ bool is_on_map(uint32_t s) { return s >= ST_MOVING && s <= ST_MALF; }
+// 4-bit transition nibble of a 16-bit cell for an agent facing dir: bit 3 = N, 2 = E, 1 = S, 0 = W
+__device__ __forceinline__ uint32_t nibble(uint32_t cell, uint32_t dir) { return (cell >> ((3u - dir) * 4u)) & 15u; }
+__device__ __forceinline__ uint32_t tbit(uint32_t cell, uint32_t dir, uint32_t m) { return (nibble(cell, dir) >> (3u - m)) & 1u; }
+// first set transition in N,E,S,W order of a non-zero nibble
+__device__ __forceinline__ uint32_t first_dir(uint32_t bits) { return (uint32_t)__clz((int)bits) - 28u; }
+__device__ __forceinline__ int step_cell(int cell, uint32_t dir, int W) {
+    // N(-1,0) E(0,1) S(1,0) W(0,-1)
+    return cell + (dir == 0 ? -W : dir == 1 ? 1 : dir == 2 ? W : -1);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// murmur3 finaliser; synthetic action stream shared with flatland_marl_amd/synth.py
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t action_hash(uint32_t seed, uint32_t b, uint32_t t, uint32_t a) {
+    uint32_t h = seed * 0x9E3779B1u;
+    h = mix32(h ^ (b * 0x85EBCA77u));
+    h = mix32(h ^ (t * 0xC2B2AE3Du));
+    h = mix32(h ^ (a * 0x27D4EB2Fu));
+    return h;
+}
+__host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint32_t t, uint32_t a, int kind) {
+    uint32_t h = action_hash(seed, b, t, a);
+    if (kind == 0) return h % 5u;
+    uint32_t r = h % 100u;
+    return r >= 95 ? 0u : r >= 90 ? 4u : r >= 85 ? 3u : r >= 80 ? 1u : 2u;
+}
+
+// kernel launchers (defined in the .hip files)
+void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
+void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
+void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
+                    int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s);

@@ -1,0 +1,23 @@
+// fl_obs.h -- observation kernels' host interface (scratch owned by the batch handle).
+#pragma once
+#include <vector>
+
+#include "fl_internal.h"
+
+#define FL_OBS_MAX_NODES 64
+#define FL_OBS_MAX_PRED 500
+
+struct FlObsScratch {
+    int pred_cap;      // waypoints kept per agent (pred_depth + 2)
+    uint32_t *path;    // [B][A][pred_cap] predicted waypoints: cell << 2 | dir
+    int *path_len;     // [B][A]
+    int *cell_head;    // [B][H*W + 1] CSR offsets of the per-cell prediction index
+    uint32_t *cell_items;  // [B][A * pred_cap] (agent << 16 | waypoint index)
+};
+
+int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);
+void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
+int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
+                         int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
+                         hipStream_t s);
+int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);

@@ -1,0 +1,263 @@
+"""ctypes binding of the C-ABI in include/flatland_hip.h (csrc/libflatland_hip.so) and the batched
+tensor-level env on top of it.  torch is used for device buffers and streams only.
+
+There is NO CPU fallback: every compute entry point fails loudly when the HIP library is missing or
+no GPU is visible.
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libflatland_hip.so")
+
+FL_OK = 0
+ERR_NAMES = {1: "FL_ERR_ARG", 2: "FL_ERR_HIP", 3: "FL_ERR_EPISODE_DONE", 4: "FL_ERR_STATE_SYNC",
+             5: "FL_ERR_ZERO_TRANSITION", 6: "FL_ERR_CAPACITY"}
+ACTION_ABSENT = 255
+STATE_COLS = 12
+STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved", "arrival",
+               "old_row", "old_col", "old_dir")
+
+# every symbol include/flatland_hip.h declares
+SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
+           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
+           "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_positions_map",
+           "fl_algorithmic_bytes_per_agent_step")
+
+_lib = None
+
+
+class FlatlandHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, code), msg))
+        self.code = code
+
+
+class EpisodeDoneError(FlatlandHipError):
+    """RailEnv.step raises Exception("Episode is done, cannot call step()") (rail_env.py:508-509)."""
+
+
+def build(force=False):
+    env = dict(os.environ)
+    if force:
+        env["FORCE"] = "1"
+    subprocess.check_call([os.path.join(HERE, "csrc", "build.sh")], env=env, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s is missing: build it with flatland_marl_amd/csrc/build.sh (hipcc --offload-arch=gfx950); "
+                "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
+        L.fl_last_error.restype = C.c_char_p
+        L.fl_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+        L.fl_destroy.argtypes = [vp]
+        L.fl_destroy.restype = None
+        L.fl_set_stream.argtypes = [vp, vp]
+        L.fl_sync.argtypes = [vp]
+        L.fl_load_env.argtypes = [vp, i32] + [vp] * 7 + [i32, u64, i32, i32, vp, i32]
+        L.fl_commit.argtypes = [vp]
+        L.fl_set_rng.argtypes = [vp, vp, vp]
+        L.fl_get_rng.argtypes = [vp, vp, vp]
+        L.fl_reset.argtypes = [vp, vp, i32]
+        L.fl_step.argtypes = [vp, vp, vp, vp, vp, i32]
+        L.fl_step_synth.argtypes = [vp, u32, u32, i32, vp, vp, vp, i32]
+        L.fl_check.argtypes = [vp]
+        L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
+        L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        L.fl_get_state.argtypes = [vp, vp, vp]
+        L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
+        L.fl_positions_map.argtypes = [vp, i32, vp]
+        L.fl_algorithmic_bytes_per_agent_step.argtypes = [vp, i32, i32]
+        L.fl_algorithmic_bytes_per_agent_step.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != FL_OK:
+        msg = lib().fl_last_error().decode()
+        if rc == 3:
+            raise EpisodeDoneError(rc, msg)
+        raise FlatlandHipError(rc, msg)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def malf_threshold(rate):
+    """ceil((1 - exp(-rate)) * 2**53): `np_random.rand() < _malfunction_prob(rate)` as a 53-bit integer
+    compare (malfunction_generators.py:24-33,46-53)."""
+    if rate <= 0:
+        return 0
+    p = float(1 - np.exp(-rate))
+    return int(math.ceil(p * 2.0 ** 53))
+
+
+class BatchedRailEnv:
+    """B independent Flatland envs stepped in lock-step on one MI355X.
+
+    `envs` is a list of B mappings with the static description of each env, as produced by the
+    reference after reset(): grid u16[H,W], init_pos i32[A,2], init_dir i32[A], target i32[A,2],
+    speed f64[A], earliest i32[A], latest i32[A], T, malf_rate, malf_min, malf_max, mt_key u32[624], mt_pos.
+    All envs of one batch share (A, H, W).
+    """
+
+    def __init__(self, envs, device=0, max_nodes=31, pred_depth=500):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedRailEnv needs a HIP device (torch.cuda.is_available() is False); "
+                               "the HIP path has no CPU fallback")
+        L = lib()
+        e0 = envs[0]
+        self.B = len(envs)
+        self.H, self.W = np.asarray(e0["grid"]).shape
+        self.A = int(len(e0["init_dir"]))
+        self.device = torch.device("cuda", device)
+        self.max_nodes, self.pred_depth = max_nodes, pred_depth
+        h = C.c_void_p()
+        _chk(L.fl_create(self.B, self.A, self.H, self.W, device, C.byref(h)))
+        self.h = h
+        self.T = np.zeros(self.B, dtype=np.int32)
+        for b, e in enumerate(envs):
+            grid = np.ascontiguousarray(e["grid"], dtype=np.uint16)
+            assert grid.shape == (self.H, self.W) and len(e["init_dir"]) == self.A
+            a32 = lambda k: np.ascontiguousarray(e[k], dtype=np.int32)  # noqa: E731
+            ip, idr, tg, ea, la = a32("init_pos"), a32("init_dir"), a32("target"), a32("earliest"), a32("latest")
+            sp = np.ascontiguousarray(e["speed"], dtype=np.float64)
+            key = np.ascontiguousarray(e["mt_key"], dtype=np.uint32)
+            self.T[b] = int(e["T"])
+            _chk(L.fl_load_env(h, b, _p(grid), _p(ip), _p(idr), _p(tg), _p(sp), _p(ea), _p(la), int(e["T"]),
+                               malf_threshold(float(e["malf_rate"])), int(e["malf_min"]), int(e["malf_max"]),
+                               _p(key), int(e["mt_pos"])))
+        with torch.cuda.device(self.device):
+            _chk(L.fl_commit(h))
+        B, A = self.B, self.A
+        self.rewards = torch.zeros((B, A), dtype=torch.int32, device=self.device)
+        self.dones = torch.zeros((B, A), dtype=torch.uint8, device=self.device)
+        self.done_all = torch.zeros((B,), dtype=torch.uint8, device=self.device)
+        self._obs = None
+        self._tree = {}
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self):
+        """enqueue on torch's current stream so torch ops and the kernels order naturally."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _chk(lib().fl_set_stream(self.h, C.c_void_p(s)))
+
+    # ---- dynamics
+    def reset(self, mask=None, fresh=True):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _chk(lib().fl_reset(self.h, None if m is None else _p(m), int(fresh)))
+
+    def step(self, actions, auto_reset=False):
+        """actions: uint8 tensor [B, A] on the device (255 = agent not in the action dict)."""
+        t = self.torch
+        if not (isinstance(actions, t.Tensor) and actions.is_cuda):
+            actions = t.as_tensor(np.ascontiguousarray(actions, dtype=np.uint8)).to(self.device)
+        actions = actions.contiguous()
+        assert actions.dtype == t.uint8 and actions.shape == (self.B, self.A)
+        _chk(lib().fl_step(self.h, actions.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(),
+                           self.done_all.data_ptr(), int(auto_reset)))
+        return self.rewards, self.dones, self.done_all
+
+    def step_synth(self, seed, stream_base=0, kind=0, auto_reset=True):
+        _chk(lib().fl_step_synth(self.h, int(seed), int(stream_base), int(kind), self.rewards.data_ptr(),
+                                 self.dones.data_ptr(), self.done_all.data_ptr(), int(auto_reset)))
+        return self.rewards, self.dones, self.done_all
+
+    def check(self):
+        _chk(lib().fl_check(self.h))
+
+    def sync(self):
+        _chk(lib().fl_sync(self.h))
+
+    # ---- observations
+    def _obs_buffers(self):
+        if self._obs is None:
+            t, B, A, N = self.torch, self.B, self.A, self.max_nodes
+            dev = self.device
+            self._obs = dict(
+                agent_attr=t.zeros((B, A, 83), dtype=t.float32, device=dev),
+                forest=t.zeros((B, A, N, 12), dtype=t.float32, device=dev),
+                adjacency=t.zeros((B, A, N - 1, 3), dtype=t.int32, device=dev),
+                node_order=t.zeros((B, A, N), dtype=t.int32, device=dev),
+                edge_order=t.zeros((B, A, N - 1), dtype=t.int32, device=dev),
+                valid_actions=t.zeros((B, A, 5), dtype=t.uint8, device=dev),
+                props=t.zeros((B, A, 3), dtype=t.float64, device=dev))
+        return self._obs
+
+    def obs_cutils(self):
+        """flatland_cutils.TreeObsForRailEnv.get_many + get_properties for every agent of every env."""
+        o = self._obs_buffers()
+        _chk(lib().fl_obs_cutils(self.h, self.max_nodes, self.pred_depth, o["agent_attr"].data_ptr(),
+                                 o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
+                                 o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
+        return o
+
+    def obs_tree(self, max_depth=2, pred_depth=30):
+        """upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense tensor."""
+        n = (4 ** (max_depth + 1) - 1) // 3
+        key = (max_depth,)
+        if key not in self._tree:
+            self._tree[key] = self.torch.zeros((self.B, self.A, n, 12), dtype=self.torch.float64, device=self.device)
+        out = self._tree[key]
+        _chk(lib().fl_obs_tree(self.h, max_depth, pred_depth, out.data_ptr()))
+        return out
+
+    # ---- read-backs
+    def state(self):
+        st = np.zeros((self.B, self.A, STATE_COLS), dtype=np.int32)
+        el = np.zeros(self.B, dtype=np.int32)
+        _chk(lib().fl_get_state(self.h, _p(st), _p(el)))
+        return st, el
+
+    def rng_state(self):
+        key = np.zeros((self.B, 624), dtype=np.uint32)
+        pos = np.zeros(self.B, dtype=np.int32)
+        _chk(lib().fl_get_rng(self.h, _p(key), _p(pos)))
+        return key, pos
+
+    def set_rng_state(self, key, pos):
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        assert key.shape == (self.B, 624) and pos.shape == (self.B,)
+        _chk(lib().fl_set_rng(self.h, _p(key), _p(pos)))
+
+    def distance_map(self, b):
+        n = C.c_int(0)
+        slot = np.zeros(self.A, dtype=np.int32)
+        _chk(lib().fl_distance_map(self.h, b, C.byref(n), None, _p(slot)))
+        dm = np.zeros((n.value, self.H, self.W, 4), dtype=np.uint16)
+        _chk(lib().fl_distance_map(self.h, b, C.byref(n), _p(dm), _p(slot)))
+        return dm, slot
+
+    def positions_map(self, b):
+        out = np.zeros((self.H, self.W), dtype=np.int32)
+        _chk(lib().fl_positions_map(self.h, b, _p(out)))
+        return out
+
+    def algorithmic_bytes_per_agent_step(self, with_cutils_obs=True, tree_depth=0):
+        return float(lib().fl_algorithmic_bytes_per_agent_step(self.h, int(with_cutils_obs), int(tree_depth)))

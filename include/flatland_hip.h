@@ -1,0 +1,117 @@
+/*
+ * flatland_hip.h -- C-ABI of the MI355X-native batched Flatland3 stepper + tree-observation builder.
+ *
+ * Drop-in boundary for the reference's hot path.  Each entry point names the reference interface it
+ * replaces (paths relative to /root/reference):
+ *
+ *   fl_create / fl_load_env / fl_commit   RailEnv.__init__ + reset() state hand-over
+ *                                         (flatland-rl/flatland/envs/rail_env.py:100-207, 260-357) and
+ *                                         flatland_cutils TreeObsForRailEnv.set_env()/reset()
+ *                                         (flatland_cutils/src/treeobs.cpp:17-28, loader.cpp:207-219,329-333)
+ *   fl_distance_map                       DistanceMap.get()/_compute (flatland/envs/distance_map.py:27-79)
+ *   fl_reset                              RailEnv.reset_agents() (rail_env.py:236-241, agent_utils.py:90-105)
+ *   fl_step                               RailEnv.step(action_dict) (rail_env.py:501-634)
+ *   fl_obs_cutils                         flatland_cutils.TreeObsForRailEnv.get_many() + get_properties()
+ *                                         (flatland_cutils/src/main.cpp:17-22, treeobs.cpp:30-108, 612-640)
+ *   fl_obs_tree                           flatland.envs.observations.TreeObsForRailEnv.get_many()
+ *                                         (flatland/envs/observations.py:60-115)
+ *   fl_get_state / fl_get_rng             EnvAgent attribute reads (agent_utils.py:57-88), np_random.get_state()
+ *
+ * Conventions: plain pointers and sizes only.  Pointers named *_dev are DEVICE pointers (hipMalloc /
+ * torch CUDA tensors), everything else is host memory.  All buffers are caller-owned; the library keeps
+ * its own device-resident state inside the opaque handle.  Calls on one handle are not thread-safe.
+ * Every function returns FL_OK (0) or an FL_ERR_* code; fl_last_error() gives the message.
+ * Work is enqueued on the handle's HIP stream (fl_set_stream); fl_sync() waits for it.
+ */
+#ifndef FLATLAND_HIP_H
+#define FLATLAND_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fl_batch fl_batch;
+
+enum {
+    FL_OK = 0,
+    FL_ERR_ARG = 1,          /* bad argument / unsupported size */
+    FL_ERR_HIP = 2,          /* HIP runtime error (no device, OOM, launch failure) */
+    FL_ERR_EPISODE_DONE = 3, /* RailEnv.step: Exception("Episode is done, cannot call step()") rail_env.py:508-509 */
+    FL_ERR_STATE_SYNC = 4,   /* env_utils.state_position_sync_check ValueError, step_utils/env_utils.py:45-52 */
+    FL_ERR_ZERO_TRANSITION = 5, /* treeobs.cpp:531-535 std::invalid_argument (0 transitions in tree search) */
+    FL_ERR_CAPACITY = 6      /* an internal fixed-capacity buffer overflowed (BFS frontier, prediction index) */
+};
+
+#define FL_ACTION_ABSENT 255 /* agent missing from the action dict (rail_env.py:527 -> DO_NOTHING) */
+#define FL_STATE_COLS 12     /* row,col,dir,state,malf,nmalf,speed_counter,saved_action,arrival,old_row,old_col,old_dir */
+#define FL_CUTILS_ATTR 83
+#define FL_NODE_FEATURES 12
+
+const char *fl_last_error(void);
+int fl_version(void);
+/* number of visible HIP devices (0 on a CPU-only host); never initialises a device context */
+int fl_device_count(void);
+
+/* B envs, each A agents on an H x W grid, resident on HIP device `device`. */
+int fl_create(int B, int A, int H, int W, int device, fl_batch **out);
+void fl_destroy(fl_batch *h);
+/* run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own stream */
+int fl_set_stream(fl_batch *h, void *hip_stream);
+int fl_sync(fl_batch *h);
+
+/* Stage env b on the host side of the handle.  init_pos/target: int32[A][2] (row, col); speed: float64[A];
+ * malf_threshold = ceil((1 - exp(-rate)) * 2^53), 0 for no malfunctions (malfunction_generators.py:24-53);
+ * mt_key[624], mt_pos: numpy RandomState (MT19937) state AFTER reset(). */
+int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_pos, const int32_t *init_dir,
+                const int32_t *target, const double *speed, const int32_t *earliest, const int32_t *latest,
+                int max_episode_steps, uint64_t malf_threshold, int malf_min, int malf_max,
+                const uint32_t *mt_key, int mt_pos);
+/* Upload all staged envs, build the distance maps on the GPU, reset all agents. */
+int fl_commit(fl_batch *h);
+/* Per-env RNG replacement after commit (host arrays: mt_key uint32[B][624], mt_pos int32[B]). */
+int fl_set_rng(fl_batch *h, const uint32_t *mt_key, const int32_t *mt_pos);
+int fl_get_rng(fl_batch *h, uint32_t *mt_key, int32_t *mt_pos);
+
+/* Reset agents (not the RNG, not the maps).  mask: host u8[B] or NULL (= all).  fresh != 0 also clears
+ * arrival_time (a freshly loaded env); fresh == 0 follows EnvAgent.reset() literally (agent_utils.py:90-105). */
+int fl_reset(fl_batch *h, const uint8_t *mask, int fresh);
+
+/* One lock-step tick of all B envs.  actions_dev u8[B][A] (FL_ACTION_ABSENT allowed);
+ * rewards_dev int32[B][A], dones_dev u8[B][A], done_all_dev u8[B].
+ * auto_reset != 0: an env whose episode ended is reset (fresh) at the start of this call instead of
+ * failing with FL_ERR_EPISODE_DONE.  Errors raised inside the kernel surface at fl_check(). */
+int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8_t *dones_dev,
+            uint8_t *done_all_dev, int auto_reset);
+/* Same, with the counter-hash synthetic action stream generated on device (flatland_marl_amd/synth.py):
+ * kind 0 = uniform 0..4, 1 = forward-biased; env b uses stream id stream_base + b and its own step counter. */
+int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
+                  uint8_t *dones_dev, uint8_t *done_all_dev, int auto_reset);
+/* Synchronise and return the first error any kernel recorded (FL_OK if none); clears it. */
+int fl_check(fl_batch *h);
+
+/* flatland_cutils observation for all agents of all envs (device outputs):
+ * attr f32[B][A][83], forest f32[B][A][max_nodes][12], adjacency i32[B][A][max_nodes-1][3],
+ * node_order i32[B][A][max_nodes], edge_order i32[B][A][max_nodes-1], valid_actions u8[B][A][5],
+ * props f64[B][A][3] = (dist_target, deadlocked, ready_not_depart) (may be NULL). */
+int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev,
+                  int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
+                  uint8_t *valid_actions_dev, double *props_dev);
+/* upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)); pred_depth < 0: no predictor.
+ * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
+int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);
+
+/* Host read-backs (synchronising). state int32[B][A][FL_STATE_COLS]; elapsed int32[B]. */
+int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed);
+/* distance map of env b: returns number of unique targets in *n_targets; dm u16[n][H][W][4] (0xFFFF = inf),
+ * target_slot int32[A].  dm may be NULL to query n only. */
+int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot);
+/* RailEnv.agent_positions (rail_env.py:360-367) of env b: int32[H][W], -1 = free */
+int fl_positions_map(fl_batch *h, int b, int32_t *out);
+/* ALGORITHMIC bytes per agent-step the bench prices the roofline with, for the given obs mix */
+double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
