@@ -102,16 +102,16 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
 
 void fl_destroy(fl_batch *h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    for (void *p : h->allocs) hipFree(p);
-    hipStreamDestroy(h->own_stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
 int fl_set_stream(fl_batch *h, void *hip_stream) {
     if (!h) return FL_ERR_ARG;
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hipStream_t)hip_stream;  // NULL = HIP's default (null) stream, which is what torch uses by default
     return FL_OK;
 }
 

@@ -11,8 +11,10 @@ struct FlObsScratch {
     int pred_cap;      // waypoints kept per agent (pred_depth + 2)
     uint32_t *path;    // [B][A][pred_cap] predicted waypoints: cell << 2 | dir
     int *path_len;     // [B][A]
-    int *cell_head;    // [B][H*W + 1] CSR offsets of the per-cell prediction index
-    uint32_t *cell_items;  // [B][A * pred_cap] (agent << 16 | waypoint index)
+    int keys;          // prediction keys per env: (W - 1) * W + H (key = col * W + row, tool.h:391-398)
+    int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index
+    int *cell_cursor;  // [B][keys + 1] fill cursors
+    uint32_t *cell_items;  // [B][A * pred_cap] agent << 12 | waypoint << 2 | dir
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);

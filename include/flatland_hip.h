@@ -56,7 +56,8 @@ int fl_device_count(void);
 /* B envs, each A agents on an H x W grid, resident on HIP device `device`. */
 int fl_create(int B, int A, int H, int W, int device, fl_batch **out);
 void fl_destroy(fl_batch *h);
-/* run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own stream */
+/* run on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = HIP's default (null) stream.
+ * Until this is called the handle uses a private non-blocking stream. */
 int fl_set_stream(fl_batch *h, void *hip_stream);
 int fl_sync(fl_batch *h);
 
