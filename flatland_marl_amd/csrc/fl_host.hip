@@ -193,7 +193,7 @@ int fl_commit(fl_batch *h) {
     FlDev &d = h->d;
     d.Umax = Umax;
     DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
-    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B);
+    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4);
     DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
     DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
     DALLOC(d.spk, BA); DALLOC(d.speed, BA);
@@ -298,6 +298,14 @@ int fl_check(fl_batch *h) {
             return e;
         }
     }
+    return FL_OK;
+}
+
+int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset) {
+    NEED_COMMIT(h);
+    if (!out4_dev) { set_err("fl_metrics: null buffer"); return FL_ERR_ARG; }
+    fl_launch_metrics(h->d, (long long *)out4_dev, reset, h->stream);
+    HIPCHK(hipGetLastError());
     return FL_OK;
 }
 

@@ -46,6 +46,7 @@ struct FlDev {
     int *malf_min, *malf_max;
     int *U;
     int *err;  // [B] first error code raised by a kernel for env b (0 = none)
+    long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
     uint16_t *grid;  // [B][H*W]
     uint16_t *dm;    // [B][Umax][H*W][4]
     int *ut;         // [B][Umax] unique target cells
@@ -103,6 +104,7 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 
 // kernel launchers (defined in the .hip files)
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
+void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s);

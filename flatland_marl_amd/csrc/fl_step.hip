@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
     uint32_t a = ACT_NOTHING, np_dir = dir;
     int np_pos = pos;
     if (act) {
-        old_pos = pos; old_dir = (pos >= 0 || true) ? dir : old_dir;  // :521-522 (old_direction = direction always)
+        old_pos = pos; old_dir = dir;  // :521-522
         uint32_t raw = SYNTH ? synth_action(seed, stream_base + (uint32_t)b, (uint32_t)(t - 1), (uint32_t)i, synth_kind)
                              : (uint32_t)actions[g];
         if (raw > 4u) raw = ACT_NOTHING;  // absent (255) or illegal -> DO_NOTHING (:527, action_preprocessing.py:7-11)
@@ -352,6 +352,8 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
             reward = is_off_map(state) ? -travel : (latest - t) - travel;
         }
         done = 1;
+        if (reward != 0) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward);
+        if (state == ST_DONE) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull);
     }
 
     // ---- write back
@@ -375,6 +377,8 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
             d.t[b] = t;
             d.done_all[b] = ended ? 1 : 0;
             done_all_out[b] = ended ? 1 : 0;
+            d.metrics[(size_t)b * 4 + 2] += A;              // only this workgroup touches env b's counters
+            if (ended) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
             if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
         }
     }
@@ -392,6 +396,25 @@ __global__ void k_reset(FlDev d, const uint8_t *mask, int fresh) {
     d.malf[g] = 0;
     d.pk[g] = pk_make(init_dir, 4, ST_WAITING, 7, 0, 0, 0, 0, 0);
     if (g == b * d.A) { d.t[b] = 0; d.done_all[b] = 0; }
+}
+
+__global__ void k_metrics(FlDev d, long long *out4, int reset) {
+    // Σ over envs of (terminal rewards, arrived agents, agent-steps, episodes); one workgroup, wave reduction
+    long long acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < d.B; b += blockDim.x)
+        for (int k = 0; k < 4; k++) {
+            acc[k] += d.metrics[(size_t)b * 4 + k];
+            if (reset) d.metrics[(size_t)b * 4 + k] = 0;
+        }
+    for (int k = 0; k < 4; k++) {
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        if ((threadIdx.x & 63) == 0 && acc[k] != 0) atomicAdd((unsigned long long *)&out4[k], (unsigned long long)acc[k]);
+    }
+}
+
+void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s) {
+    (void)hipMemsetAsync(out4, 0, 4 * sizeof(long long), s);
+    hipLaunchKernelGGL(k_metrics, dim3(1), dim3(256), 0, s, d, out4, reset);
 }
 
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s) {

@@ -1,0 +1,55 @@
+"""Multi-GPU harness pieces: one process per GPU, envs sharded contiguously across ranks (no data-path
+collective: envs are independent), one all-reduce(SUM) of the int64[4] episode metrics and one
+all-reduce(MAX) of the timed region per measurement window.  backend "nccl" is RCCL on ROCm; the
+same code runs on "gloo"/CPU tensors in the tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """returns (rank, world_size, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_range(n_total, rank, world):
+    """contiguous shard [lo, hi) of n_total envs for this rank (the remainder goes to the first ranks)."""
+    q, r = divmod(n_total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_metrics(metrics):
+    """all-reduce(SUM) of the int64[4] metrics tensor (sum reward, arrived, agent-steps, episodes)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+    return metrics
+
+
+def max_over_ranks(seconds, device=None):
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -25,7 +25,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
-           "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_positions_map",
+           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -72,6 +72,7 @@ def lib():
         L.fl_step.argtypes = [vp, vp, vp, vp, vp, i32]
         L.fl_step_synth.argtypes = [vp, u32, u32, i32, vp, vp, vp, i32]
         L.fl_check.argtypes = [vp]
+        L.fl_metrics.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
         L.fl_get_state.argtypes = [vp, vp, vp]
@@ -187,6 +188,13 @@ class BatchedRailEnv:
         _chk(lib().fl_step_synth(self.h, int(seed), int(stream_base), int(kind), self.rewards.data_ptr(),
                                  self.dones.data_ptr(), self.done_all.data_ptr(), int(auto_reset)))
         return self.rewards, self.dones, self.done_all
+
+    def metrics(self, reset=False):
+        """int64[4] device tensor: (sum terminal rewards, arrived agents, agent-steps, finished episodes)."""
+        if not hasattr(self, "_metrics"):
+            self._metrics = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
+        _chk(lib().fl_metrics(self.h, self._metrics.data_ptr(), int(reset)))
+        return self._metrics
 
     def check(self):
         _chk(lib().fl_check(self.h))

@@ -88,6 +88,10 @@ int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8
  * kind 0 = uniform 0..4, 1 = forward-biased; env b uses stream id stream_base + b and its own step counter. */
 int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
                   uint8_t *dones_dev, uint8_t *done_all_dev, int auto_reset);
+/* Running sums over all envs since the last reset of the counters, written to out4_dev int64[4] (device):
+ * (sum of terminal rewards, arrived agents, agent-steps, finished episodes) -- the scalars the multi-GPU
+ * harness all-reduces; mirrors eval_env.final_metric's inputs (solution/eval_env.py:81-94). */
+int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset);
 /* Synchronise and return the first error any kernel recorded (FL_OK if none); clears it. */
 int fl_check(fl_batch *h);
 
