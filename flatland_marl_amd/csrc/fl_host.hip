@@ -390,8 +390,8 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
 
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     NEED_COMMIT(h);
-    if (max_depth < 1 || max_depth > 4 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
-        set_err("fl_obs_tree: max_depth must be in [1,4], pred_depth <= %d", FL_OBS_MAX_PRED);
+    if (max_depth < 1 || max_depth > 3 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
+        set_err("fl_obs_tree: max_depth must be in [1,3], pred_depth <= %d", FL_OBS_MAX_PRED);
         return FL_ERR_ARG;
     }
     int rc = fl_launch_obs_tree(h->obs, h->d, max_depth, pred_depth, out_dev, h->stream);

@@ -4,7 +4,7 @@
 
 #include "fl_internal.h"
 
-#define FL_OBS_MAX_NODES 64
+#define FL_OBS_MAX_NODES 33  /* one BFS level of a tree is explored by a 32-lane group */
 #define FL_OBS_MAX_PRED 500
 
 struct FlObsScratch {
@@ -12,9 +12,8 @@ struct FlObsScratch {
     uint32_t *path;    // [B][A][pred_cap] predicted waypoints: cell << 2 | dir
     int *path_len;     // [B][A]
     int keys;          // prediction keys per env: (W - 1) * W + H (key = col * W + row, tool.h:391-398)
-    int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index
-    int *cell_cursor;  // [B][keys + 1] fill cursors
-    uint32_t *cell_items;  // [B][A * pred_cap] agent << 12 | waypoint << 2 | dir
+    int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index (used when they do not fit LDS)
+    uint32_t *cell_items;  // [B][A * pred_cap] agent << 20 | t_lo << 11 | t_hi << 2 | dir
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);

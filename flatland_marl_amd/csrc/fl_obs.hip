@@ -21,15 +21,25 @@
 
 #include "../../include/flatland_hip.h"
 
-#define OBS_NT 512
+#define OBS_NT 1024
 #define OBS_WAVES (OBS_NT / 64)
+#define OBS_GROUPS (OBS_WAVES * 2)   // cutils trees: two agents per wavefront, 32 lanes each (max_nodes <= 33)
+#define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
+
+// prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
+//   bits 0-1 direction, 2-10 t_hi, 11-19 t_lo, 20-29 agent
+#define IT_DIR(it) ((it)&3u)
+#define IT_THI(it) (((it) >> 2) & 511u)
+#define IT_TLO(it) (((it) >> 11) & 511u)
+#define IT_AGENT(it) ((int)((it) >> 20))
 
 // ---------------------------------------------------------------------------------------------- context
 struct ObsCtx {
     int A, H, W, HW, K;           // K = number of prediction keys (col * W + row), tool.h:391-398
     const uint16_t *grid;         // LDS
-    const int16_t *cell_agent;    // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
-    const uint16_t *cell_ready;   // LDS: number of off-map agents whose initial position is the cell
+    const uint16_t *cell_slot;    // LDS: index of the cell's entry in the occupied-cell table, 0xFFFF = nothing there
+    const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
+    const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
     const uint32_t *cell_target;  // LDS bitmap: some agent's target (upstream location_has_target)
     const int *a_vpos;            // LDS per agent: virtual position (cell)
     const uint8_t *a_dir, *a_state;
@@ -41,8 +51,8 @@ struct ObsCtx {
     const int *a_target;
     const uint32_t *path;         // HBM [A][pcap] cell << 2 | dir
     int pcap;
-    const int *csr_head;          // HBM [K + 1]
-    const uint32_t *csr_items;    // HBM: agent << 12 | waypoint << 2 | dir
+    const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
+    const uint32_t *csr_items;    // HBM: IT_* packed items
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // HBM env base [Umax][HW][4]
 };
@@ -112,12 +122,13 @@ __device__ void explore_branch(const ObsCtx &X, int handle, int cell, uint32_t d
     const int max_visits = 4 * X.HW + 4;
     int visit = 0;
     while (true) {
-        const int ag = X.cell_agent[cell];
+        const uint32_t sl = X.cell_slot[cell];
+        const int ag = sl != 0xFFFFu ? X.slot_agent[sl] : -1;
         if (ag >= 0) {  // treeobs.cpp:322-357
             if ((double)tot_dist < other_agent) other_agent = tot_dist;
             const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
             if (mf > malfunctioning) malfunctioning = mf;
-            const int rd = X.cell_ready[cell];
+            const int rd = X.slot_ready[sl];
             if (rd > 0) ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
             if (X.a_dir[ag] == d) {
                 same_dir += 1;
@@ -133,34 +144,45 @@ __device__ void explore_branch(const ObsCtx &X, int handle, int cell, uint32_t d
         const bool crossing = g == 0x8421u;
         if (X.Tn > 0) {  // potential conflict (treeobs.cpp:378-465 / observations.py:329-367)
             const int pt = CUTILS ? (int)((float)tot_dist * tpc_f) : (int)((double)tot_dist * tpc_d);
-            if (pt < X.Tn && tot_dist < X.Tn) {
+            if (pt < X.Tn && tot_dist < X.Tn && !((double)tot_dist >= pot_conflict)) {
                 const int r = cell / W, c = cell - r * W;
                 const int key = c * W + r;
-                const int lo = X.csr_head[key], hi = X.csr_head[key + 1];
+                const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
                 if (hi > lo) {
-                    const int pre = max(pt - 1, 0), post = min(pt + 1, X.Tn - 1);
-                    int sel = -1;
-                    for (int k = 0; k < 3 && sel < 0; k++) {  // some OTHER agent predicted on this key at that time
-                        const int ts = k == 0 ? pt : (k == 1 ? pre : post);
-                        for (int e = lo; e < hi; e++) {
-                            const uint32_t it = X.csr_items[e];
-                            const int a = (int)(it >> 12);
-                            if (a != handle && waypoint_at<CUTILS>(X, a, ts) == (int)((it >> 2) & 1023u)) { sel = ts; break; }
+                    const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
+                    // one pass: is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted
+                    // there (self included) satisfy the conflict condition
+                    bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
+                    for (int e = lo; e < hi; e++) {
+                        const uint32_t it = X.csr_items[e];
+                        const uint32_t tl = IT_TLO(it), th = IT_THI(it);
+                        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+                        if (!(in0 | in1 | in2)) continue;
+                        const int a = IT_AGENT(it);
+                        const uint32_t cd = IT_DIR(it);
+                        const bool oth = a != handle;
+                        const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
+                        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
+                        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                    }
+                    bool hit = false;
+                    if (other0) hit = cond0;
+                    else if (other1 | other2) {
+                        const uint32_t sel = other1 ? t1 : t2;
+                        if (!CUTILS) hit = other1 ? cond1 : cond2;
+                        else {
+                            // cutils indexes predicted_dir with predicted_time in the pre/post branches
+                            // (treeobs.cpp:429-433, 449-453): look the direction at t0 up in the agent's path
+                            for (int e = lo; e < hi; e++) {
+                                const uint32_t it = X.csr_items[e];
+                                if (!(IT_TLO(it) <= sel && sel <= IT_THI(it))) continue;
+                                const int a = IT_AGENT(it);
+                                const uint32_t cd = X.path[(size_t)a * X.pcap + waypoint_at<true>(X, a, pt)] & 3u;
+                                if ((d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE) hit = true;
+                            }
                         }
                     }
-                    if (sel >= 0) {
-                        for (int e = lo; e < hi; e++) {  // every agent (self included) predicted on this key at `sel`
-                            const uint32_t it = X.csr_items[e];
-                            const int a = (int)(it >> 12);
-                            if (waypoint_at<CUTILS>(X, a, sel) != (int)((it >> 2) & 1023u)) continue;
-                            uint32_t cd = it & 3u;
-                            if (CUTILS && sel != pt)  // cutils indexes predicted_dir with predicted_time (treeobs.cpp:429-433,449-453)
-                                cd = X.path[(size_t)a * X.pcap + waypoint_at<CUTILS>(X, a, pt)] & 3u;
-                            if (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u) && (double)tot_dist < pot_conflict)
-                                pot_conflict = tot_dist;
-                            if (X.a_state[a] == ST_DONE && (double)tot_dist < pot_conflict) pot_conflict = tot_dist;
-                        }
-                    }
+                    if (hit) pot_conflict = tot_dist;
                 }
             }
         }
@@ -265,7 +287,7 @@ struct ObsArgs {
     int n_tree_nodes;
 };
 
-template <int MODE>
+template <int MODE, bool CSR_LDS>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
     constexpr bool CUTILS = MODE == 0;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -277,8 +299,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     size_t off = 0;
     auto carve = [&](size_t bytes) { void *p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
     uint16_t *grid = (uint16_t *)carve((size_t)HW * 2);
-    int16_t *cell_agent = (int16_t *)carve((size_t)HW * 2);
-    uint16_t *cell_ready = (uint16_t *)carve((size_t)HW * 2);
+    uint16_t *cell_slot = (uint16_t *)carve((size_t)HW * 2);
+    int *slot_agent = (int *)carve((size_t)A * 4);
+    int *slot_ready = (int *)carve((size_t)A * 4);
     uint32_t *cell_target = (uint32_t *)carve((size_t)((HW + 31) / 32) * 4);
     double *a_speed = (double *)carve((size_t)A * 8);
     int *a_vpos = (int *)carve((size_t)A * 4);
@@ -293,13 +316,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
-    int *wave_par = (int *)carve((size_t)OBS_WAVES * 64 * 4);  // per-wave parent[] scratch for the evaluation orders
+    int *grp_par = (int *)carve((size_t)OBS_GROUPS * 64 * 4);  // per-group parent[] / height[] scratch (evaluation orders)
+    int *partial = (int *)carve((size_t)OBS_NT * 4);           // scan scratch
+    int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
 
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
-    for (int c = tid; c < HW; c += nt) { grid[c] = ggrid[c]; cell_agent[c] = -1; cell_ready[c] = 0; }
+    for (int c = tid; c < HW; c += nt) { grid[c] = ggrid[c]; cell_slot[c] = 0xFFFFu; }
+    for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
     __syncthreads();
@@ -322,26 +348,28 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         (void)spk;
     }
     __syncthreads();
-    // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91)
+    // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
+    // Occupied cells get an entry in a small table; the dense per-cell array only holds the entry index.
     for (int i = tid; i < A; i += nt) {
         const uint32_t state = a_state[i];
-        if (!is_off_map(state) && a_pos[i] >= 0) {
-            // 16-bit atomic max emulated on the containing 32-bit word
-            const int c = a_pos[i];
-            unsigned int *wptr = (unsigned int *)(cell_agent) + (c >> 1);
+        const bool on = !is_off_map(state) && a_pos[i] >= 0, off = is_off_map(state);
+        if (on || off) {
+            const int c = on ? a_pos[i] : d.init_pos[b * A + i];
+            unsigned int *wptr = (unsigned int *)(cell_slot) + (c >> 1);
             const int sh = (c & 1) * 16;
-            unsigned int old = *wptr, assumed;
-            do {
-                assumed = old;
-                const int16_t cur = (int16_t)((assumed >> sh) & 0xFFFFu);
-                if (cur >= (int16_t)i) break;
-                const unsigned int nw = (assumed & ~(0xFFFFu << sh)) | (((unsigned int)(uint16_t)i) << sh);
-                old = atomicCAS(wptr, assumed, nw);
-            } while (old != assumed);
-        }
-        if (is_off_map(state)) {
-            const int c = d.init_pos[b * A + i];
-            atomicAdd((unsigned int *)cell_ready + (c >> 1), 1u << ((c & 1) * 16));
+            int slot = -1;
+            unsigned int cur = *(volatile unsigned int *)wptr;
+            while (true) {  // claim (or find) the cell's table entry: 16-bit CAS on the containing 32-bit word
+                const unsigned int have = (cur >> sh) & 0xFFFFu;
+                if (have != 0xFFFFu) { slot = (int)have; break; }
+                if (slot < 0) slot = atomicAdd(&misc[1], 1);
+                const unsigned int nw = (cur & ~(0xFFFFu << sh)) | ((unsigned int)slot << sh);
+                const unsigned int old = atomicCAS(wptr, cur, nw);
+                if (old == cur) break;
+                cur = old;
+            }
+            if (on) atomicMax(&slot_agent[slot], i);
+            else atomicAdd(&slot_ready[slot], 1);
         }
         if (!CUTILS) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
     }
@@ -349,15 +377,14 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 
     ObsCtx X;
     X.A = A; X.H = H; X.W = W; X.HW = HW; X.K = K;
-    X.grid = grid; X.cell_agent = cell_agent; X.cell_ready = cell_ready; X.cell_target = cell_target;
+    X.grid = grid; X.cell_slot = cell_slot; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_lp = a_lp; X.a_tslot = a_tslot; X.a_target = a_target;
     X.pcap = S.pred_cap;
     X.path = S.path + (size_t)b * A * S.pred_cap;
-    int *csr_head = S.cell_head + (size_t)b * (S.keys + 1);
-    int *csr_cursor = S.cell_cursor + (size_t)b * (S.keys + 1);
+    int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
-    X.csr_head = csr_head; X.csr_items = csr_items;
+    X.csr_end = csr; X.csr_items = csr_items;
     X.Tn = P.pred_depth >= 0 ? P.pred_depth + 1 : 0;
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
@@ -375,7 +402,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 for (uint32_t m = 0; m < 4 && !fr; m++) {
                     if (!((bits >> (3 - m)) & 1)) continue;
                     const int nr = r + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = c + (m == 1 ? 1 : m == 3 ? -1 : 0);
-                    if (nr < 0 || nc < 0 || nr >= H || nc >= W || cell_agent[nr * W + nc] < 0) fr = true;
+                    if (nr < 0 || nc < 0 || nr >= H || nc >= W) { fr = true; continue; }
+                    const uint32_t sl = cell_slot[nr * W + nc];
+                    if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
                 }
             }
             a_free[i] = fr;
@@ -388,7 +417,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     bool fr = false;
                     for (uint32_t m = 0; m < 4 && !fr; m++) {
                         if (!((bits >> (3 - m)) & 1)) continue;
-                        const int opp = cell_agent[step_cell(a_pos[i], m, W)];
+                        const uint32_t sl = cell_slot[step_cell(a_pos[i], m, W)];
+                        const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
                         if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
                     }
                     if (fr) { a_free[i] = 1; misc[0] = 1; }
@@ -495,9 +525,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         }
     }
 
-    // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint)
+    // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
     if (X.Tn > 0) {
-        for (int k = tid; k <= K; k += nt) csr_head[k] = 0;
+        for (int k = tid; k <= K; k += nt) csr[k] = 0;
         __syncthreads();
         const int pred_depth = P.pred_depth;
         for (int i = tid; i < A; i += nt) {
@@ -526,13 +556,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                             if (v != FL_INF16 && v < distance) { best = (int)ex; distance = v; }
                         }
                     } else {
-                        for (int j = -1; j <= 1; j++) {  // L, F, R: the reference's iteration order decides ties
-                            const uint32_t nd = (dd + (uint32_t)(j + 4)) & 3u;
-                            if ((bits >> (3 - nd)) & 1) {
-                                const uint32_t v = X.dm[(dmb + step_cell(cell, nd, W)) * 4 + nd];
-                                if (v != FL_INF16 && v < distance) { best = (int)nd; distance = v; }
-                            }
+                        // L, F, R: the reference's iteration order decides ties; the three gathers are independent
+                        uint32_t v3[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const uint32_t nd = (dd + (uint32_t)(j + 3)) & 3u;
+                            v3[j] = ((bits >> (3 - nd)) & 1) ? (uint32_t)X.dm[(dmb + step_cell(cell, nd, W)) * 4 + nd] : FL_INF16;
                         }
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (v3[j] != FL_INF16 && v3[j] < distance) { best = (int)((dd + (uint32_t)(j + 3)) & 3u); distance = v3[j]; }
                     }
                     path[n++] = ((uint32_t)cell << 2) | dd;
                     depth++;
@@ -556,57 +589,80 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             for (int k = 0; k <= lp; k++) {
                 const int c = (int)(path[k] >> 2);
                 const int r = c / W, col = c - r * W;
-                atomicAdd(&csr_head[col * W + r], 1);
+                atomicAdd(&csr[col * W + r], 1);
             }
         }
         __syncthreads();
-        // exclusive scan over K + 1 keys: per-thread chunk sums, serial scan of the nt partial sums, rescan
+        // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan
         {
-            int *partial = (int *)wave_par;  // reuse (>= OBS_NT ints)
             const int chunk = (K + 1 + nt - 1) / nt;
             const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
-            int s = 0;
-            for (int k = lo; k < hi; k++) s += csr_head[k];
-            partial[tid] = s;
+            int sum = 0;
+            for (int k = lo; k < hi; k++) sum += csr[k];
+            partial[tid] = sum;
             __syncthreads();
-            if (tid == 0) {
-                int run = 0;
-                for (int k = 0; k < nt; k++) { const int v = partial[k]; partial[k] = run; run += v; }
+            if (wave == 0) {
+                // each lane of wave 0 owns OBS_NT / 64 consecutive partials
+                constexpr int PER = OBS_NT / 64;
+                int loc[PER], tot = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { loc[q] = partial[lane * PER + q]; tot += loc[q]; }
+                int incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+                int run = incl - tot;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { partial[lane * PER + q] = run; run += loc[q]; }
             }
             __syncthreads();
             int run = partial[tid];
-            for (int k = lo; k < hi; k++) { const int v = csr_head[k]; csr_head[k] = run; csr_cursor[k] = run; run += v; }
+            for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
         }
         __syncthreads();
+        // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1])
         for (int i = tid; i < A; i += nt) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
-            const int lp = a_lp[i];
+            const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             for (int k = 0; k <= lp; k++) {
                 const uint32_t w = path[k];
                 const int c = (int)(w >> 2);
                 const int r = c / W, col = c - r * W;
-                const int slot = atomicAdd(&csr_cursor[col * W + r], 1);
-                csr_items[slot] = ((uint32_t)i << 12) | ((uint32_t)k << 2) | (w & 3u);
+                // closed time interval during which the agent is predicted on waypoint k
+                int tlo, thi;
+                if (CUTILS) {  // w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp) afterwards
+                    tlo = k == 0 ? 0 : (k - 1) * tpc + 1;
+                    thi = k == lp ? tlast : (k == 0 ? 0 : k * tpc);
+                } else {       // w(t) = min(t / tpc, lp)
+                    tlo = k * tpc;
+                    thi = k == lp ? tlast : (k + 1) * tpc - 1;
+                }
+                const int slot = atomicAdd(&csr[col * W + r], 1);
+                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)min(thi, tlast) << 2) | (w & 3u);
             }
         }
         __syncthreads();
     }
 
-    // ---- phase 3: trees, one wavefront per agent
+    // ---- phase 3: trees
     const float max_dist = (float)T;
-    for (int i = wave; i < A; i += OBS_WAVES) {
-        const int g = b * A + i;
-        const int vpos = a_vpos[i];
-        const uint32_t dir = a_dir[i];
-        const uint32_t rbits = nibble(grid[vpos], dir);
-        uint32_t orientation = dir;
-        if (__popc(rbits) == 1) orientation = first_dir(rbits);
-        if (CUTILS) {
-            const int N = P.max_nodes;
+    if (CUTILS) {
+        // two agents per wavefront: a 32-lane group explores one BFS level of its agent's tree at a time
+        const int grp = lane >> 5, gl = lane & 31;
+        const int N = P.max_nodes;
+        int *par = grp_par + (wave * 2 + grp) * 64;  // [0,32) parent of node k, [32,64) height of node k
+        for (int base = 0; base < A; base += OBS_GROUPS) {
+            const int i = base + wave * 2 + grp;
+            const bool have = i < A;
+            const int ia = have ? i : 0;
+            const int g = b * A + ia;
+            const int vpos = a_vpos[ia];
+            const uint32_t dir = a_dir[ia];
+            const uint32_t rbits = nibble(grid[vpos], dir);
+            uint32_t orientation = dir;
+            if (__popc(rbits) == 1) orientation = first_dir(rbits);
             float *F = P.forest + (size_t)g * N * 12;
             int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
-            volatile int *par = wave_par + wave * 64;
-            if (lane == 0) {  // root (treeobs.cpp:171-186)
+            if (have && gl == 0) {  // root (treeobs.cpp:171-186)
                 const uint32_t state = a_state[i];
                 double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 uint16_t dv = FL_INF16;
@@ -618,21 +674,24 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 root[10] = (double)(float)a_speed[i];
                 scale_and_store(root, max_dist, A, F);
             }
-            if (lane < 64) par[lane] = -2;
+            par[gl] = -2;
+            par[32 + gl] = 0;
             // level 1: three cells from the root (treeobs.cpp:205-222)
             int c_cell = -1, c_parent = 0, c_tot = 1, c_act = 0;
             uint32_t c_dir = 0;
             bool c_null = true;
-            if (lane < 3) {
-                c_act = lane - 1;
+            if (gl < 3) {
+                c_act = gl - 1;
                 c_dir = (orientation + (uint32_t)(c_act + 4)) & 3u;
                 if ((rbits >> (3 - c_dir)) & 1) { c_cell = step_cell(vpos, c_dir, W); c_null = false; }
             }
             int n_cur = 3, node_base = 1;
-            while (node_base < N && n_cur > 0) {
-                const int m = min(n_cur, N - node_base);
-                const bool mine = lane < m;
-                const int idx_node = node_base + lane;
+            while (true) {
+                const bool active = have && node_base < N && n_cur > 0;
+                if (!__any(active)) break;  // wave-uniform: both groups take part in the shuffles below
+                const int m = active ? min(n_cur, N - node_base) : 0;
+                const bool mine = gl < m;
+                const int idx_node = node_base + gl;
                 // children descriptors this lane would push (treeobs.cpp:583-608)
                 int ch_cell[3] = {-1, -1, -1};
                 uint32_t ch_dir[3] = {0, 0, 0};
@@ -650,6 +709,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                         explored = true;
                         ch_tot = br.tot_dist + 1;
                         const uint32_t pbits = nibble(grid[br.end_cell], br.end_dir);
+#pragma unroll
                         for (int k = 0; k < 3; k++) {
                             const uint32_t bd = (br.end_dir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
                             ch_dir[k] = bd;
@@ -661,49 +721,69 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     adj[0] = c_parent; adj[1] = idx_node; adj[2] = c_act;
                     par[idx_node] = c_parent;
                 }
-                const uint64_t exp_mask = __ballot(explored);
-                const int n_next = 3 * __popcll(exp_mask);
+                const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
+                const int n_next = 3 * __popc(exp_mask);
                 // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
-                const int src_rank = lane / 3, which = lane - 3 * src_rank;
-                const int src = (lane < n_next) ? kth_set_bit(exp_mask, src_rank) : 0;
-                const int s_c0 = __shfl(ch_cell[0], src), s_c1 = __shfl(ch_cell[1], src), s_c2 = __shfl(ch_cell[2], src);
-                const uint32_t s_d0 = __shfl(ch_dir[0], src), s_d1 = __shfl(ch_dir[1], src), s_d2 = __shfl(ch_dir[2], src);
-                const int s_tot = __shfl(ch_tot, src);
-                node_base += m;
-                n_cur = n_next;
-                if (lane < n_next) {
-                    c_cell = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
-                    c_dir = which == 0 ? s_d0 : (which == 1 ? s_d1 : s_d2);
-                    c_null = c_cell < 0;
-                    c_parent = (node_base - m) + src;
-                    c_tot = s_tot;
-                    c_act = which - 1;
+                const int src_rank = gl / 3, which = gl - 3 * src_rank;
+                const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
+                const int s_c0 = __shfl(ch_cell[0], src, 32), s_c1 = __shfl(ch_cell[1], src, 32), s_c2 = __shfl(ch_cell[2], src, 32);
+                const uint32_t s_d0 = __shfl(ch_dir[0], src, 32), s_d1 = __shfl(ch_dir[1], src, 32), s_d2 = __shfl(ch_dir[2], src, 32);
+                const int s_tot = __shfl(ch_tot, src, 32);
+                if (active) {
+                    const int parent_base = node_base;
+                    node_base += m;
+                    n_cur = n_next;
+                    if (gl < n_next) {
+                        c_cell = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
+                        c_dir = which == 0 ? s_d0 : (which == 1 ? s_d1 : s_d2);
+                        c_null = c_cell < 0;
+                        c_parent = parent_base + src;
+                        c_tot = s_tot;
+                        c_act = which - 1;
+                    }
                 }
             }
-            // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
-            for (int idx = node_base + lane; idx < N; idx += 64) {
-                const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
-                adj[0] = adj[1] = adj[2] = -2;
+            if (have) {
+                // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
+                for (int idx = node_base + gl; idx < N; idx += 32) {
+                    const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                    scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+                    adj[0] = adj[1] = adj[2] = -2;
+                }
             }
-            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede children
-            // in BFS numbering, so one reverse sweep settles it
-            int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
+            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
+            // children in BFS numbering, so one reverse sweep settles it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                int h[FL_OBS_MAX_NODES];
-                for (int k = 0; k < N; k++) h[k] = 0;
+            if (have && gl == 0) {
+                volatile int *vp = par;
                 for (int k = N - 1; k >= 1; k--) {
-                    const int p = par[k];
-                    if (p >= 0 && h[p] < h[k] + 1) h[p] = h[k] + 1;
+                    const int p = vp[k];
+                    if (p >= 0) { const int hk = vp[32 + k] + 1; if (vp[32 + p] < hk) vp[32 + p] = hk; }
                 }
-                const int n_real = node_base;  // real (non padding) nodes
-                for (int k = 0; k < N; k++) NO[k] = k < n_real ? h[k] : -2;
-                for (int k = 1; k < N; k++) EO[k - 1] = par[k] < 0 ? -2 : h[par[k]];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (have) {
+                int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
+                volatile int *vp = par;
+                for (int k = gl; k < N; k += 32) {
+                    NO[k] = k < node_base ? vp[32 + k] : -2;
+                    if (k >= 1) { const int p = vp[k]; EO[k - 1] = p < 0 ? -2 : vp[32 + p]; }
+                }
             }
             __builtin_amdgcn_wave_barrier();
-        } else {
+        }
+    }
+    for (int i = wave; !CUTILS && i < A; i += OBS_WAVES) {
+        const int g = b * A + i;
+        const int vpos = a_vpos[i];
+        const uint32_t dir = a_dir[i];
+        const uint32_t rbits = nibble(grid[vpos], dir);
+        uint32_t orientation = dir;
+        if (__popc(rbits) == 1) orientation = first_dir(rbits);
+        {
             // upstream dense tree, DFS pre-order layout; level L is explored by 4^L lanes (observations.py:196-254, 464-494)
             const int D = P.max_depth, NN = P.n_tree_nodes;
             double *out = P.tree_out + (size_t)g * NN * 12;
@@ -786,8 +866,6 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
-    o.cell_cursor = (int *)p; allocs.push_back(p);
     (void)s;
     return FL_OK;
 }
@@ -798,46 +876,48 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
+    const size_t K = (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 2) * 3 + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 4 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
-           al((size_t)OBS_WAVES * 64 * 4) + 64;
+    return al(HW * 2) * 2 + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
+           al((size_t)OBS_GROUPS * 64 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) + 64;
+}
+
+static bool obs_pick_csr_lds(const FlDev &d) {
+    const size_t K = (size_t)(d.W - 1) * d.W + d.H;
+    return K <= OBS_CSR_LDS_MAX_KEYS && obs_lds_bytes(d, true) <= 160 * 1024;
+}
+
+template <typename KernelT>
+static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, size_t lds, hipStream_t s) {
+    if (lds > 160 * 1024) return FL_ERR_ARG;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(d.B), dim3(OBS_NT), lds, s, d, o, P);
+    return FL_OK;
 }
 
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                          hipStream_t s) {
-    const size_t lds = obs_lds_bytes(d);
-    if (lds > 160 * 1024) return FL_ERR_ARG;
-    if (d.A >= (1 << 20) || pred_depth + 2 > o.pred_cap) return FL_ERR_ARG;
-    ObsArgs P;
-    ObsArgs Z = {};
-    P = Z;
+    if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
+    ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
-        if (hipFuncSetAttribute((const void *)k_obs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_obs<0>, dim3(d.B), dim3(OBS_NT), lds, s, d, o, P);
-    return FL_OK;
+    const bool csr_lds = obs_pick_csr_lds(d);
+    const size_t lds = obs_lds_bytes(d, csr_lds);
+    return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, s) : obs_launch(k_obs<0, false>, d, o, P, lds, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
-    const size_t lds = obs_lds_bytes(d);
-    if (lds > 160 * 1024) return FL_ERR_ARG;
-    if (pred_depth + 2 > o.pred_cap) return FL_ERR_ARG;
-    ObsArgs P;
-    ObsArgs Z = {};
-    P = Z;
+    if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
+    if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
+    ObsArgs P = {};
     P.max_depth = max_depth; P.pred_depth = pred_depth; P.tree_out = out;
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;
-    if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
-    hipLaunchKernelGGL(k_obs<1>, dim3(d.B), dim3(OBS_NT), lds, s, d, o, P);
-    return FL_OK;
+    const bool csr_lds = obs_pick_csr_lds(d);
+    const size_t lds = obs_lds_bytes(d, csr_lds);
+    return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, s) : obs_launch(k_obs<1, false>, d, o, P, lds, s);
 }
