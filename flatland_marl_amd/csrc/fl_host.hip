@@ -400,6 +400,14 @@ int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     return FL_OK;
 }
 
+// diagnostic (not part of the public header): copy the per-env phase clocks of a -DFL_OBS_TIMING build
+extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][8] */) {
+    NEED_COMMIT(h);
+    HIPCHK(hipMemcpyAsync(out, h->obs.dbg, (size_t)h->B * 8 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FL_OK;
+}
+
 double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {
     if (!h) return 0.0;
     // DESIGN.md "algorithmic bytes": compulsory HBM traffic per agent-step with this SoA.

@@ -25,6 +25,7 @@
 #define OBS_WAVES (OBS_NT / 64)
 #define OBS_GROUPS (OBS_WAVES * 2)   // cutils trees: two agents per wavefront, 32 lanes each (max_nodes <= 33)
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
+#define OBS_ITEMS_LDS_CAP 8192       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction, 2-10 t_hi, 11-19 t_lo, 20-29 agent
@@ -153,17 +154,24 @@ __device__ void explore_branch(const ObsCtx &X, int handle, int cell, uint32_t d
                     // one pass: is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted
                     // there (self included) satisfy the conflict condition
                     bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
-                    for (int e = lo; e < hi; e++) {
-                        const uint32_t it = X.csr_items[e];
-                        const uint32_t tl = IT_TLO(it), th = IT_THI(it);
-                        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
-                        if (!(in0 | in1 | in2)) continue;
-                        const int a = IT_AGENT(it);
-                        const uint32_t cd = IT_DIR(it);
-                        const bool oth = a != handle;
-                        const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
-                        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
-                        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                    for (int e0 = lo; e0 < hi; e0 += 4) {
+                        uint32_t itv[4];  // four independent loads in flight
+#pragma unroll
+                        for (int q = 0; q < 4; q++) itv[q] = X.csr_items[min(e0 + q, hi - 1)];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            if (e0 + q >= hi) break;
+                            const uint32_t it = itv[q];
+                            const uint32_t tl = IT_TLO(it), th = IT_THI(it);
+                            const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+                            if (!(in0 | in1 | in2)) continue;
+                            const int a = IT_AGENT(it);
+                            const uint32_t cd = IT_DIR(it);
+                            const bool oth = a != handle;
+                            const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
+                            other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
+                            cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                        }
                     }
                     bool hit = false;
                     if (other0) hit = cond0;
@@ -285,6 +293,7 @@ struct ObsArgs {
     double *props;
     double *tree_out;
     int n_tree_nodes;
+    long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
 };
 
 template <int MODE, bool CSR_LDS>
@@ -319,9 +328,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     int *grp_par = (int *)carve((size_t)OBS_GROUPS * 64 * 4);  // per-group parent[] / height[] scratch (evaluation orders)
     int *partial = (int *)carve((size_t)OBS_NT * 4);           // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
+    uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
+#ifdef FL_OBS_TIMING
+#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define OBS_STAMP(k) do {} while (0)
+#endif
+    OBS_STAMP(0);
 
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
     for (int c = tid; c < HW; c += nt) { grid[c] = ggrid[c]; cell_slot[c] = 0xFFFFu; }
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     X.Tn = P.pred_depth >= 0 ? P.pred_depth + 1 : 0;
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
+    OBS_STAMP(1);
     // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows
     if (CUTILS) {
         // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
@@ -525,6 +542,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         }
     }
 
+    OBS_STAMP(2);
     // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
     if (X.Tn > 0) {
         for (int k = tid; k <= K; k += nt) csr[k] = 0;
@@ -593,6 +611,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             }
         }
         __syncthreads();
+        OBS_STAMP(3);
         // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan
         {
             const int chunk = (K + 1 + nt - 1) / nt;
@@ -617,8 +636,10 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             __syncthreads();
             int run = partial[tid];
             for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
+            if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
         }
         __syncthreads();
+        if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1])
         for (int i = tid; i < A; i += nt) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
@@ -643,6 +664,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         __syncthreads();
     }
 
+    OBS_STAMP(4);
     // ---- phase 3: trees
     const float max_dist = (float)T;
     if (CUTILS) {
@@ -852,6 +874,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             }
         }
     }
+    OBS_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -866,6 +889,8 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
+    if (hipMalloc(&p, (size_t)d.B * 8 * 8) != hipSuccess) return FL_ERR_HIP;
+    o.dbg = (long long *)p; allocs.push_back(p);
     (void)s;
     return FL_OK;
 }
@@ -881,7 +906,8 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds) {
     const size_t K = (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 2) * 2 + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
-           al((size_t)OBS_GROUPS * 64 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) + 64;
+           al((size_t)OBS_GROUPS * 64 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
+           al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
 }
 
 static bool obs_pick_csr_lds(const FlDev &d) {
@@ -903,7 +929,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
-    P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props;
+    P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     const bool csr_lds = obs_pick_csr_lds(d);
     const size_t lds = obs_lds_bytes(d, csr_lds);
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, s) : obs_launch(k_obs<0, false>, d, o, P, lds, s);
@@ -913,7 +939,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
     if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
     ObsArgs P = {};
-    P.max_depth = max_depth; P.pred_depth = pred_depth; P.tree_out = out;
+    P.max_depth = max_depth; P.pred_depth = pred_depth; P.tree_out = out; P.dbg = o.dbg;
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;
