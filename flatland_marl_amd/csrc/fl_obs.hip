@@ -926,7 +926,7 @@ static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                          hipStream_t s) {
-    if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
+    if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
@@ -936,7 +936,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
-    if (d.A > 1023 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
+    if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
     if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
     ObsArgs P = {};
     P.max_depth = max_depth; P.pred_depth = pred_depth; P.tree_out = out; P.dbg = o.dbg;

@@ -1,0 +1,353 @@
+"""Dict-shaped facade over the batched HIP env for B = 1: keeps the API surface of the reference's
+`flatland.envs.rail_env.RailEnv` (reset()/step(), rail_env.py:260-357, 501-634), of the
+`ObservationBuilder` plugin interface (core/env_observation_builder.py:18-73), of the native module
+`flatland_cutils.TreeObsForRailEnv` (flatland_cutils/src/main.cpp:17-22) and of the caller
+`LocalTestEnvWrapper` (solution/eval_env.py:97-114), so solution/plfActor.py consumes it unchanged.
+
+Everything is computed by the HIP kernels through the C-ABI; this file only reshapes tensors into the
+reference's dicts / lists.  Map / line / timetable generators are out of scope:
+an env is created from the static description the reference produces at reset().
+"""
+from enum import IntEnum
+
+import numpy as np
+
+from .hip_backend import BatchedRailEnv, EpisodeDoneError, FlatlandHipError
+
+
+class TrainState(IntEnum):  # flatland/envs/step_utils/states.py:5-25
+    WAITING = 0
+    READY_TO_DEPART = 1
+    MALFUNCTION_OFF_MAP = 2
+    MOVING = 3
+    STOPPED = 4
+    MALFUNCTION = 5
+    DONE = 6
+
+    def is_malfunction_state(self):
+        return self in (TrainState.MALFUNCTION, TrainState.MALFUNCTION_OFF_MAP)
+
+    def is_off_map_state(self):
+        return self in (TrainState.WAITING, TrainState.READY_TO_DEPART, TrainState.MALFUNCTION_OFF_MAP)
+
+    def is_on_map_state(self):
+        return self in (TrainState.MOVING, TrainState.STOPPED, TrainState.MALFUNCTION)
+
+
+class RailEnvActions(IntEnum):  # flatland/envs/rail_env_action.py:5-27
+    DO_NOTHING = 0
+    MOVE_LEFT = 1
+    MOVE_FORWARD = 2
+    MOVE_RIGHT = 3
+    STOP_MOVING = 4
+
+
+class _SpeedCounter:  # step_utils/speed_counter.py:4-53 (read-only view)
+    def __init__(self, speed):
+        self.speed = float(speed)
+        self.max_count = int(1 / self.speed) - 1
+        self.counter = 0
+
+    @property
+    def is_cell_entry(self):
+        return self.counter == 0
+
+    @property
+    def is_cell_exit(self):
+        return self.counter == self.max_count
+
+
+class _MalfunctionHandler:  # step_utils/malfunction_handler.py:10-67 (read-only view)
+    def __init__(self):
+        self.malfunction_down_counter = 0
+        self.num_malfunctions = 0
+
+    @property
+    def in_malfunction(self):
+        return self.malfunction_down_counter > 0
+
+    @property
+    def malfunction_counter_complete(self):
+        return self.malfunction_down_counter == 0
+
+
+class _ActionSaver:  # step_utils/action_saver.py:4-36 (read-only view)
+    def __init__(self):
+        self.saved_action = None
+
+    @property
+    def is_action_saved(self):
+        return self.saved_action is not None
+
+
+class EnvAgent:
+    """read-only mirror of flatland.envs.agent_utils.EnvAgent (agent_utils.py:57-88), refreshed after every step."""
+
+    def __init__(self, handle, st):
+        self.handle = handle
+        self.initial_position = tuple(int(v) for v in st["init_pos"][handle])
+        self.initial_direction = int(st["init_dir"][handle])
+        self.target = tuple(int(v) for v in st["target"][handle])
+        self.earliest_departure = int(st["earliest"][handle])
+        self.latest_arrival = int(st["latest"][handle])
+        self.speed_counter = _SpeedCounter(st["speed"][handle])
+        self.malfunction_handler = _MalfunctionHandler()
+        self.action_saver = _ActionSaver()
+        self.position = None
+        self.direction = self.initial_direction
+        self.old_position = None
+        self.old_direction = None
+        self.arrival_time = None
+        self.state = TrainState.WAITING
+        self.moving = False
+
+    def _refresh(self, row):
+        r, c, d, s, malf, nmalf, scount, saved, arrival, orow, ocol, odir = (int(v) for v in row)
+        self.position = None if r < 0 else (r, c)
+        self.direction = d
+        self.state = TrainState(s)
+        self.malfunction_handler.malfunction_down_counter = malf
+        self.malfunction_handler.num_malfunctions = nmalf
+        self.speed_counter.counter = scount
+        self.action_saver.saved_action = None if saved == 0 else RailEnvActions(saved)
+        self.arrival_time = None if arrival < 0 else arrival
+        self.old_position = None if orow < 0 else (orow, ocol)
+        self.old_direction = None if odir < 0 else odir
+
+
+class _Rail:
+    def __init__(self, grid):
+        self.grid = np.array(grid, dtype=np.uint16)
+        self.height, self.width = self.grid.shape
+
+
+class _DistanceMap:
+    """DistanceMap.get() (flatland/envs/distance_map.py:27-45): float64 [A, H, W, 4], inf = unreachable."""
+
+    def __init__(self, env):
+        self._env = env
+        self._cache = None
+
+    def get(self):
+        if self._cache is None:
+            dm, slot = self._env._batch.distance_map(0)
+            full = dm[slot].astype(np.float64)
+            full[dm[slot] == 0xFFFF] = np.inf
+            self._cache = full
+        return self._cache
+
+
+class ObservationBuilder:
+    """core/env_observation_builder.py:18-73"""
+
+    def __init__(self):
+        self.env = None
+
+    def set_env(self, env):
+        self.env = env
+
+    def reset(self):
+        pass
+
+    def get_many(self, handles=None):
+        raise NotImplementedError
+
+    def get(self, handle=0):
+        return self.get_many([handle])
+
+
+class TreeObsForRailEnv(ObservationBuilder):
+    """Drop-in for flatland_cutils.TreeObsForRailEnv(max_nodes, max_pred_depth) (treeobs.h:133-169)."""
+
+    def __init__(self, max_nodes=31, max_pred_depth=500):
+        super().__init__()
+        self.max_nodes, self.max_pred_depth = max_nodes, max_pred_depth
+        self._last = None
+
+    def set_env(self, env):
+        self.env = env
+        env._batch.max_nodes, env._batch.pred_depth = self.max_nodes, self.max_pred_depth
+        env._batch._obs = None
+
+    def get_many(self, handles):
+        """-> (agent_attr [A][83], (nodes [A][N][12], adjacency [A][N-1][3], node_order [A][N], edge_order [A][N-1]))
+        as nested lists, like the pybind11 STL casters return them (treeobs.h:160-161)."""
+        o = self.env._batch.obs_cutils()
+        self.env._batch.check()
+        self._last = {k: v[0].cpu().numpy() for k, v in o.items()}
+        h = list(handles)
+        L = self._last
+        return (L["agent_attr"][h].tolist(),
+                (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(),
+                 L["edge_order"][h].tolist()))
+
+    def get_properties(self):
+        """treeobs.cpp:612-640"""
+        e, L = self.env, self._last
+        cfg = {"curr_step": e._elapsed_steps, "n_agents": e.get_num_agents(), "max_timesteps": e._max_episode_steps,
+               "height": e.height, "width": e.width}
+        props = {"dist_target": L["props"][:, 0].tolist(), "deadlocked": L["props"][:, 1].tolist(),
+                 "ready_not_depart": L["props"][:, 2].tolist(),
+                 "earliest_departure": [float(a.earliest_departure) for a in e.agents],
+                 "latest_arrival": [float(a.latest_arrival) for a in e.agents],
+                 "speed": [float(np.float32(a.speed_counter.speed)) for a in e.agents]}
+        return cfg, props, L["valid_actions"].astype(bool).tolist()
+
+
+class TreeObsUpstream(ObservationBuilder):
+    """flatland.envs.observations.TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense
+    float64 array per agent: [N(max_depth), 12] in DFS pre-order (node, L, F, R, B), missing subtree = -inf
+    (observations.py:20-32 gives the 12 field names, in this order)."""
+
+    FIELDS = ("dist_own_target_encountered", "dist_other_target_encountered", "dist_other_agent_encountered",
+              "dist_potential_conflict", "dist_unusable_switch", "dist_to_next_branch", "dist_min_to_target",
+              "num_agents_same_direction", "num_agents_opposite_direction", "num_agents_malfunctioning",
+              "speed_min_fractional", "num_agents_ready_to_depart")
+
+    def __init__(self, max_depth=2, pred_depth=30):
+        super().__init__()
+        self.max_depth, self.pred_depth = max_depth, pred_depth
+
+    def get_many(self, handles=None):
+        t = self.env._batch.obs_tree(self.max_depth, self.pred_depth)
+        self.env._batch.check()
+        arr = t[0].cpu().numpy()
+        handles = range(self.env.get_num_agents()) if handles is None else handles
+        return {h: arr[h] for h in handles}
+
+
+class RailEnv:
+    """B = 1 view with the reference's attribute / method surface (rail_env.py:35-777)."""
+
+    def __init__(self, static, obs_builder_object=None, device=0):
+        self._static = static
+        self._batch = BatchedRailEnv([static], device=device)
+        self.rail = _Rail(static["grid"])
+        self.height, self.width = self.rail.height, self.rail.width
+        self.number_of_agents = self._batch.A
+        self._max_episode_steps = int(static["T"])
+        self.agents = [EnvAgent(i, static) for i in range(self.number_of_agents)]
+        self.distance_map = _DistanceMap(self)
+        self.obs_builder = obs_builder_object if obs_builder_object is not None else TreeObsForRailEnv()
+        self.obs_builder.set_env(self)
+        self._elapsed_steps = 0
+        self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
+        self.rewards_dict = {i: 0 for i in range(self.number_of_agents)}
+        self.obs_dict = None
+
+    def get_num_agents(self):
+        return len(self.agents)
+
+    def get_agent_handles(self):
+        return range(self.get_num_agents())
+
+    def action_required(self, agent):  # rail_env.py:243-258
+        return agent.state == TrainState.READY_TO_DEPART or \
+            (agent.state.is_on_map_state() and agent.speed_counter.is_cell_entry)
+
+    def _refresh(self):
+        st, el = self._batch.state()
+        for a, row in zip(self.agents, st[0]):
+            a._refresh(row)
+        self._elapsed_steps = int(el[0])
+
+    def get_info_dict(self):  # rail_env.py:452-468
+        return {"action_required": {i: self.action_required(a) for i, a in enumerate(self.agents)},
+                "malfunction": {i: a.malfunction_handler.malfunction_down_counter for i, a in enumerate(self.agents)},
+                "speed": {i: a.speed_counter.speed for i, a in enumerate(self.agents)},
+                "state": {i: a.state for i, a in enumerate(self.agents)}}
+
+    def _get_observations(self):  # rail_env.py:660-666
+        self.obs_dict = self.obs_builder.get_many(list(range(self.get_num_agents())))
+        return self.obs_dict
+
+    def reset(self, regenerate_rail=False, regenerate_schedule=False, *, random_seed=None):
+        if regenerate_rail or regenerate_schedule or random_seed is not None:
+            raise NotImplementedError("rail / line / timetable generation is outside the accelerated hot path; "
+                                      "create the env from the static description of a generated env")
+        self._batch.reset(fresh=True)
+        self.obs_builder.reset()
+        self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
+        self.rewards_dict = {i: 0 for i in range(self.number_of_agents)}
+        self._refresh()
+        return self._get_observations(), self.get_info_dict()
+
+    def step(self, action_dict):  # rail_env.py:501-634
+        if self.dones["__all__"]:
+            self._elapsed_steps += 1
+            raise Exception("Episode is done, cannot call step()")
+        acts = np.full((1, self.number_of_agents), 255, dtype=np.uint8)
+        for i, a in action_dict.items():
+            if 0 <= int(i) < self.number_of_agents:
+                v = int(a)
+                acts[0, int(i)] = v if 0 <= v <= 4 else 7   # illegal values become DO_NOTHING inside the kernel
+        rew, done, done_all = self._batch.step(acts)
+        try:
+            self._batch.check()
+        except EpisodeDoneError as e:
+            raise Exception("Episode is done, cannot call step()") from e
+        except FlatlandHipError as e:
+            if e.code == 4:
+                raise ValueError(str(e)) from e
+            raise
+        rew, done = rew[0].cpu().numpy(), done[0].cpu().numpy()
+        self.rewards_dict = {i: int(rew[i]) for i in range(self.number_of_agents)}
+        for i in range(self.number_of_agents):
+            self.dones[i] = bool(done[i])
+        self.dones["__all__"] = bool(done_all[0].item())
+        self._refresh()
+        return self._get_observations(), self.rewards_dict, self.dones, self.get_info_dict()
+
+
+class LocalTestEnvWrapper:
+    """Counterpart of solution/eval_env.py:9-114 (TestEnvWrapper / LocalTestEnvWrapper)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.obs_properties = {}
+
+    def action_required(self):
+        return {i: self.env.action_required(a) for i, a in enumerate(self.env.agents)}
+
+    def parse_actions(self, actions):  # eval_env.py:33-39
+        req = self.action_required()
+        return {idx: act for idx, act in actions.items() if req[idx]}
+
+    def update_obs_properties(self):  # eval_env.py:56-62
+        cfg, props, valid = self.env.obs_builder.get_properties()
+        self.obs_properties = {}
+        self.obs_properties.update(cfg)
+        self.obs_properties.update(props)
+        self.obs_properties["valid_actions"] = valid
+
+    @staticmethod
+    def parse_features(feature, obs_properties):  # eval_env.py:64-79
+        fl = {"agent_attr": np.array(feature[0]), "forest": np.array(feature[1][0])}
+        fl["forest"][fl["forest"] == np.inf] = -1
+        fl["adjacency"] = np.array(feature[1][1])
+        fl["node_order"] = np.array(feature[1][2])
+        fl["edge_order"] = np.array(feature[1][3])
+        fl.update(obs_properties)
+        return fl
+
+    def get_valid_actions(self):
+        return self.obs_properties["valid_actions"]
+
+    def reset(self):
+        feature, _ = self.env.reset()
+        self.update_obs_properties()
+        return [self.parse_features(feature, self.obs_properties)]
+
+    def step(self, actions):
+        actions = self.parse_actions(actions)
+        feature, reward, done, info = self.env.step(actions)
+        self.update_obs_properties()
+        return [self.parse_features(feature, self.obs_properties)], reward, done
+
+    def final_metric(self):  # eval_env.py:81-94 (counts every off-map, non-READY agent as "arrived")
+        assert self.env.dones["__all__"]
+        env = self.env
+        n_arrival = sum(1 for a in env.agents if a.position is None and a.state != TrainState.READY_TO_DEPART)
+        total_reward = sum(env.rewards_dict.values())
+        norm_reward = 1 + total_reward / env._max_episode_steps / env.get_num_agents()
+        return n_arrival / env.get_num_agents(), total_reward, norm_reward

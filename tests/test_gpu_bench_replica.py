@@ -1,0 +1,29 @@
+"""GPU: replica 0 of the bench workload reuses the MT state and action-stream seed of a committed golden
+episode, so its trajectory must equal that fixture bit for bit while the other 255 replicas run beside it."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,B", [("cfg2", 256), ("cfg3", 32)])
+def test_bench_replica0_equals_golden_episode(workload, B):
+    from flatland_marl_amd import workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    envs, seed = wl.make_envs(workload, B=B)
+    name, fseed = wl.WORKLOADS[workload]["pinned"]
+    fx = util.load(name)
+    assert seed == fseed == int(fx["stream_seed"])
+    env = BatchedRailEnv(envs)
+    n = len(fx["actions"])
+    for t in range(n):
+        rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=True)
+        st, _ = env.state()
+        np.testing.assert_array_equal(st[0], util.golden_state(fx, t), err_msg=f"step {t}")
+        np.testing.assert_array_equal(rew.cpu().numpy()[0], fx["s_reward"][t])
+        assert bool(done_all.cpu().numpy()[0]) == bool(fx["done_all"][t])
+    env.check()
+    m = env.metrics().cpu().numpy()
+    assert m[2] == B * env.A * n and m[3] >= 1
