@@ -103,6 +103,80 @@ __global__ __launch_bounds__(256) void k_distance_map(FlDev d) {
     if (tid == 0 && *overflow) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);
 }
 
+// ---------------------------------------------------------------------------------------------- segment table
+// The branch walk of the tree observations (treeobs.cpp:322-539 / observations.py:296-425) is a deterministic
+// chain over (cell, orientation) states until a switch, a dead end, a zero-transition cell or a revisited state;
+// only the stop at the agent's own target depends on the agent.  The chain's end, its length, and the first
+// "unusable switch" offset are therefore static per start state and are tabulated once per env.
+__device__ __forceinline__ int seg_next(const uint16_t *grid, int H, int W, int state) {
+    const int cell = state >> 2;
+    const uint32_t d = state & 3;
+    const uint32_t g = grid[cell];
+    const uint32_t bits = nibble(g, d);
+    int total = __popc(g);
+    if (g == 0x8421u) total = 2;
+    if (__popc(bits) != 1 || total == 1) return -1;
+    const uint32_t nd = first_dir(bits);
+    const int r = cell / W, c = cell - r * W;
+    const int nr = r + (nd == 0 ? -1 : nd == 2 ? 1 : 0), nc = c + (nd == 1 ? 1 : nd == 3 ? -1 : 0);
+    if (nr < 0 || nc < 0 || nr >= H || nc >= W) return -1;  // malformed map: treat as the end of the chain
+    return ((nr * W + nc) << 2) | (int)nd;
+}
+
+__global__ __launch_bounds__(256) void k_segments(FlDev d) {
+    const int HW = d.H * d.W, NS = HW * 4;
+    const int per_env = (NS + 255) / 256;
+    const int b = blockIdx.x / per_env;
+    const int s0 = (blockIdx.x % per_env) * 256 + threadIdx.x;
+    if (s0 >= NS) return;
+    const uint16_t *grid = d.grid + (size_t)b * HW;
+    uint2 out = make_uint2((uint32_t)s0 | (SEG_ZERO << 20), 0xFFFF0000u);
+    if (grid[s0 >> 2] != 0) {
+        const int cap = 65534;  // rail states < 65534 is enforced at fl_load_env, so a longer walk has revisited a state
+        int cur = s0, k = 0, unus = 0xFFFF;
+        uint32_t kind = SEG_ZERO;
+        while (true) {
+            const uint32_t g = grid[cur >> 2];
+            const uint32_t bits = nibble(g, cur & 3);
+            int total = __popc(g);
+            if (g == 0x8421u) total = 2;
+            const int num = __popc(bits);
+            if (total > 2 && 2 > num && unus == 0xFFFF) unus = k;
+            if (num == 1) {
+                if (total == 1) { kind = SEG_DEAD_END; break; }
+                const int nx = seg_next(grid, d.H, d.W, cur);
+                if (nx < 0) { kind = SEG_ZERO; break; }
+                cur = nx;
+                k++;
+                if (k >= cap) {  // cycle: find the first revisited state (Brent), the walk is terminal there
+                    int power = 1, lam = 1, tort = s0, hare = seg_next(grid, d.H, d.W, s0);
+                    while (tort != hare) {
+                        if (power == lam) { tort = hare; power *= 2; lam = 0; }
+                        hare = seg_next(grid, d.H, d.W, hare);
+                        lam++;
+                    }
+                    tort = hare = s0;
+                    for (int i = 0; i < lam; i++) hare = seg_next(grid, d.H, d.W, hare);
+                    int mu = 0;
+                    while (tort != hare) { tort = seg_next(grid, d.H, d.W, tort); hare = seg_next(grid, d.H, d.W, hare); mu++; }
+                    k = mu + lam;
+                    cur = hare;  // state at index mu == state at index mu + lam
+                    kind = SEG_CYCLE;
+                    break;
+                }
+            } else if (num > 1) { kind = SEG_SWITCH; break; }
+            else { kind = SEG_ZERO; break; }
+        }
+        out = make_uint2((uint32_t)cur | (kind << 20), (uint32_t)k | ((uint32_t)unus << 16));
+    }
+    d.seg[(size_t)b * NS + s0] = out;
+}
+
+void fl_launch_segments(const FlDev &d, hipStream_t s) {
+    const int NS = d.H * d.W * 4;
+    hipLaunchKernelGGL(k_segments, dim3(d.B * ((NS + 255) / 256)), dim3(256), 0, s, d);
+}
+
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s) {
     const int HW = d.H * d.W;
     size_t lds = ((size_t)(HW * 4 + 31) / 32 + 2 * DM_FRONTIER_CAP + 4) * sizeof(uint32_t);

@@ -195,6 +195,7 @@ int fl_commit(fl_batch *h) {
     DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
     DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4);
     DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
+    DALLOC(d.seg, (size_t)B * HW * 4);
     DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
     DALLOC(d.spk, BA); DALLOC(d.speed, BA);
     DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
@@ -208,6 +209,8 @@ int fl_commit(fl_batch *h) {
     UPLOAD(d.latest, h->h_latest); UPLOAD(d.tslot, h->h_tslot); UPLOAD(d.spk, h->h_spk); UPLOAD(d.speed, h->h_speed);
     HIPCHK(hipStreamSynchronize(h->stream));  // `ut` is a local
     fl_launch_distance_maps(d, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_segments(d, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_reset(d, nullptr, 1, h->stream);
     HIPCHK(hipGetLastError());

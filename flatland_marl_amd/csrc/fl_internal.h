@@ -12,6 +12,15 @@
 
 #define FL_INF16 0xFFFFu
 
+// static branch-walk table entry (uint2) of a start state (cell, dir): the walk of _explore_branch ignoring the
+// agent's own target.  x = end state (cell << 2 | dir) | kind << 20;  y = steps to the end | first "unusable
+// switch" offset << 16 (0xFFFF = none)
+enum { SEG_SWITCH = 0, SEG_DEAD_END = 1, SEG_ZERO = 2, SEG_CYCLE = 3 };
+#define SEG_END(e) ((int)((e).x & 0xFFFFFu))
+#define SEG_KIND(e) (((e).x >> 20) & 3u)
+#define SEG_LEN(e) ((int)((e).y & 0xFFFFu))
+#define SEG_UNUS(e) ((int)((e).y >> 16))
+
 enum { ST_WAITING = 0, ST_READY = 1, ST_MALF_OFF = 2, ST_MOVING = 3, ST_STOPPED = 4, ST_MALF = 5, ST_DONE = 6 };
 enum { ACT_NOTHING = 0, ACT_LEFT = 1, ACT_FORWARD = 2, ACT_RIGHT = 3, ACT_STOP = 4 };
 
@@ -50,6 +59,7 @@ struct FlDev {
     uint16_t *grid;  // [B][H*W]
     uint16_t *dm;    // [B][Umax][H*W][4]
     int *ut;         // [B][Umax] unique target cells
+    uint2 *seg;      // [B][H*W*4] static branch-walk table per (cell, orientation), see fl_dmap.hip k_segments
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
     uint32_t *spk;
@@ -104,6 +114,7 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 
 // kernel launchers (defined in the .hip files)
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
+void fl_launch_segments(const FlDev &d, hipStream_t s);
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,

@@ -4,7 +4,7 @@
 
 #include "fl_internal.h"
 
-#define FL_OBS_MAX_NODES 33  /* one BFS level of a tree is explored by a 32-lane group */
+#define FL_OBS_MAX_NODES 32  /* all non-root nodes of a tree are evaluated by one 32-lane group */
 #define FL_OBS_MAX_PRED 500
 
 struct FlObsScratch {

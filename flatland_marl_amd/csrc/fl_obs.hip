@@ -36,9 +36,9 @@
 
 // ---------------------------------------------------------------------------------------------- context
 struct ObsCtx {
-    int A, H, W, HW, K;           // K = number of prediction keys (col * W + row), tool.h:391-398
-    const uint16_t *grid;         // LDS
-    const uint16_t *cell_slot;    // LDS: index of the cell's entry in the occupied-cell table, 0xFFFF = nothing there
+    int A, H, W, HW;
+    bool keycell;                 // prediction keys (col * W + row, tool.h:391-398) are injective (H <= W): index by cell id
+    const uint32_t *cellw;        // LDS per cell: rail bitmap (low 16) | occupied-cell table index (high 16, 0xFFFF = none)
     const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
     const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
     const uint32_t *cell_target;  // LDS bitmap: some agent's target (upstream location_has_target)
@@ -53,10 +53,17 @@ struct ObsCtx {
     const uint32_t *path;         // HBM [A][pcap] cell << 2 | dir
     int pcap;
     const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
-    const uint32_t *csr_items;    // HBM: IT_* packed items
+    const uint32_t *csr_items;    // IT_* packed items; LDS or HBM
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // HBM env base [Umax][HW][4]
+    const uint2 *seg;             // HBM env base [HW * 4] static branch-walk table
 };
+
+__device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
+    if (X.keycell) return cell;
+    const int r = cell / X.W;
+    return (cell - r * X.W) * X.W + r;
+}
 
 // waypoint index of agent a at predicted time t
 template <bool CUTILS>
@@ -69,85 +76,86 @@ __device__ __forceinline__ int waypoint_at(const ObsCtx &X, int a, int t) {
     return min(t / tpc, lp);  // predictions.py:159-174: advance when index % times_per_cell == 0, index >= 1
 }
 
-struct BranchOut {
-    double f[12];
-    int end_cell;
-    uint32_t end_dir;
-    int tot_dist;
-    bool is_switch, is_dead_end, is_terminal, is_target, zero_transition, cycle_suspect;
+// One node of a tree = one branch walk (_explore_branch: treeobs.cpp:258-610 / observations.py:256-494).
+// Where the walk ends, how long it is and its first "unusable switch" are static per start state (segment table,
+// fl_dmap.hip); the stop at the agent's own target follows from the distance map: along a chain of single-transition
+// cells the distance drops by one per step, so the target is on the chain iff dm[start] <= chain length.
+struct NodeDesc {
+    int start;      // start state cell << 2 | dir, -1 = null cell
+    int tot0;       // tot_dist at the first visited cell
+    int nvis;       // number of visited cells (feature block executions)
+    int end;        // end state (direction unknown / irrelevant when the walk stops at the target)
+    uint32_t flags; // bit 0 target stop, 1 switch, 2 dead end, 3 terminal (zero transition or cycle), 4 zero transition
+    int unus;       // tot_dist of the first unusable switch or -1
+};
+enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO = 16 };
+
+__device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, int cell, uint32_t dir, int tot0) {
+    NodeDesc n;
+    n.start = (cell << 2) | (int)dir;
+    n.tot0 = tot0;
+    const uint2 e = X.seg[n.start];
+    const uint32_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + n.start];
+    const int len = SEG_LEN(e), unus = SEG_UNUS(e);
+    if (dv != FL_INF16 && (int)dv <= len) {  // reaches its own target first
+        n.nvis = (int)dv + 1;
+        n.end = (X.a_target[handle] << 2);
+        n.flags = ND_TARGET;
+        n.unus = (unus != 0xFFFF && unus < (int)dv) ? tot0 + unus : -1;  // the target cell breaks before that check
+    } else {
+        n.nvis = len + 1;
+        n.end = SEG_END(e);
+        const uint32_t k = SEG_KIND(e);
+        n.flags = k == SEG_SWITCH ? ND_SWITCH : k == SEG_DEAD_END ? ND_DEAD_END : k == SEG_ZERO ? (ND_TERMINAL | ND_ZERO) : ND_TERMINAL;
+        n.unus = unus != 0xFFFF ? tot0 + unus : -1;
+    }
+    return n;
+}
+
+// the agent-dependent features of a walk: everything that depends on where the other agents are and are predicted
+struct WalkDyn {
+    int other_agent, pot_conflict, other_target;  // tot_dist of the first hit, INT_MAX = none
+    int same_dir, opp_dir, malfunctioning, ready;
+    double min_speed;
 };
 
-// deterministic successor of a walk state while the walk keeps going; -1 when the walk stops there
-__device__ __forceinline__ int walk_next(const ObsCtx &X, int state, int target) {
-    const int cell = state >> 2;
-    const uint32_t d = state & 3;
-    if (cell == target) return -1;
-    const uint32_t g = X.grid[cell];
-    const uint32_t bits = nibble(g, d);
-    if (__popc(bits) != 1) return -1;
-    int total = __popc(g);
-    if (g == 0x8421u) total = 2;
-    if (total == 1) return -1;
-    const uint32_t nd = first_dir(bits);
-    return (step_cell(cell, nd, X.W) << 2) | (int)nd;
-}
-
-// index of the first revisited state of the (non-terminating) walk from `start`: Brent's cycle detection
-__device__ int first_repeat_index(const ObsCtx &X, int start, int target) {
-    int power = 1, lam = 1, tort = start, hare = walk_next(X, start, target);
-    while (tort != hare) {
-        if (power == lam) { tort = hare; power *= 2; lam = 0; }
-        hare = walk_next(X, hare, target);
-        lam++;
-    }
-    tort = hare = start;
-    for (int i = 0; i < lam; i++) hare = walk_next(X, hare, target);
-    int mu = 0;
-    while (tort != hare) { tort = walk_next(X, tort, target); hare = walk_next(X, hare, target); mu++; }
-    return mu + lam;
-}
-
-// _explore_branch: treeobs.cpp:258-610 (CUTILS) / observations.py:256-494 (upstream).
-// stop_at_visit >= 0: the visit with that index is a revisited (cell, dir) -> terminal (cycle), see caller.
 template <bool CUTILS>
-__device__ void explore_branch(const ObsCtx &X, int handle, int cell, uint32_t d, int tot_dist, int stop_at_visit,
-                               BranchOut &o) {
+__device__ void walk_dynamic(const ObsCtx &X, int handle, const NodeDesc &nd, WalkDyn &o) {
     const int W = X.W;
     const int target = X.a_target[handle];
-    double own_target = INFINITY, other_agent = INFINITY, other_target = INFINITY, pot_conflict = INFINITY,
-           unusable = INFINITY, min_speed = 1.0;
-    int same_dir = 0, opp_dir = 0, malfunctioning = 0, ready = 0;
-    const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed
-    const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed)
-    o.is_switch = o.is_dead_end = o.is_terminal = o.is_target = o.zero_transition = o.cycle_suspect = false;
-    const int max_visits = 4 * X.HW + 4;
-    int visit = 0;
-    while (true) {
-        const uint32_t sl = X.cell_slot[cell];
-        const int ag = sl != 0xFFFFu ? X.slot_agent[sl] : -1;
-        if (ag >= 0) {  // treeobs.cpp:322-357
-            if ((double)tot_dist < other_agent) other_agent = tot_dist;
-            const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
-            if (mf > malfunctioning) malfunctioning = mf;
-            const int rd = X.slot_ready[sl];
-            if (rd > 0) ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
-            if (X.a_dir[ag] == d) {
-                same_dir += 1;
-                const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
-                if (sp < min_speed) min_speed = sp;
-            } else {
-                opp_dir += 1;
+    int cell = nd.start >> 2;
+    uint32_t d = nd.start & 3;
+    int tot = nd.tot0;
+    o.other_agent = o.pot_conflict = o.other_target = 0x7fffffff;
+    o.same_dir = o.opp_dir = o.malfunctioning = o.ready = 0;
+    o.min_speed = 1.0;
+    const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
+    const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
+    for (int v = 0; v < nd.nvis; v++) {
+        const uint32_t cw = X.cellw[cell];
+        const uint32_t bits = nibble(cw & 0xFFFFu, d);
+        const uint32_t sl = cw >> 16;
+        if (sl != 0xFFFFu) {  // treeobs.cpp:322-357
+            const int ag = X.slot_agent[sl];
+            if (ag >= 0) {
+                if (tot < o.other_agent) o.other_agent = tot;
+                const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
+                if (mf > o.malfunctioning) o.malfunctioning = mf;
+                const int rd = X.slot_ready[sl];
+                if (rd > 0) o.ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
+                if (X.a_dir[ag] == d) {
+                    o.same_dir += 1;
+                    const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
+                    if (sp < o.min_speed) o.min_speed = sp;
+                } else {
+                    o.opp_dir += 1;
+                }
             }
         }
-        const uint32_t g = X.grid[cell];
-        const uint32_t bits = nibble(g, d);
-        int total = __popc(g);
-        const bool crossing = g == 0x8421u;
-        if (X.Tn > 0) {  // potential conflict (treeobs.cpp:378-465 / observations.py:329-367)
-            const int pt = CUTILS ? (int)((float)tot_dist * tpc_f) : (int)((double)tot_dist * tpc_d);
-            if (pt < X.Tn && tot_dist < X.Tn && !((double)tot_dist >= pot_conflict)) {
-                const int r = cell / W, c = cell - r * W;
-                const int key = c * W + r;
+        if (X.Tn > 0 && o.pot_conflict == 0x7fffffff && tot < X.Tn) {  // treeobs.cpp:378-465 / observations.py:329-367
+            const int pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
+            if (pt < X.Tn) {
+                const int key = key_of(X, cell);
                 const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
                 if (hi > lo) {
                     const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
@@ -190,54 +198,52 @@ __device__ void explore_branch(const ObsCtx &X, int handle, int cell, uint32_t d
                             }
                         }
                     }
-                    if (hit) pot_conflict = tot_dist;
+                    if (hit) o.pot_conflict = tot;
                 }
             }
         }
-        if (!CUTILS && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target) {
-            if ((double)tot_dist < other_target) other_target = tot_dist;  // cutils never fills the map (treeobs.cpp:72)
-        }
-        if (cell == target && (double)tot_dist < own_target) own_target = tot_dist;
-        if (visit == stop_at_visit) { o.is_terminal = true; break; }  // (cell, dir) already visited: cycle
-        if (cell == target) { o.is_target = true; break; }
-        if (crossing) total = 2;
-        const int num = __popc(bits);
-        if (total > 2 && 2 > num && (double)tot_dist < unusable) unusable = tot_dist;
-        if (num == 1) {
-            if (total == 1) { o.is_dead_end = true; break; }
+        if (!CUTILS && o.other_target == 0x7fffffff && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target)
+            o.other_target = tot;  // cutils never fills the map (treeobs.cpp:72)
+        if (v + 1 < nd.nvis) {  // keep walking along the only transition
             d = first_dir(bits);
             cell = step_cell(cell, d, W);
-            tot_dist += 1;
-            if (++visit >= max_visits && stop_at_visit < 0) { o.cycle_suspect = true; return; }
-        } else if (num > 0) {
-            o.is_switch = true;
-            break;
-        } else {
-            o.zero_transition = true;  // treeobs.cpp:529-535 throws; observations.py:420-425 treats it as terminal
-            o.is_terminal = true;
-            break;
+            tot += 1;
         }
     }
-    const uint16_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW + cell) * 4 + d];
-    const double dmv = dv == FL_INF16 ? INFINITY : (double)dv;
-    double dist_next, dist_min;
-    if (o.is_target) { dist_next = tot_dist; dist_min = 0; }
-    else if (o.is_terminal) { dist_next = INFINITY; dist_min = dmv; }
-    else { dist_next = tot_dist; dist_min = dmv; }
-    o.f[0] = own_target; o.f[1] = other_target; o.f[2] = other_agent; o.f[3] = pot_conflict; o.f[4] = unusable;
-    o.f[5] = dist_next; o.f[6] = dist_min; o.f[7] = same_dir; o.f[8] = opp_dir; o.f[9] = malfunctioning;
-    o.f[10] = min_speed; o.f[11] = ready;
-    o.end_cell = cell; o.end_dir = d; o.tot_dist = tot_dist;
 }
 
+// the 12 node features (treeobs.cpp:546-573 / observations.py:433-461), as doubles
 template <bool CUTILS>
-__device__ __forceinline__ void explore_branch_exact(const ObsCtx &X, int handle, int cell, uint32_t d, int tot_dist,
-                                                     BranchOut &o) {
-    explore_branch<CUTILS>(X, handle, cell, d, tot_dist, -1, o);
-    if (o.cycle_suspect) {  // a walk longer than the number of (cell, dir) states repeats a state: replay up to the first repeat
-        const int k = first_repeat_index(X, (cell << 2) | (int)d, X.a_target[handle]);
-        explore_branch<CUTILS>(X, handle, cell, d, tot_dist, k, o);
+__device__ __forceinline__ void node_features(const ObsCtx &X, int handle, const NodeDesc &nd, double *f) {
+    WalkDyn w;
+    walk_dynamic<CUTILS>(X, handle, nd, w);
+    const int tot_end = nd.tot0 + nd.nvis - 1;
+    const bool tgt = nd.flags & ND_TARGET;
+    double dist_min = 0;
+    if (!tgt) {
+        const uint16_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + nd.end];
+        dist_min = dv == FL_INF16 ? INFINITY : (double)dv;
     }
+    f[0] = tgt ? (double)tot_end : INFINITY;
+    f[1] = w.other_target == 0x7fffffff ? INFINITY : (double)w.other_target;
+    f[2] = w.other_agent == 0x7fffffff ? INFINITY : (double)w.other_agent;
+    f[3] = w.pot_conflict == 0x7fffffff ? INFINITY : (double)w.pot_conflict;
+    f[4] = nd.unus < 0 ? INFINITY : (double)nd.unus;
+    f[5] = (nd.flags & ND_TERMINAL) ? INFINITY : (double)tot_end;
+    f[6] = dist_min;
+    f[7] = w.same_dir; f[8] = w.opp_dir; f[9] = w.malfunctioning; f[10] = w.min_speed; f[11] = w.ready;
+}
+
+// children of a node (treeobs.cpp:583-608 / observations.py:464-489): child k (k = 0 left, 1 forward, 2 right, 3 back)
+// -> start state or -1 (null cell)
+__device__ __forceinline__ int child_state(const ObsCtx &X, const NodeDesc &nd, int k) {
+    if (!(nd.flags & (ND_SWITCH | ND_DEAD_END))) return -1;
+    const int ecell = nd.end >> 2;
+    const uint32_t edir = nd.end & 3;
+    const uint32_t pbits = nibble(X.cellw[ecell] & 0xFFFFu, edir);
+    const uint32_t bd = (edir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
+    if (nd.flags & ND_DEAD_END) return ((pbits >> (3 - rev)) & 1) ? ((step_cell(ecell, rev, X.W) << 2) | (int)rev) : -1;
+    return ((pbits >> (3 - bd)) & 1) ? ((step_cell(ecell, bd, X.W) << 2) | (int)bd) : -1;
 }
 
 // scale_node (treeobs.cpp:111-152), float32 arithmetic
@@ -301,14 +307,14 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     constexpr bool CUTILS = MODE == 0;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, H = d.H, W = d.W, HW = H * W;
-    const int K = (W - 1) * W + H;
+    const bool keycell = H <= W;  // col * W + row is injective over the grid: use the cell id as prediction key
+    const int K = keycell ? HW : (W - 1) * W + H;
     const int lane = tid & 63, wave = tid >> 6;
 
     extern __shared__ __align__(16) unsigned char lds[];
     size_t off = 0;
     auto carve = [&](size_t bytes) { void *p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    uint16_t *grid = (uint16_t *)carve((size_t)HW * 2);
-    uint16_t *cell_slot = (uint16_t *)carve((size_t)HW * 2);
+    uint32_t *cellw = (uint32_t *)carve((size_t)HW * 4);  // rail bitmap | occupied-cell table index << 16
     int *slot_agent = (int *)carve((size_t)A * 4);
     int *slot_ready = (int *)carve((size_t)A * 4);
     uint32_t *cell_target = (uint32_t *)carve((size_t)((HW + 31) / 32) * 4);
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
-    int *grp_par = (int *)carve((size_t)OBS_GROUPS * 64 * 4);  // per-group parent[] / height[] scratch (evaluation orders)
+    int *wave_scr = (int *)carve((size_t)OBS_WAVES * 512 * 4);  // per-wave node descriptors / parent / height scratch
     int *partial = (int *)carve((size_t)OBS_NT * 4);           // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     OBS_STAMP(0);
 
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
-    for (int c = tid; c < HW; c += nt) { grid[c] = ggrid[c]; cell_slot[c] = 0xFFFFu; }
+    for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
     for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
@@ -371,16 +377,13 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         const bool on = !is_off_map(state) && a_pos[i] >= 0, off = is_off_map(state);
         if (on || off) {
             const int c = on ? a_pos[i] : d.init_pos[b * A + i];
-            unsigned int *wptr = (unsigned int *)(cell_slot) + (c >> 1);
-            const int sh = (c & 1) * 16;
             int slot = -1;
-            unsigned int cur = *(volatile unsigned int *)wptr;
-            while (true) {  // claim (or find) the cell's table entry: 16-bit CAS on the containing 32-bit word
-                const unsigned int have = (cur >> sh) & 0xFFFFu;
+            unsigned int cur = *(volatile unsigned int *)&cellw[c];
+            while (true) {  // claim (or find) the cell's table entry
+                const unsigned int have = cur >> 16;
                 if (have != 0xFFFFu) { slot = (int)have; break; }
                 if (slot < 0) slot = atomicAdd(&misc[1], 1);
-                const unsigned int nw = (cur & ~(0xFFFFu << sh)) | ((unsigned int)slot << sh);
-                const unsigned int old = atomicCAS(wptr, cur, nw);
+                const unsigned int old = atomicCAS(&cellw[c], cur, (cur & 0xFFFFu) | ((unsigned int)slot << 16));
                 if (old == cur) break;
                 cur = old;
             }
@@ -392,8 +395,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     __syncthreads();
 
     ObsCtx X;
-    X.A = A; X.H = H; X.W = W; X.HW = HW; X.K = K;
-    X.grid = grid; X.cell_slot = cell_slot; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
+    X.A = A; X.H = H; X.W = W; X.HW = HW;
+    X.keycell = keycell; X.cellw = cellw; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
+    X.seg = d.seg + (size_t)b * HW * 4;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_lp = a_lp; X.a_tslot = a_tslot; X.a_target = a_target;
     X.pcap = S.pred_cap;
@@ -413,14 +417,14 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         for (int i = tid; i < A; i += nt) {
             bool fr = false;
             if (is_on_map(a_state[i]) && !a_dead[i]) {
-                const uint32_t bits = nibble(grid[a_pos[i]], a_dir[i]);
+                const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
                 if (bits == 0) fr = true;
                 const int r = a_pos[i] / W, c = a_pos[i] - r * W;
                 for (uint32_t m = 0; m < 4 && !fr; m++) {
                     if (!((bits >> (3 - m)) & 1)) continue;
                     const int nr = r + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = c + (m == 1 ? 1 : m == 3 ? -1 : 0);
                     if (nr < 0 || nc < 0 || nr >= H || nc >= W) { fr = true; continue; }
-                    const uint32_t sl = cell_slot[nr * W + nc];
+                    const uint32_t sl = cellw[nr * W + nc] >> 16;
                     if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
                 }
             }
@@ -430,11 +434,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         while (true) {
             for (int i = tid; i < A; i += nt) {
                 if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
-                    const uint32_t bits = nibble(grid[a_pos[i]], a_dir[i]);
+                    const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
                     bool fr = false;
                     for (uint32_t m = 0; m < 4 && !fr; m++) {
                         if (!((bits >> (3 - m)) & 1)) continue;
-                        const uint32_t sl = cell_slot[step_cell(a_pos[i], m, W)];
+                        const uint32_t sl = cellw[step_cell(a_pos[i], m, W)] >> 16;
                         const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
                         if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
                     }
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             }
             // valid-action mask (loader.cpp:273-312)
             uint32_t va = 0;
-            const uint32_t cell = pos >= 0 ? grid[pos] : 0;
+            const uint32_t cell = pos >= 0 ? (cellw[pos] & 0xFFFFu) : 0;
             if (state == ST_MOVING || state == ST_STOPPED) {
                 if (scount == 0) {
                     const uint32_t bits = nibble(cell, dir);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                         if ((bits >> (3 - nd)) & 1) {
                             va |= 1u << a;
                             cnt++;
-                            if (__popc((uint32_t)grid[step_cell(pos, nd, W)]) > 2) has_branch = true;
+                            if (__popc(cellw[step_cell(pos, nd, W)] & 0xFFFFu) > 2) has_branch = true;
                         }
                     }
                     if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 // cutils walks max_depth iterations and stops where nothing is strictly closer (predictions.cpp:107-133);
                 // upstream stops at the target (rail_env_shortest_paths.py:245-265)
                 while (depth < pred_depth && (CUTILS || cell != target)) {
-                    const uint32_t g = grid[cell];
+                    const uint32_t g = cellw[cell] & 0xFFFFu;
                     const uint32_t bits = nibble(g, dd);
                     int best = -1;
                     if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
@@ -604,11 +608,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
-            for (int k = 0; k <= lp; k++) {
-                const int c = (int)(path[k] >> 2);
-                const int r = c / W, col = c - r * W;
-                atomicAdd(&csr[col * W + r], 1);
-            }
+            for (int k = 0; k <= lp; k++) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
         }
         __syncthreads();
         OBS_STAMP(3);
@@ -646,8 +646,6 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             for (int k = 0; k <= lp; k++) {
                 const uint32_t w = path[k];
-                const int c = (int)(w >> 2);
-                const int r = c / W, col = c - r * W;
                 // closed time interval during which the agent is predicted on waypoint k
                 int tlo, thi;
                 if (CUTILS) {  // w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp) afterwards
@@ -657,7 +655,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     tlo = k * tpc;
                     thi = k == lp ? tlast : (k + 1) * tpc - 1;
                 }
-                const int slot = atomicAdd(&csr[col * W + r], 1);
+                const int slot = atomicAdd(&csr[key_of(X, (int)(w >> 2))], 1);
                 csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)min(thi, tlast) << 2) | (w & 3u);
             }
         }
@@ -665,13 +663,17 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     }
 
     OBS_STAMP(4);
-    // ---- phase 3: trees
+    // ---- phase 3: trees.  Pass A derives the topology of a tree from the static segment table (O(1) per node, one
+    // BFS level per step); pass B then evaluates the agent-dependent features of ALL nodes of the tree concurrently,
+    // one lane per node.
     const float max_dist = (float)T;
     if (CUTILS) {
-        // two agents per wavefront: a 32-lane group explores one BFS level of its agent's tree at a time
+        // two agents per wavefront, 32 lanes each
         const int grp = lane >> 5, gl = lane & 31;
         const int N = P.max_nodes;
-        int *par = grp_par + (wave * 2 + grp) * 64;  // [0,32) parent of node k, [32,64) height of node k
+        int *scr = wave_scr + wave * 512 + grp * 256;  // per group: NodeDesc fields [6][32], parent[32], height[32]
+        int *n_start = scr, *n_tot = scr + 32, *n_vis = scr + 64, *n_end = scr + 96, *n_flags = scr + 128, *n_unus = scr + 160;
+        int *par = scr + 192, *hgt = scr + 224;
         for (int base = 0; base < A; base += OBS_GROUPS) {
             const int i = base + wave * 2 + grp;
             const bool have = i < A;
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             const int g = b * A + ia;
             const int vpos = a_vpos[ia];
             const uint32_t dir = a_dir[ia];
-            const uint32_t rbits = nibble(grid[vpos], dir);
+            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
             uint32_t orientation = dir;
             if (__popc(rbits) == 1) orientation = first_dir(rbits);
             float *F = P.forest + (size_t)g * N * 12;
@@ -697,48 +699,34 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 scale_and_store(root, max_dist, A, F);
             }
             par[gl] = -2;
-            par[32 + gl] = 0;
+            hgt[gl] = 0;
             // level 1: three cells from the root (treeobs.cpp:205-222)
-            int c_cell = -1, c_parent = 0, c_tot = 1, c_act = 0;
-            uint32_t c_dir = 0;
-            bool c_null = true;
+            int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
             if (gl < 3) {
                 c_act = gl - 1;
-                c_dir = (orientation + (uint32_t)(c_act + 4)) & 3u;
-                if ((rbits >> (3 - c_dir)) & 1) { c_cell = step_cell(vpos, c_dir, W); c_null = false; }
+                const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
+                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
             }
             int n_cur = 3, node_base = 1;
-            while (true) {
+            while (true) {  // pass A
                 const bool active = have && node_base < N && n_cur > 0;
                 if (!__any(active)) break;  // wave-uniform: both groups take part in the shuffles below
                 const int m = active ? min(n_cur, N - node_base) : 0;
                 const bool mine = gl < m;
                 const int idx_node = node_base + gl;
-                // children descriptors this lane would push (treeobs.cpp:583-608)
-                int ch_cell[3] = {-1, -1, -1};
-                uint32_t ch_dir[3] = {0, 0, 0};
-                int ch_tot = 0;
+                int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
                 bool explored = false;
                 if (mine) {
-                    if (c_null) {
-                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                        scale_and_store(nn, max_dist, A, F + (size_t)idx_node * 12);
-                    } else {
-                        BranchOut br;
-                        explore_branch_exact<true>(X, i, c_cell, c_dir, c_tot, br);
-                        if (br.zero_transition) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);
-                        scale_and_store(br.f, max_dist, A, F + (size_t)idx_node * 12);
+                    NodeDesc nd;
+                    nd.start = -1; nd.tot0 = 0; nd.nvis = 0; nd.end = 0; nd.flags = 0; nd.unus = -1;
+                    if (c_state >= 0) {
+                        nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
                         explored = true;
-                        ch_tot = br.tot_dist + 1;
-                        const uint32_t pbits = nibble(grid[br.end_cell], br.end_dir);
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            const uint32_t bd = (br.end_dir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
-                            ch_dir[k] = bd;
-                            if (br.is_dead_end && ((pbits >> (3 - rev)) & 1)) { ch_cell[k] = step_cell(br.end_cell, rev, W); ch_dir[k] = rev; }
-                            else if (br.is_switch && ((pbits >> (3 - bd)) & 1)) ch_cell[k] = step_cell(br.end_cell, bd, W);
-                        }
+                        ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
+                        ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
                     }
+                    n_start[idx_node] = nd.start; n_tot[idx_node] = nd.tot0; n_vis[idx_node] = nd.nvis; n_end[idx_node] = nd.end;
+                    n_flags[idx_node] = (int)nd.flags; n_unus[idx_node] = nd.unus;
                     int32_t *adj = ADJ + (size_t)(idx_node - 1) * 3;
                     adj[0] = c_parent; adj[1] = idx_node; adj[2] = c_act;
                     par[idx_node] = c_parent;
@@ -748,66 +736,83 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
                 const int src_rank = gl / 3, which = gl - 3 * src_rank;
                 const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
-                const int s_c0 = __shfl(ch_cell[0], src, 32), s_c1 = __shfl(ch_cell[1], src, 32), s_c2 = __shfl(ch_cell[2], src, 32);
-                const uint32_t s_d0 = __shfl(ch_dir[0], src, 32), s_d1 = __shfl(ch_dir[1], src, 32), s_d2 = __shfl(ch_dir[2], src, 32);
+                const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
                 const int s_tot = __shfl(ch_tot, src, 32);
                 if (active) {
                     const int parent_base = node_base;
                     node_base += m;
                     n_cur = n_next;
                     if (gl < n_next) {
-                        c_cell = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
-                        c_dir = which == 0 ? s_d0 : (which == 1 ? s_d1 : s_d2);
-                        c_null = c_cell < 0;
+                        c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
                         c_parent = parent_base + src;
                         c_tot = s_tot;
                         c_act = which - 1;
                     }
                 }
             }
-            if (have) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (have) {  // pass B: lane gl evaluates node gl + 1
+                const int idx = gl + 1;
+                if (idx < node_base) {
+                    volatile int *vs = scr;
+                    NodeDesc nd;
+                    nd.start = vs[idx]; nd.tot0 = vs[32 + idx]; nd.nvis = vs[64 + idx]; nd.end = vs[96 + idx];
+                    nd.flags = (uint32_t)vs[128 + idx]; nd.unus = vs[160 + idx];
+                    if (nd.start < 0) {
+                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                    } else {
+                        double f[12];
+                        node_features<true>(X, i, nd, f);
+                        if (nd.flags & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
+                        scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
+                    }
+                }
                 // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
-                for (int idx = node_base + gl; idx < N; idx += 32) {
+                for (int k = node_base + gl; k < N; k += 32) {
                     const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                    scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+                    scale_and_store(nn, max_dist, A, F + (size_t)k * 12);
+                    int32_t *adj = ADJ + (size_t)(k - 1) * 3;
                     adj[0] = adj[1] = adj[2] = -2;
                 }
             }
             // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
             // children in BFS numbering, so one reverse sweep settles it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             if (have && gl == 0) {
-                volatile int *vp = par;
+                volatile int *vp = par, *vh = hgt;
                 for (int k = N - 1; k >= 1; k--) {
                     const int p = vp[k];
-                    if (p >= 0) { const int hk = vp[32 + k] + 1; if (vp[32 + p] < hk) vp[32 + p] = hk; }
+                    if (p >= 0) { const int hk = vh[k] + 1; if (vh[p] < hk) vh[p] = hk; }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (have) {
                 int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-                volatile int *vp = par;
+                volatile int *vp = par, *vh = hgt;
                 for (int k = gl; k < N; k += 32) {
-                    NO[k] = k < node_base ? vp[32 + k] : -2;
-                    if (k >= 1) { const int p = vp[k]; EO[k - 1] = p < 0 ? -2 : vp[32 + p]; }
+                    NO[k] = k < node_base ? vh[k] : -2;
+                    if (k >= 1) { const int p = vp[k]; EO[k - 1] = p < 0 ? -2 : vh[p]; }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    for (int i = wave; !CUTILS && i < A; i += OBS_WAVES) {
-        const int g = b * A + i;
-        const int vpos = a_vpos[i];
-        const uint32_t dir = a_dir[i];
-        const uint32_t rbits = nibble(grid[vpos], dir);
-        uint32_t orientation = dir;
-        if (__popc(rbits) == 1) orientation = first_dir(rbits);
-        {
-            // upstream dense tree, DFS pre-order layout; level L is explored by 4^L lanes (observations.py:196-254, 464-494)
-            const int D = P.max_depth, NN = P.n_tree_nodes;
+    } else {
+        // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout; one wavefront per agent; level L
+        // of pass A is handled by 4^L lanes; every row that is not a real node is -inf
+        const int D = P.max_depth, NN = P.n_tree_nodes;
+        int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
+        { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
+        int *scr = wave_scr + wave * 512;  // NodeDesc fields [6][85]
+        for (int i = wave; i < A; i += OBS_WAVES) {
+            const int g = b * A + i;
+            const int vpos = a_vpos[i];
+            const uint32_t dir = a_dir[i];
+            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+            uint32_t orientation = dir;
+            if (__popc(rbits) == 1) orientation = first_dir(rbits);
             double *out = P.tree_out + (size_t)g * NN * 12;
             if (lane == 0) {
                 const uint16_t dv = X.dm[((size_t)a_tslot[i] * HW + vpos) * 4 + dir];
@@ -817,61 +822,65 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 root[10] = a_speed[i];
                 for (int k = 0; k < 12; k++) out[k] = root[k];
             }
-            // subtree sizes: sz[l] = nodes of a subtree rooted at depth l
-            int sz[6];
-            { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
-            // lane state for the level being explored
-            int c_cell = -1, c_tot = 1, c_index = 0;
-            uint32_t c_dir = 0;
-            bool c_real = false;
+            for (int k = lane; k < NN; k += 64) scr[k] = -1;  // start < 0: not a real node
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // pass A
+            int c_state = -1, c_tot = 1, c_index = -1;
             if (lane < 4) {
                 const uint32_t bd = (orientation + (uint32_t)(lane + 3)) & 3u;
                 c_index = 1 + lane * sz[1];
-                if ((rbits >> (3 - bd)) & 1) { c_cell = step_cell(vpos, bd, W); c_dir = bd; c_real = true; }
+                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
             }
             int width = 4;
             for (int level = 1; level <= D; level++) {
-                int ch_cell[4] = {-1, -1, -1, -1};
-                uint32_t ch_dir[4] = {0, 0, 0, 0};
+                int ch[4] = {-1, -1, -1, -1};
                 int ch_tot = 0;
-                if (lane < width && c_index >= 0) {
-                    double *row = out + (size_t)c_index * 12;
-                    if (c_real) {
-                        BranchOut br;
-                        explore_branch_exact<false>(X, i, c_cell, c_dir, c_tot, br);
-                        for (int k = 0; k < 12; k++) row[k] = br.f[k];
-                        ch_tot = br.tot_dist + 1;
-                        const uint32_t pbits = nibble(grid[br.end_cell], br.end_dir);
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t bd = (br.end_dir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
-                            if (br.is_dead_end && ((pbits >> (3 - rev)) & 1)) { ch_cell[k] = step_cell(br.end_cell, rev, W); ch_dir[k] = rev; }
-                            else if (br.is_switch && ((pbits >> (3 - bd)) & 1)) { ch_cell[k] = step_cell(br.end_cell, bd, W); ch_dir[k] = bd; }
-                        }
-                    } else {
-                        // missing child: the whole subtree is -inf
-                        const int n = sz[level] * 12;
-                        for (int k = 0; k < n; k++) row[k] = -INFINITY;
-                    }
+                if (lane < width && c_index >= 0 && c_state >= 0) {
+                    const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                    scr[c_index] = nd.start; scr[85 + c_index] = nd.tot0; scr[170 + c_index] = nd.nvis; scr[255 + c_index] = nd.end;
+                    scr[340 + c_index] = (int)nd.flags; scr[425 + c_index] = nd.unus;
+                    ch_tot = nd.tot0 + nd.nvis;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ch[k] = child_state(X, nd, k);
+                } else if (lane < width) {
+                    c_index = -1;  // missing node: its whole subtree stays -inf
                 }
                 if (level == D) break;
                 // children of lane p go to lanes 4p .. 4p+3 of the next level (all lanes take part in the shuffles)
                 const int src = lane >> 2, which = lane & 3;
                 const int p_index = __shfl(c_index, src);
-                const bool p_real = __shfl((int)c_real, src) != 0;
-                const int s0 = __shfl(ch_cell[0], src), s1 = __shfl(ch_cell[1], src), s2 = __shfl(ch_cell[2], src), s3 = __shfl(ch_cell[3], src);
-                const uint32_t e0 = __shfl(ch_dir[0], src), e1 = __shfl(ch_dir[1], src), e2 = __shfl(ch_dir[2], src), e3 = __shfl(ch_dir[3], src);
+                const int s0 = __shfl(ch[0], src), s1 = __shfl(ch[1], src), s2 = __shfl(ch[2], src), s3 = __shfl(ch[3], src);
                 const int s_tot = __shfl(ch_tot, src);
                 width *= 4;
-                c_index = -1;  // -1: nothing to write (covered by an ancestor's -inf fill, or lane unused)
-                c_real = false;
-                if (lane < width && p_index >= 0 && p_real) {
-                    c_cell = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
-                    c_dir = which == 0 ? e0 : which == 1 ? e1 : which == 2 ? e2 : e3;
+                c_index = -1;
+                c_state = -1;
+                if (lane < width && p_index >= 0) {
+                    c_state = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
                     c_tot = s_tot;
                     c_index = p_index + 1 + which * sz[level + 1];
-                    c_real = c_cell >= 0;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // pass B: one lane per row
+            for (int idx = 1 + lane; idx < NN; idx += 64) {
+                volatile int *vs = scr;
+                double *row = out + (size_t)idx * 12;
+                NodeDesc nd;
+                nd.start = vs[idx];
+                if (nd.start < 0) {
+                    for (int k = 0; k < 12; k++) row[k] = -INFINITY;
+                } else {
+                    nd.tot0 = vs[85 + idx]; nd.nvis = vs[170 + idx]; nd.end = vs[255 + idx];
+                    nd.flags = (uint32_t)vs[340 + idx]; nd.unus = vs[425 + idx];
+                    double f[12];
+                    node_features<false>(X, i, nd, f);
+                    for (int k = 0; k < 12; k++) row[k] = f[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     OBS_STAMP(5);
@@ -880,7 +889,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 // ---------------------------------------------------------------------------------------------- host side
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
-    o.keys = (d.W - 1) * d.W + d.H;
+    o.keys = d.H <= d.W ? d.H * d.W : (d.W - 1) * d.W + d.H;
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;
     if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
@@ -903,15 +912,15 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
 
 static size_t obs_lds_bytes(const FlDev &d, bool csr_lds) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
-    const size_t K = (size_t)(d.W - 1) * d.W + d.H;
+    const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 2) * 2 + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
-           al((size_t)OBS_GROUPS * 64 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
+    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
+           al((size_t)OBS_WAVES * 512 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
 }
 
 static bool obs_pick_csr_lds(const FlDev &d) {
-    const size_t K = (size_t)(d.W - 1) * d.W + d.H;
+    const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     return K <= OBS_CSR_LDS_MAX_KEYS && obs_lds_bytes(d, true) <= 160 * 1024;
 }
 
