@@ -560,55 +560,65 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             const size_t dmb = (size_t)a_tslot[i] * HW;
             int n = 0;
             bool none = false;
+            // last waypoint that can be occupied within the horizon; only those enter the per-key index
+            const int tpc = a_tpc[i];
+            const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
             if (cell == target) {  // holds at its position (DONE agents): predictions.cpp:208-214
+                atomicAdd(&csr[key_of(X, cell)], 1);
                 path[n++] = ((uint32_t)cell << 2) | dd;
             } else {
-                uint32_t distance = 0x10000u;  // +inf
+                // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265).
+                // On a BFS distance map dm[state] = 1 + min over its transitions, so a state with a single candidate
+                // always descends to dm - 1: only switches need distance gathers, the rest is walked on the LDS bitmap.
+                uint32_t distance = X.dm[(dmb + cell) * 4 + dd];  // finite <=> some candidate is strictly closer
                 int depth = 0;
-                // cutils walks max_depth iterations and stops where nothing is strictly closer (predictions.cpp:107-133);
-                // upstream stops at the target (rail_env_shortest_paths.py:245-265)
+                // cutils walks max_depth iterations and stops where nothing is strictly closer;
+                // upstream stops at the target
                 while (depth < pred_depth && (CUTILS || cell != target)) {
                     const uint32_t g = cellw[cell] & 0xFFFFu;
                     const uint32_t bits = nibble(g, dd);
                     int best = -1;
-                    if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
-                        const uint32_t ex = (dd + 2u) & 3u;
-                        if ((bits >> (3 - ex)) & 1) {
-                            const uint32_t v = X.dm[(dmb + step_cell(cell, ex, W)) * 4 + ex];
-                            if (v != FL_INF16 && v < distance) { best = (int)ex; distance = v; }
-                        }
-                    } else {
-                        // L, F, R: the reference's iteration order decides ties; the three gathers are independent
-                        uint32_t v3[3];
+                    if (cell != target && distance != FL_INF16) {
+                        if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
+                            const uint32_t ex = (dd + 2u) & 3u;
+                            if ((bits >> (3 - ex)) & 1) best = (int)ex;
+                        } else {
+                            const uint32_t fwd3 = bits & ~(1u << (3 - ((dd + 2u) & 3u)));  // L, F, R candidates
+                            if (__popc(fwd3) == 1 && fwd3 == bits) best = (int)first_dir(fwd3);
+                            else {
+                                // L, F, R in the reference's iteration order; ties go to the first minimum
+                                uint32_t v3[3], bestv = distance;
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            const uint32_t nd = (dd + (uint32_t)(j + 3)) & 3u;
-                            v3[j] = ((bits >> (3 - nd)) & 1) ? (uint32_t)X.dm[(dmb + step_cell(cell, nd, W)) * 4 + nd] : FL_INF16;
-                        }
+                                for (int j = 0; j < 3; j++) {
+                                    const uint32_t nd = (dd + (uint32_t)(j + 3)) & 3u;
+                                    v3[j] = ((bits >> (3 - nd)) & 1) ? (uint32_t)X.dm[(dmb + step_cell(cell, nd, W)) * 4 + nd] : FL_INF16;
+                                }
 #pragma unroll
-                        for (int j = 0; j < 3; j++)
-                            if (v3[j] != FL_INF16 && v3[j] < distance) { best = (int)((dd + (uint32_t)(j + 3)) & 3u); distance = v3[j]; }
+                                for (int j = 0; j < 3; j++)
+                                    if (v3[j] != FL_INF16 && v3[j] < bestv) { best = (int)((dd + (uint32_t)(j + 3)) & 3u); bestv = v3[j]; }
+                            }
+                        }
                     }
+                    if (n <= horizon) atomicAdd(&csr[key_of(X, cell)], 1);
                     path[n++] = ((uint32_t)cell << 2) | dd;
                     depth++;
                     if (best < 0) { none = true; break; }
                     cell = step_cell(cell, (uint32_t)best, W);
                     dd = (uint32_t)best;
+                    distance -= 1;
                 }
-                if (CUTILS) { if (!none) path[n++] = ((uint32_t)cell << 2) | dd; }
-                else {
-                    if (none) { n = 1; }  // path None: the agent stands still (predictions.py:150-156)
-                    else if (depth < pred_depth) path[n++] = ((uint32_t)cell << 2) | dd;
+                // the final waypoint (predictions.cpp:131-133; rail_env_shortest_paths.py:266-267 when not cut by max_depth)
+                if (!none && (CUTILS || depth < pred_depth)) {
+                    if (n <= horizon) atomicAdd(&csr[key_of(X, cell)], 1);
+                    path[n++] = ((uint32_t)cell << 2) | dd;
                 }
+                // upstream: a None path (nothing strictly closer) means the agent stands still (predictions.py:150-156);
+                // that only happens on the first step, where exactly one waypoint was counted
             }
-            // last waypoint that can be occupied within the horizon
             int lp = n - 1;
-            const int tpc = a_tpc[i];
-            const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
-            for (int k = 0; k <= lp; k++) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
         }
         __syncthreads();
         OBS_STAMP(3);
@@ -640,11 +650,12 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         }
         __syncthreads();
         if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; }
-        // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1])
-        for (int i = tid; i < A; i += nt) {
+        // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
+        // one wavefront per agent, one lane per waypoint
+        for (int i = wave; i < A; i += OBS_WAVES) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
-            for (int k = 0; k <= lp; k++) {
+            for (int k = lane; k <= lp; k += 64) {
                 const uint32_t w = path[k];
                 // closed time interval during which the agent is predicted on waypoint k
                 int tlo, thi;
