@@ -148,7 +148,7 @@ def main():
                          "note": "dependent-gather/latency-bound integer kernel; achieved = algorithmic bytes per launch / mean launch time"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload if args.workload in ("cfg2", "cfg3", "cfg1") else "cfg2",
+            out["cpu_baseline"] = cpu_baseline(args.workload,
                                                args.tree_depth, args.tree_pred)
         print(json.dumps(out))
     env.close()

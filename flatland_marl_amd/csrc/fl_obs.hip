@@ -343,6 +343,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 #else
 #define OBS_STAMP(k) do {} while (0)
 #endif
+#ifdef FL_OBS_TIMING
+    if (tid == 0) { P.dbg[(size_t)b * 8 + 6] = 0; P.dbg[(size_t)b * 8 + 7] = 0; }
+#endif
     OBS_STAMP(0);
 
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
@@ -552,7 +555,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         for (int k = tid; k <= K; k += nt) csr[k] = 0;
         __syncthreads();
         const int pred_depth = P.pred_depth;
-        for (int i = tid; i < A; i += nt) {
+        // one walker per agent, spread over the wavefronts first: walkers that share a wavefront serialise each other's
+        // divergent steps (a lane at a switch makes the whole wave wait for its distance gathers)
+        for (int i = lane * OBS_WAVES + wave; i < A; i += OBS_NT) {  // A <= 1024 = 64 lanes x 16 waves: one pass
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
             uint32_t dd = a_dir[i];
@@ -571,6 +576,10 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 // On a BFS distance map dm[state] = 1 + min over its transitions, so a state with a single candidate
                 // always descends to dm - 1: only switches need distance gathers, the rest is walked on the LDS bitmap.
                 uint32_t distance = X.dm[(dmb + cell) * 4 + dd];  // finite <=> some candidate is strictly closer
+                // consume the gather here: inside the loop its wait would also wait for the previous iteration's path
+                // store (loads and stores retire in order on vmcnt), i.e. one HBM round trip per step
+                const bool reachable = distance != FL_INF16;
+                asm volatile("" :: "v"(reachable));
                 int depth = 0;
                 // cutils walks max_depth iterations and stops where nothing is strictly closer;
                 // upstream stops at the target
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     const uint32_t g = cellw[cell] & 0xFFFFu;
                     const uint32_t bits = nibble(g, dd);
                     int best = -1;
-                    if (cell != target && distance != FL_INF16) {
+                    if (cell != target && reachable) {
                         if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
                             const uint32_t ex = (dd + 2u) & 3u;
                             if ((bits >> (3 - ex)) & 1) best = (int)ex;
@@ -619,6 +628,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
+#ifdef FL_OBS_TIMING
+            { const long long tw = (long long)wall_clock64() - P.dbg[(size_t)b * 8 + 2];
+              // longest walk of the env: (clocks since phase-2 start) << 16 | steps
+              atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 6], ((unsigned long long)tw << 16) | (unsigned long long)n); }
+#endif
         }
         __syncthreads();
         OBS_STAMP(3);
@@ -738,9 +752,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     }
                     n_start[idx_node] = nd.start; n_tot[idx_node] = nd.tot0; n_vis[idx_node] = nd.nvis; n_end[idx_node] = nd.end;
                     n_flags[idx_node] = (int)nd.flags; n_unus[idx_node] = nd.unus;
-                    int32_t *adj = ADJ + (size_t)(idx_node - 1) * 3;
-                    adj[0] = c_parent; adj[1] = idx_node; adj[2] = c_act;
                     par[idx_node] = c_parent;
+                    hgt[idx_node] = c_act;  // parked here until pass B writes the adjacency row (heights start after that)
                 }
                 const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
                 const int n_next = 3 * __popc(exp_mask);
@@ -767,6 +780,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 const int idx = gl + 1;
                 if (idx < node_base) {
                     volatile int *vs = scr;
+                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+                    adj[0] = vs[192 + idx]; adj[1] = idx; adj[2] = vs[224 + idx];
                     NodeDesc nd;
                     nd.start = vs[idx]; nd.tot0 = vs[32 + idx]; nd.nvis = vs[64 + idx]; nd.end = vs[96 + idx];
                     nd.flags = (uint32_t)vs[128 + idx]; nd.unus = vs[160 + idx];
@@ -790,6 +805,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             }
             // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
             // children in BFS numbering, so one reverse sweep settles it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            hgt[gl] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (have && gl == 0) {
                 volatile int *vp = par, *vh = hgt;
                 for (int k = N - 1; k >= 1; k--) {

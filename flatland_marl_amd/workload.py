@@ -22,6 +22,11 @@ WORKLOADS = {
     # BASELINE.json configs[2]: 1024 envs x 35x30 / 80 agents / 5 cities, malfunctions on
     "cfg3": dict(bases=["cfg3_uniform"] + ["base_cfg3_L%d" % i for i in range(1, 4)], B=1024,
                  pinned=("cfg3_uniform", 21), desc="1024 envs x 35x30 / 80 agents / 5 cities (Round-2 Test_4)"),
+    # BASELINE.json configs[3] / configs[4] per-GPU shards (512 resp. 256 envs per GPU on an 8-GPU node); one base env each
+    "cfg4": dict(bases=["cfg4_fwd_head"], B=512, pinned=("cfg4_fwd_head", 31),
+                 desc="512 envs/GPU x 60x60 / 80 agents / 17 cities (Round-2 Test_8)"),
+    "cfg5": dict(bases=["cfg5_fwd_head"], B=256, pinned=("cfg5_fwd_head", 41),
+                 desc="256 envs/GPU x 150x150 / 400 agents / 37 cities (Round-2 Test_13)"),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case
     "cfg1": dict(bases=["cfg1_uniform"], B=1, pinned=("cfg1_uniform", 1), desc="1 env 30x30 / 7 agents / 2 cities"),
 }
