@@ -628,11 +628,6 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
-#ifdef FL_OBS_TIMING
-            { const long long tw = (long long)wall_clock64() - P.dbg[(size_t)b * 8 + 2];
-              // longest walk of the env: (clocks since phase-2 start) << 16 | steps
-              atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 6], ((unsigned long long)tw << 16) | (unsigned long long)n); }
-#endif
         }
         __syncthreads();
         OBS_STAMP(3);
@@ -776,6 +771,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef FL_OBS_TIMING
+            if (have && gl == 0) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 6], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
+#endif
             if (have) {  // pass B: lane gl evaluates node gl + 1
                 const int idx = gl + 1;
                 if (idx < node_base) {
@@ -803,6 +801,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     adj[0] = adj[1] = adj[2] = -2;
                 }
             }
+#ifdef FL_OBS_TIMING
+            if (have) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 7], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
+#endif
             // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
             // children in BFS numbering, so one reverse sweep settles it
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
