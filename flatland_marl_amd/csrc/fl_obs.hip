@@ -112,26 +112,34 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, i
     return n;
 }
 
-// the agent-dependent features of a walk: everything that depends on where the other agents are and are predicted
+// the agent-dependent features of (a slice of) a walk: everything that depends on where the other agents are and
+// are predicted to be
 struct WalkDyn {
     int other_agent, pot_conflict, other_target;  // tot_dist of the first hit, INT_MAX = none
     int same_dir, opp_dir, malfunctioning, ready;
     double min_speed;
 };
 
+// advance k cells along a chain of single-transition cells (no features)
+__device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t &d, int k) {
+    for (int v = 0; v < k; v++) {
+        d = first_dir(nibble(X.cellw[cell] & 0xFFFFu, d));
+        cell = step_cell(cell, d, X.W);
+    }
+}
+
+// feature block of `count` consecutive cells of a branch walk starting at (cell, d) with tot_dist `tot`
+// (treeobs.cpp:322-465 / observations.py:296-371)
 template <bool CUTILS>
-__device__ void walk_dynamic(const ObsCtx &X, int handle, const NodeDesc &nd, WalkDyn &o) {
+__device__ void walk_cells(const ObsCtx &X, int handle, int cell, uint32_t d, int tot, int count, WalkDyn &o) {
     const int W = X.W;
     const int target = X.a_target[handle];
-    int cell = nd.start >> 2;
-    uint32_t d = nd.start & 3;
-    int tot = nd.tot0;
     o.other_agent = o.pot_conflict = o.other_target = 0x7fffffff;
     o.same_dir = o.opp_dir = o.malfunctioning = o.ready = 0;
     o.min_speed = 1.0;
     const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
     const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
-    for (int v = 0; v < nd.nvis; v++) {
+    for (int v = 0; v < count; v++) {
         const uint32_t cw = X.cellw[cell];
         const uint32_t bits = nibble(cw & 0xFFFFu, d);
         const uint32_t sl = cw >> 16;
@@ -171,8 +179,8 @@ __device__ void walk_dynamic(const ObsCtx &X, int handle, const NodeDesc &nd, Wa
                             if (e0 + q >= hi) break;
                             const uint32_t it = itv[q];
                             const uint32_t tl = IT_TLO(it), th = IT_THI(it);
+                            if (th < t1 || tl > t2) continue;  // not predicted here anywhere near this time
                             const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
-                            if (!(in0 | in1 | in2)) continue;
                             const int a = IT_AGENT(it);
                             const uint32_t cd = IT_DIR(it);
                             const bool oth = a != handle;
@@ -204,7 +212,7 @@ __device__ void walk_dynamic(const ObsCtx &X, int handle, const NodeDesc &nd, Wa
         }
         if (!CUTILS && o.other_target == 0x7fffffff && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target)
             o.other_target = tot;  // cutils never fills the map (treeobs.cpp:72)
-        if (v + 1 < nd.nvis) {  // keep walking along the only transition
+        if (v + 1 < count) {  // keep walking along the only transition
             d = first_dir(bits);
             cell = step_cell(cell, d, W);
             tot += 1;
@@ -212,26 +220,104 @@ __device__ void walk_dynamic(const ObsCtx &X, int handle, const NodeDesc &nd, Wa
     }
 }
 
-// the 12 node features (treeobs.cpp:546-573 / observations.py:433-461), as doubles
-template <bool CUTILS>
-__device__ __forceinline__ void node_features(const ObsCtx &X, int handle, const NodeDesc &nd, double *f) {
-    WalkDyn w;
-    walk_dynamic<CUTILS>(X, handle, nd, w);
-    const int tot_end = nd.tot0 + nd.nvis - 1;
-    const bool tgt = nd.flags & ND_TARGET;
+// per-team node table in LDS: CAP entries per field
+enum { F_START = 0, F_TOT, F_VIS, F_END, F_FLAGS, F_UNUS, F_PAR, F_HGT, F_INCL, F_OA, F_PC, F_OT, F_SAME, F_OPP, F_MALF,
+       F_READY, F_MS /* u64: two ints per node */, F_WORDS = 18 };
+
+__device__ __forceinline__ void team_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Pass B of a tree: the visited cells of ALL nodes (node k has n_vis[k] of them) are split evenly over the TEAM lanes;
+// every lane walks its slice (a cheap skip to the slice start, then the feature block per cell) and merges its
+// partial result into the node's accumulators with LDS atomics (min / sum / max are associative).
+template <bool CUTILS, int TEAM, int CAP>
+__device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool have, int tl, int n_nodes, int *scr) {
+    volatile int *vs = scr;
+    unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
+    // accumulators + inclusive prefix of the visit counts
+    int run_base = 0;
+    for (int k0 = 0; k0 < CAP; k0 += TEAM) {
+        const int k = k0 + tl;
+        int v = (k < n_nodes && k < CAP) ? vs[F_VIS * CAP + k] : 0;
+        if (k < CAP && (k >= n_nodes || vs[F_START * CAP + k] < 0)) v = 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < TEAM; off <<= 1) { const int u = __shfl_up(incl, off, TEAM); if (tl >= off) incl += u; }
+        incl += run_base;
+        if (k < CAP) {
+            scr[F_INCL * CAP + k] = incl;
+            scr[F_OA * CAP + k] = 0x7fffffff; scr[F_PC * CAP + k] = 0x7fffffff; scr[F_OT * CAP + k] = 0x7fffffff;
+            scr[F_SAME * CAP + k] = 0; scr[F_OPP * CAP + k] = 0; scr[F_MALF * CAP + k] = 0; scr[F_READY * CAP + k] = 0;
+            ms[k] = 0x3FF0000000000000ull;  // 1.0; positive doubles order like their bit patterns
+        }
+        run_base = __shfl(incl, TEAM - 1, TEAM);
+    }
+    team_sync();
+    const int total = have ? run_base : 0;
+    const int q = (total + TEAM - 1) / TEAM;
+    int pos = tl * q;
+    const int end = min(pos + q, total);
+    if (pos < end) {
+        // first node whose inclusive prefix exceeds pos
+        int lo = 0, hi = n_nodes - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (vs[F_INCL * CAP + mid] > pos) hi = mid; else lo = mid + 1;
+        }
+        int node = lo;
+        while (pos < end) {
+            const int nvis = vs[F_VIS * CAP + node];
+            const int incl = vs[F_INCL * CAP + node];
+            const int k = pos - (incl - nvis);  // offset inside the node's walk
+            const int cnt = min(nvis - k, end - pos);
+            const int st = vs[F_START * CAP + node];
+            int cell = st >> 2;
+            uint32_t dd = st & 3;
+            skip_cells(X, cell, dd, k);
+            WalkDyn w;
+            walk_cells<CUTILS>(X, handle, cell, dd, vs[F_TOT * CAP + node] + k, cnt, w);
+            if (w.other_agent != 0x7fffffff) atomicMin(&scr[F_OA * CAP + node], w.other_agent);
+            if (w.pot_conflict != 0x7fffffff) atomicMin(&scr[F_PC * CAP + node], w.pot_conflict);
+            if (w.other_target != 0x7fffffff) atomicMin(&scr[F_OT * CAP + node], w.other_target);
+            if (w.same_dir) atomicAdd(&scr[F_SAME * CAP + node], w.same_dir);
+            if (w.opp_dir) atomicAdd(&scr[F_OPP * CAP + node], w.opp_dir);
+            if (w.malfunctioning) atomicMax(&scr[F_MALF * CAP + node], w.malfunctioning);
+            if (w.ready) atomicAdd(&scr[F_READY * CAP + node], w.ready);
+            if (w.min_speed < 1.0) atomicMin(&ms[node], (unsigned long long)__double_as_longlong(w.min_speed));
+            pos += cnt;
+            do { node++; } while (pos < end && node < n_nodes && (vs[F_VIS * CAP + node] == 0 || vs[F_START * CAP + node] < 0));
+        }
+    }
+    team_sync();
+}
+
+// the 12 features of node k from its descriptor and accumulators (treeobs.cpp:546-573 / observations.py:433-461)
+template <int CAP>
+__device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int *scr, int k, double *f) {
+    volatile const int *vs = scr;
+    const unsigned long long *ms = reinterpret_cast<const unsigned long long *>(scr + F_MS * CAP);
+    const int tot_end = vs[F_TOT * CAP + k] + vs[F_VIS * CAP + k] - 1;
+    const uint32_t flags = (uint32_t)vs[F_FLAGS * CAP + k];
+    const bool tgt = flags & ND_TARGET;
     double dist_min = 0;
     if (!tgt) {
-        const uint16_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + nd.end];
+        const uint16_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + vs[F_END * CAP + k]];
         dist_min = dv == FL_INF16 ? INFINITY : (double)dv;
     }
+    const int oa = vs[F_OA * CAP + k], pc = vs[F_PC * CAP + k], ot = vs[F_OT * CAP + k], un = vs[F_UNUS * CAP + k];
     f[0] = tgt ? (double)tot_end : INFINITY;
-    f[1] = w.other_target == 0x7fffffff ? INFINITY : (double)w.other_target;
-    f[2] = w.other_agent == 0x7fffffff ? INFINITY : (double)w.other_agent;
-    f[3] = w.pot_conflict == 0x7fffffff ? INFINITY : (double)w.pot_conflict;
-    f[4] = nd.unus < 0 ? INFINITY : (double)nd.unus;
-    f[5] = (nd.flags & ND_TERMINAL) ? INFINITY : (double)tot_end;
+    f[1] = ot == 0x7fffffff ? INFINITY : (double)ot;
+    f[2] = oa == 0x7fffffff ? INFINITY : (double)oa;
+    f[3] = pc == 0x7fffffff ? INFINITY : (double)pc;
+    f[4] = un < 0 ? INFINITY : (double)un;
+    f[5] = (flags & ND_TERMINAL) ? INFINITY : (double)tot_end;
     f[6] = dist_min;
-    f[7] = w.same_dir; f[8] = w.opp_dir; f[9] = w.malfunctioning; f[10] = w.min_speed; f[11] = w.ready;
+    f[7] = vs[F_SAME * CAP + k]; f[8] = vs[F_OPP * CAP + k]; f[9] = vs[F_MALF * CAP + k];
+    f[10] = __longlong_as_double((long long)((volatile const unsigned long long *)ms)[k]);
+    f[11] = vs[F_READY * CAP + k];
 }
 
 // children of a node (treeobs.cpp:583-608 / observations.py:464-489): child k (k = 0 left, 1 forward, 2 right, 3 back)
@@ -289,6 +375,7 @@ __device__ __forceinline__ int road_type_of(uint32_t cell) {  // loader.cpp:122-
     return 0;
 }
 
+
 // ---------------------------------------------------------------------------------------------- kernel
 // MODE 0 = flatland_cutils outputs, MODE 1 = upstream dense tree.
 struct ObsArgs {
@@ -300,7 +387,100 @@ struct ObsArgs {
     double *tree_out;
     int n_tree_nodes;
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
+    int scr_words;   // ints of tree scratch per wavefront
 };
+
+// upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
+// (TEAM = 32: two agents per wavefront, depth <= 2; TEAM = 64: depth 3).  Level L of pass A is handled by 4^L lanes;
+// every row that is not a real node is -inf.
+template <int TEAM, int CAP>
+__device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
+                                              int nwaves, int *wave_scr_base, const uint32_t *cellw, const int *a_vpos,
+                                              const uint8_t *a_dir, const uint16_t *a_malf, const double *a_speed,
+                                              const int *a_tslot) {
+    constexpr int TPW = 64 / TEAM;  // teams per wavefront
+    const int A = X.A, W = X.W, HW = X.HW;
+    const int team = lane / TEAM, tl = lane % TEAM;
+    const int D = P.max_depth, NN = P.n_tree_nodes;
+    int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
+    { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
+    int *scr = wave_scr_base + team * (F_WORDS * CAP);
+    for (int base = 0; base < A; base += nwaves * TPW) {
+        const int i = base + wave * TPW + team;
+        const bool have = i < A;
+        const int ia = have ? i : 0;
+        const int g = b * A + ia;
+        const int vpos = a_vpos[ia];
+        const uint32_t dir = a_dir[ia];
+        const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+        uint32_t orientation = dir;
+        if (__popc(rbits) == 1) orientation = first_dir(rbits);
+        double *out = P.tree_out + (size_t)g * NN * 12;
+        if (have && tl == 0) {
+            const uint16_t dv = X.dm[((size_t)a_tslot[i] * HW + vpos) * 4 + dir];
+            double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
+            root[9] = (double)a_malf[i];
+            root[10] = a_speed[i];
+            for (int k = 0; k < 12; k++) out[k] = root[k];
+        }
+        for (int k = tl; k < CAP; k += TEAM) { scr[F_START * CAP + k] = -1; scr[F_VIS * CAP + k] = 0; }
+        team_sync();
+        // pass A
+        int c_state = -1, c_tot = 1, c_index = -1;
+        if (tl < 4) {
+            const uint32_t bd = (orientation + (uint32_t)(tl + 3)) & 3u;
+            c_index = 1 + tl * sz[1];
+            if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
+        }
+        int width = 4;
+        for (int level = 1; level <= D; level++) {
+            int ch[4] = {-1, -1, -1, -1};
+            int ch_tot = 0;
+            if (have && tl < width && c_index >= 0 && c_state >= 0) {
+                const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                scr[F_START * CAP + c_index] = nd.start; scr[F_TOT * CAP + c_index] = nd.tot0;
+                scr[F_VIS * CAP + c_index] = nd.nvis; scr[F_END * CAP + c_index] = nd.end;
+                scr[F_FLAGS * CAP + c_index] = (int)nd.flags; scr[F_UNUS * CAP + c_index] = nd.unus;
+                ch_tot = nd.tot0 + nd.nvis;
+#pragma unroll
+                for (int k = 0; k < 4; k++) ch[k] = child_state(X, nd, k);
+            } else if (tl < width) {
+                c_index = -1;  // missing node: its whole subtree stays -inf
+            }
+            if (level == D) break;
+            // children of lane p go to lanes 4p .. 4p+3 of the next level (all lanes take part in the shuffles)
+            const int src = tl >> 2, which = tl & 3;
+            const int p_index = __shfl(c_index, src, TEAM);
+            const int s0 = __shfl(ch[0], src, TEAM), s1 = __shfl(ch[1], src, TEAM), s2 = __shfl(ch[2], src, TEAM), s3 = __shfl(ch[3], src, TEAM);
+            const int s_tot = __shfl(ch_tot, src, TEAM);
+            width *= 4;
+            c_index = -1;
+            c_state = -1;
+            if (tl < width && p_index >= 0) {
+                c_state = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
+                c_tot = s_tot;
+                c_index = p_index + 1 + which * sz[level + 1];
+            }
+        }
+        team_sync();
+        team_pass_b<false, TEAM, CAP>(X, ia, have, tl, have ? NN : 1, scr);
+        if (have) {  // rows
+            volatile int *vs = scr;
+            for (int idx = 1 + tl; idx < NN; idx += TEAM) {
+                double *row = out + (size_t)idx * 12;
+                if (vs[F_START * CAP + idx] < 0) {
+                    for (int k = 0; k < 12; k++) row[k] = -INFINITY;
+                } else {
+                    double f[12];
+                    node_row<CAP>(X, i, scr, idx, f);
+                    for (int k = 0; k < 12; k++) row[k] = f[k];
+                }
+            }
+        }
+        team_sync();
+    }
+}
 
 template <int MODE, bool CSR_LDS>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
@@ -331,8 +511,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
-    int *wave_scr = (int *)carve((size_t)OBS_WAVES * 512 * 4);  // per-wave node descriptors / parent / height scratch
-    int *partial = (int *)carve((size_t)OBS_NT * 4);           // scan scratch
+    int *wave_scr = (int *)carve((size_t)(nt >> 6) * P.scr_words * 4);  // per-wave tree scratch (node tables)
+    int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
 
@@ -557,7 +737,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         const int pred_depth = P.pred_depth;
         // one walker per agent, spread over the wavefronts first: walkers that share a wavefront serialise each other's
         // divergent steps (a lane at a switch makes the whole wave wait for its distance gathers)
-        for (int i = lane * OBS_WAVES + wave; i < A; i += OBS_NT) {  // A <= 1024 = 64 lanes x 16 waves: one pass
+        for (int i = lane * (nt >> 6) + wave; i < A; i += nt) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
             uint32_t dd = a_dir[i];
@@ -640,17 +820,18 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
-                // each lane of wave 0 owns OBS_NT / 64 consecutive partials
+                // each lane of wave 0 owns nt / 64 consecutive partials
                 constexpr int PER = OBS_NT / 64;
+                const int per = nt >> 6;
                 int loc[PER], tot = 0;
 #pragma unroll
-                for (int q = 0; q < PER; q++) { loc[q] = partial[lane * PER + q]; tot += loc[q]; }
+                for (int q = 0; q < PER; q++) { loc[q] = q < per ? partial[lane * per + q] : 0; tot += loc[q]; }
                 int incl = tot;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
                 int run = incl - tot;
 #pragma unroll
-                for (int q = 0; q < PER; q++) { partial[lane * PER + q] = run; run += loc[q]; }
+                for (int q = 0; q < PER; q++) { if (q < per) partial[lane * per + q] = run; run += loc[q]; }
             }
             __syncthreads();
             int run = partial[tid];
@@ -661,7 +842,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
-        for (int i = wave; i < A; i += OBS_WAVES) {
+        for (int i = wave; i < A; i += (nt >> 6)) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             for (int k = lane; k <= lp; k += 64) {
@@ -684,17 +865,17 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 
     OBS_STAMP(4);
     // ---- phase 3: trees.  Pass A derives the topology of a tree from the static segment table (O(1) per node, one
-    // BFS level per step); pass B then evaluates the agent-dependent features of ALL nodes of the tree concurrently,
-    // one lane per node.
+    // BFS level per step); pass B evaluates the agent-dependent features with the visited cells of all nodes split
+    // evenly over the lanes of the team (team_pass_b); then one lane per node writes its row.
     const float max_dist = (float)T;
+    const int nwaves = nt >> 6;
     if (CUTILS) {
-        // two agents per wavefront, 32 lanes each
+        // two agents per wavefront, a team of 32 lanes each
+        constexpr int CAP = 32;
         const int grp = lane >> 5, gl = lane & 31;
         const int N = P.max_nodes;
-        int *scr = wave_scr + wave * 512 + grp * 256;  // per group: NodeDesc fields [6][32], parent[32], height[32]
-        int *n_start = scr, *n_tot = scr + 32, *n_vis = scr + 64, *n_end = scr + 96, *n_flags = scr + 128, *n_unus = scr + 160;
-        int *par = scr + 192, *hgt = scr + 224;
-        for (int base = 0; base < A; base += OBS_GROUPS) {
+        int *scr = wave_scr + wave * P.scr_words + grp * (F_WORDS * CAP);
+        for (int base = 0; base < A; base += nwaves * 2) {
             const int i = base + wave * 2 + grp;
             const bool have = i < A;
             const int ia = have ? i : 0;
@@ -718,8 +899,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 root[10] = (double)(float)a_speed[i];
                 scale_and_store(root, max_dist, A, F);
             }
-            par[gl] = -2;
-            hgt[gl] = 0;
+            scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
+            scr[F_PAR * CAP + gl] = -2;
             // level 1: three cells from the root (treeobs.cpp:205-222)
             int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
             if (gl < 3) {
@@ -730,25 +911,24 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             int n_cur = 3, node_base = 1;
             while (true) {  // pass A
                 const bool active = have && node_base < N && n_cur > 0;
-                if (!__any(active)) break;  // wave-uniform: both groups take part in the shuffles below
+                if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
                 const int m = active ? min(n_cur, N - node_base) : 0;
                 const bool mine = gl < m;
                 const int idx_node = node_base + gl;
                 int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
                 bool explored = false;
                 if (mine) {
-                    NodeDesc nd;
-                    nd.start = -1; nd.tot0 = 0; nd.nvis = 0; nd.end = 0; nd.flags = 0; nd.unus = -1;
                     if (c_state >= 0) {
-                        nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                        const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
                         explored = true;
                         ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
                         ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
+                        scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
+                        scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
+                        scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
                     }
-                    n_start[idx_node] = nd.start; n_tot[idx_node] = nd.tot0; n_vis[idx_node] = nd.nvis; n_end[idx_node] = nd.end;
-                    n_flags[idx_node] = (int)nd.flags; n_unus[idx_node] = nd.unus;
-                    par[idx_node] = c_parent;
-                    hgt[idx_node] = c_act;  // parked here until pass B writes the adjacency row (heights start after that)
+                    scr[F_PAR * CAP + idx_node] = c_parent;
+                    scr[F_HGT * CAP + idx_node] = c_act;  // parked here until the adjacency row is written
                 }
                 const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
                 const int n_next = 3 * __popc(exp_mask);
@@ -769,151 +949,63 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
 #ifdef FL_OBS_TIMING
             if (have && gl == 0) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 6], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
 #endif
-            if (have) {  // pass B: lane gl evaluates node gl + 1
-                const int idx = gl + 1;
-                if (idx < node_base) {
-                    volatile int *vs = scr;
-                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
-                    adj[0] = vs[192 + idx]; adj[1] = idx; adj[2] = vs[224 + idx];
-                    NodeDesc nd;
-                    nd.start = vs[idx]; nd.tot0 = vs[32 + idx]; nd.nvis = vs[64 + idx]; nd.end = vs[96 + idx];
-                    nd.flags = (uint32_t)vs[128 + idx]; nd.unus = vs[160 + idx];
-                    if (nd.start < 0) {
-                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                    } else {
-                        double f[12];
-                        node_features<true>(X, i, nd, f);
-                        if (nd.flags & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
-                        scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
-                    }
-                }
-                // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
-                for (int k = node_base + gl; k < N; k += 32) {
-                    const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                    scale_and_store(nn, max_dist, A, F + (size_t)k * 12);
-                    int32_t *adj = ADJ + (size_t)(k - 1) * 3;
-                    adj[0] = adj[1] = adj[2] = -2;
-                }
-            }
+            team_pass_b<true, 32, CAP>(X, ia, have, gl, have ? node_base : 1, scr);
 #ifdef FL_OBS_TIMING
             if (have) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 7], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
 #endif
+            if (have) {  // rows: lane gl writes node gl + 1
+                volatile int *vs = scr;
+                for (int idx = gl + 1; idx < N; idx += 32) {
+                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+                    if (idx < node_base) {
+                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = vs[F_HGT * CAP + idx];
+                        if (vs[F_START * CAP + idx] < 0) {
+                            const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                            scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                        } else {
+                            double f[12];
+                            node_row<CAP>(X, i, scr, idx, f);
+                            if (vs[F_FLAGS * CAP + idx] & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
+                            scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
+                        }
+                    } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
+                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                        adj[0] = adj[1] = adj[2] = -2;
+                    }
+                }
+            }
             // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
             // children in BFS numbering, so one reverse sweep settles it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            hgt[gl] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
+            scr[F_HGT * CAP + gl] = 0;
+            team_sync();
             if (have && gl == 0) {
-                volatile int *vp = par, *vh = hgt;
+                volatile int *vp = scr + F_PAR * CAP, *vh = scr + F_HGT * CAP;
                 for (int k = N - 1; k >= 1; k--) {
                     const int p = vp[k];
                     if (p >= 0) { const int hk = vh[k] + 1; if (vh[p] < hk) vh[p] = hk; }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
             if (have) {
                 int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-                volatile int *vp = par, *vh = hgt;
+                volatile int *vp = scr + F_PAR * CAP, *vh = scr + F_HGT * CAP;
                 for (int k = gl; k < N; k += 32) {
                     NO[k] = k < node_base ? vh[k] : -2;
                     if (k >= 1) { const int p = vp[k]; EO[k - 1] = p < 0 ? -2 : vh[p]; }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
         }
+    } else if (P.max_depth <= 2) {
+        tree_upstream<32, 32>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     } else {
-        // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout; one wavefront per agent; level L
-        // of pass A is handled by 4^L lanes; every row that is not a real node is -inf
-        const int D = P.max_depth, NN = P.n_tree_nodes;
-        int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
-        { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
-        int *scr = wave_scr + wave * 512;  // NodeDesc fields [6][85]
-        for (int i = wave; i < A; i += OBS_WAVES) {
-            const int g = b * A + i;
-            const int vpos = a_vpos[i];
-            const uint32_t dir = a_dir[i];
-            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
-            uint32_t orientation = dir;
-            if (__popc(rbits) == 1) orientation = first_dir(rbits);
-            double *out = P.tree_out + (size_t)g * NN * 12;
-            if (lane == 0) {
-                const uint16_t dv = X.dm[((size_t)a_tslot[i] * HW + vpos) * 4 + dir];
-                double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
-                root[9] = (double)a_malf[i];
-                root[10] = a_speed[i];
-                for (int k = 0; k < 12; k++) out[k] = root[k];
-            }
-            for (int k = lane; k < NN; k += 64) scr[k] = -1;  // start < 0: not a real node
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // pass A
-            int c_state = -1, c_tot = 1, c_index = -1;
-            if (lane < 4) {
-                const uint32_t bd = (orientation + (uint32_t)(lane + 3)) & 3u;
-                c_index = 1 + lane * sz[1];
-                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
-            }
-            int width = 4;
-            for (int level = 1; level <= D; level++) {
-                int ch[4] = {-1, -1, -1, -1};
-                int ch_tot = 0;
-                if (lane < width && c_index >= 0 && c_state >= 0) {
-                    const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
-                    scr[c_index] = nd.start; scr[85 + c_index] = nd.tot0; scr[170 + c_index] = nd.nvis; scr[255 + c_index] = nd.end;
-                    scr[340 + c_index] = (int)nd.flags; scr[425 + c_index] = nd.unus;
-                    ch_tot = nd.tot0 + nd.nvis;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) ch[k] = child_state(X, nd, k);
-                } else if (lane < width) {
-                    c_index = -1;  // missing node: its whole subtree stays -inf
-                }
-                if (level == D) break;
-                // children of lane p go to lanes 4p .. 4p+3 of the next level (all lanes take part in the shuffles)
-                const int src = lane >> 2, which = lane & 3;
-                const int p_index = __shfl(c_index, src);
-                const int s0 = __shfl(ch[0], src), s1 = __shfl(ch[1], src), s2 = __shfl(ch[2], src), s3 = __shfl(ch[3], src);
-                const int s_tot = __shfl(ch_tot, src);
-                width *= 4;
-                c_index = -1;
-                c_state = -1;
-                if (lane < width && p_index >= 0) {
-                    c_state = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
-                    c_tot = s_tot;
-                    c_index = p_index + 1 + which * sz[level + 1];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // pass B: one lane per row
-            for (int idx = 1 + lane; idx < NN; idx += 64) {
-                volatile int *vs = scr;
-                double *row = out + (size_t)idx * 12;
-                NodeDesc nd;
-                nd.start = vs[idx];
-                if (nd.start < 0) {
-                    for (int k = 0; k < 12; k++) row[k] = -INFINITY;
-                } else {
-                    nd.tot0 = vs[85 + idx]; nd.nvis = vs[170 + idx]; nd.end = vs[255 + idx];
-                    nd.flags = (uint32_t)vs[340 + idx]; nd.unus = vs[425 + idx];
-                    double f[12];
-                    node_features<false>(X, i, nd, f);
-                    for (int k = 0; k < 12; k++) row[k] = f[k];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+        tree_upstream<64, 88>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     }
     OBS_STAMP(5);
 }
@@ -942,25 +1034,35 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
-           al((size_t)OBS_WAVES * 512 * 4) + al((size_t)OBS_NT * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
+           al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
 }
 
-static bool obs_pick_csr_lds(const FlDev &d) {
+// pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
+static bool obs_pick_config(const FlDev &d, int scr_words, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
-    return K <= OBS_CSR_LDS_MAX_KEYS && obs_lds_bytes(d, true) <= 160 * 1024;
+    const int nts[3] = {OBS_NT, 512, 256};
+    for (int c = 0; c < 2; c++) {
+        csr_lds = c == 0 && K <= OBS_CSR_LDS_MAX_KEYS;
+        if (c == 0 && !csr_lds) continue;
+        for (int k = 0; k < 3; k++) {
+            nt = nts[k];
+            lds = obs_lds_bytes(d, csr_lds, nt, scr_words);
+            if (lds <= 160 * 1024) return true;
+        }
+    }
+    return false;
 }
 
 template <typename KernelT>
-static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, size_t lds, hipStream_t s) {
-    if (lds > 160 * 1024) return FL_ERR_ARG;
+static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, size_t lds, int nt, hipStream_t s) {
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(d.B), dim3(OBS_NT), lds, s, d, o, P);
+    hipLaunchKernelGGL(kern, dim3(d.B), dim3(nt), lds, s, d, o, P);
     return FL_OK;
 }
 
@@ -971,9 +1073,10 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
-    const bool csr_lds = obs_pick_csr_lds(d);
-    const size_t lds = obs_lds_bytes(d, csr_lds);
-    return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, s) : obs_launch(k_obs<0, false>, d, o, P, lds, s);
+    P.scr_words = 2 * F_WORDS * 32;
+    bool csr_lds; int nt; size_t lds;
+    if (!obs_pick_config(d, P.scr_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
@@ -984,7 +1087,8 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;
-    const bool csr_lds = obs_pick_csr_lds(d);
-    const size_t lds = obs_lds_bytes(d, csr_lds);
-    return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, s) : obs_launch(k_obs<1, false>, d, o, P, lds, s);
+    P.scr_words = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
+    bool csr_lds; int nt; size_t lds;
+    if (!obs_pick_config(d, P.scr_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
