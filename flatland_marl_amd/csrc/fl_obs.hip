@@ -28,10 +28,15 @@
 #define OBS_ITEMS_LDS_CAP 8192       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
-//   bits 0-1 direction, 2-10 t_hi, 11-19 t_lo, 20-29 agent
+//   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
+//   6-9 interval length - 1, 10 "until the end of the horizon", 11-19 t_lo, 20-29 agent
 #define IT_DIR(it) ((it)&3u)
-#define IT_THI(it) (((it) >> 2) & 511u)
+#define IT_DNEXT(it) (((it) >> 2) & 3u)
+#define IT_DPREV(it) (((it) >> 4) & 3u)
+#define IT_THI(it, tlast) ((((it) >> 10) & 1u) ? (uint32_t)(tlast) : IT_TLO(it) + (((it) >> 6) & 15u))
 #define IT_TLO(it) (((it) >> 11) & 511u)
+#define IT_TOEND(it) (((it) >> 10) & 1u)
+#define IT_SORTKEY(it) (IT_TOEND(it) ? 0u : IT_TLO(it) + 1u)
 #define IT_AGENT(it) ((int)((it) >> 20))
 
 // ---------------------------------------------------------------------------------------------- context
@@ -57,6 +62,7 @@ struct ObsCtx {
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // HBM env base [Umax][HW][4]
     const uint2 *seg;             // HBM env base [HW * 4] static branch-walk table
+    long long *dbg;               // diagnostic builds
 };
 
 __device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
@@ -118,6 +124,7 @@ struct WalkDyn {
     int other_agent, pot_conflict, other_target;  // tot_dist of the first hit, INT_MAX = none
     int same_dir, opp_dir, malfunctioning, ready;
     double min_speed;
+    int dbg_items;
 };
 
 // advance k cells along a chain of single-transition cells (no features)
@@ -137,6 +144,7 @@ __device__ void walk_cells(const ObsCtx &X, int handle, int cell, uint32_t d, in
     o.other_agent = o.pot_conflict = o.other_target = 0x7fffffff;
     o.same_dir = o.opp_dir = o.malfunctioning = o.ready = 0;
     o.min_speed = 1.0;
+    o.dbg_items = 0;
     const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
     const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
     for (int v = 0; v < count; v++) {
@@ -160,52 +168,59 @@ __device__ void walk_cells(const ObsCtx &X, int handle, int cell, uint32_t d, in
                 }
             }
         }
+#ifdef FL_DBG_NOCONF
+        if (false) {
+#else
         if (X.Tn > 0 && o.pot_conflict == 0x7fffffff && tot < X.Tn) {  // treeobs.cpp:378-465 / observations.py:329-367
+#endif
             const int pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
             if (pt < X.Tn) {
                 const int key = key_of(X, cell);
                 const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
                 if (hi > lo) {
+                    o.dbg_items += hi - lo;
+                    const uint32_t tlast = (uint32_t)(X.Tn - 1);
                     const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
-                    // one pass: is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted
-                    // there (self included) satisfy the conflict condition
+                    // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
+                    // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
+                    // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
                     bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
-                    for (int e0 = lo; e0 < hi; e0 += 4) {
-                        uint32_t itv[4];  // four independent loads in flight
-#pragma unroll
-                        for (int q = 0; q < 4; q++) itv[q] = X.csr_items[min(e0 + q, hi - 1)];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (e0 + q >= hi) break;
-                            const uint32_t it = itv[q];
-                            const uint32_t tl = IT_TLO(it), th = IT_THI(it);
-                            if (th < t1 || tl > t2) continue;  // not predicted here anywhere near this time
-                            const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
-                            const int a = IT_AGENT(it);
-                            const uint32_t cd = IT_DIR(it);
-                            const bool oth = a != handle;
-                            const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
-                            other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
-                            cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                    auto test_item = [&](uint32_t it) {
+                        const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
+                        if (th < t1 || tl > t2) return;
+                        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+                        const int a = IT_AGENT(it);
+                        // direction the conflict test uses: upstream takes the one at the matching time step
+                        // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
+                        // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is
+                        // not on this waypoint at t0
+                        uint32_t cd = IT_DIR(it);
+                        if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
+                        const bool oth = a != handle;
+                        const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
+                        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
+                        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                    };
+                    int e = lo;
+                    for (; e < hi; e++) {  // until-the-end items
+                        const uint32_t it = X.csr_items[e];
+                        if (!IT_TOEND(it)) break;
+                        test_item(it);
+                    }
+                    if (e < hi) {
+                        const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
+                        int l = e, h = hi;  // first item with t_lo >= tmin
+                        while (l < h) {
+                            const int mid = (l + h) >> 1;
+                            if (IT_TLO(X.csr_items[mid]) < tmin) l = mid + 1; else h = mid;
+                        }
+                        for (; l < hi; l++) {
+                            const uint32_t it = X.csr_items[l];
+                            if (IT_TLO(it) > t2) break;
+                            test_item(it);
                         }
                     }
-                    bool hit = false;
-                    if (other0) hit = cond0;
-                    else if (other1 | other2) {
-                        const uint32_t sel = other1 ? t1 : t2;
-                        if (!CUTILS) hit = other1 ? cond1 : cond2;
-                        else {
-                            // cutils indexes predicted_dir with predicted_time in the pre/post branches
-                            // (treeobs.cpp:429-433, 449-453): look the direction at t0 up in the agent's path
-                            for (int e = lo; e < hi; e++) {
-                                const uint32_t it = X.csr_items[e];
-                                if (!(IT_TLO(it) <= sel && sel <= IT_THI(it))) continue;
-                                const int a = IT_AGENT(it);
-                                const uint32_t cd = X.path[(size_t)a * X.pcap + waypoint_at<true>(X, a, pt)] & 3u;
-                                if ((d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE) hit = true;
-                            }
-                        }
-                    }
+                    const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
                     if (hit) o.pot_conflict = tot;
                 }
             }
@@ -235,8 +250,11 @@ __device__ __forceinline__ void team_sync() {
 // partial result into the node's accumulators with LDS atomics (min / sum / max are associative).
 template <bool CUTILS, int TEAM, int CAP>
 __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool have, int tl, int n_nodes, int *scr) {
-    volatile int *vs = scr;
+    const int *vs = scr;  // plain LDS reads; team_sync() orders them against the other lanes' writes
     unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
+#ifdef FL_OBS_TIMING
+    const long long dbg_t0 = (long long)wall_clock64();
+#endif
     // accumulators + inclusive prefix of the visit counts
     int run_base = 0;
     for (int k0 = 0; k0 < CAP; k0 += TEAM) {
@@ -256,10 +274,14 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
         run_base = __shfl(incl, TEAM - 1, TEAM);
     }
     team_sync();
+#ifdef FL_OBS_TIMING
+    const long long dbg_t1 = (long long)wall_clock64();
+#endif
     const int total = have ? run_base : 0;
     const int q = (total + TEAM - 1) / TEAM;
     int pos = tl * q;
     const int end = min(pos + q, total);
+    int dbg_items = 0, dbg_skip = 0;
     if (pos < end) {
         // first node whose inclusive prefix exceeds pos
         int lo = 0, hi = n_nodes - 1;
@@ -279,6 +301,7 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
             skip_cells(X, cell, dd, k);
             WalkDyn w;
             walk_cells<CUTILS>(X, handle, cell, dd, vs[F_TOT * CAP + node] + k, cnt, w);
+            dbg_items += w.dbg_items; dbg_skip += k;
             if (w.other_agent != 0x7fffffff) atomicMin(&scr[F_OA * CAP + node], w.other_agent);
             if (w.pot_conflict != 0x7fffffff) atomicMin(&scr[F_PC * CAP + node], w.pot_conflict);
             if (w.other_target != 0x7fffffff) atomicMin(&scr[F_OT * CAP + node], w.other_target);
@@ -291,13 +314,21 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
             do { node++; } while (pos < end && node < n_nodes && (vs[F_VIS * CAP + node] == 0 || vs[F_START * CAP + node] < 0));
         }
     }
+#ifdef FL_OBS_TIMING
+    if (X.dbg) {
+        const long long dbg_t2 = (long long)wall_clock64();
+        // slowest lane of the env: slice-loop ticks << 40 | items scanned << 20 | (cells walked + skipped)
+        atomicMax((unsigned long long *)&X.dbg[6], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)dbg_items << 20) | (unsigned long long)(dbg_skip + (end > tl * q ? end - tl * q : 0)));
+        atomicMax((unsigned long long *)&X.dbg[7], (unsigned long long)total);
+    }
+#endif
     team_sync();
 }
 
 // the 12 features of node k from its descriptor and accumulators (treeobs.cpp:546-573 / observations.py:433-461)
 template <int CAP>
 __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int *scr, int k, double *f) {
-    volatile const int *vs = scr;
+    const int *vs = scr;
     const unsigned long long *ms = reinterpret_cast<const unsigned long long *>(scr + F_MS * CAP);
     const int tot_end = vs[F_TOT * CAP + k] + vs[F_VIS * CAP + k] - 1;
     const uint32_t flags = (uint32_t)vs[F_FLAGS * CAP + k];
@@ -316,7 +347,7 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
     f[5] = (flags & ND_TERMINAL) ? INFINITY : (double)tot_end;
     f[6] = dist_min;
     f[7] = vs[F_SAME * CAP + k]; f[8] = vs[F_OPP * CAP + k]; f[9] = vs[F_MALF * CAP + k];
-    f[10] = __longlong_as_double((long long)((volatile const unsigned long long *)ms)[k]);
+    f[10] = __longlong_as_double((long long)ms[k]);
     f[11] = vs[F_READY * CAP + k];
 }
 
@@ -466,7 +497,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         team_sync();
         team_pass_b<false, TEAM, CAP>(X, ia, have, tl, have ? NN : 1, scr);
         if (have) {  // rows
-            volatile int *vs = scr;
+            const int *vs = scr;
             for (int idx = 1 + tl; idx < NN; idx += TEAM) {
                 double *row = out + (size_t)idx * 12;
                 if (vs[F_START * CAP + idx] < 0) {
@@ -581,6 +612,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     X.A = A; X.H = H; X.W = W; X.HW = HW;
     X.keycell = keycell; X.cellw = cellw; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
     X.seg = d.seg + (size_t)b * HW * 4;
+    X.dbg = P.dbg ? P.dbg + (size_t)b * 8 : nullptr;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_lp = a_lp; X.a_tslot = a_tslot; X.a_target = a_target;
     X.pcap = S.pred_cap;
@@ -847,17 +879,37 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             for (int k = lane; k <= lp; k += 64) {
                 const uint32_t w = path[k];
+                const uint32_t dnext = k < lp ? (path[k + 1] & 3u) : (w & 3u), dprev = k > 0 ? (path[k - 1] & 3u) : (w & 3u);
                 // closed time interval during which the agent is predicted on waypoint k
-                int tlo, thi;
+                int tlo, span;
                 if (CUTILS) {  // w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp) afterwards
                     tlo = k == 0 ? 0 : (k - 1) * tpc + 1;
-                    thi = k == lp ? tlast : (k == 0 ? 0 : k * tpc);
+                    span = k == 0 ? 1 : tpc;
                 } else {       // w(t) = min(t / tpc, lp)
                     tlo = k * tpc;
-                    thi = k == lp ? tlast : (k + 1) * tpc - 1;
+                    span = tpc;
                 }
+                const bool to_end = k == lp || tlo + span - 1 >= tlast;
                 const int slot = atomicAdd(&csr[key_of(X, (int)(w >> 2))], 1);
-                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)min(thi, tlast) << 2) | (w & 3u);
+                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                                  ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+            }
+        }
+        __syncthreads();
+        // sort every key's list (until-the-end items first, then by t_lo): lists are short, one lane per key
+        for (int k = tid; k < K; k += nt) {
+            const int hi = csr[k], lo = k > 0 ? csr[k - 1] : 0;
+            for (int x = lo + 1; x < hi; x++) {
+                const uint32_t it = csr_items[x];
+                const uint32_t sk = IT_SORTKEY(it);
+                int y = x - 1;
+                while (y >= lo) {
+                    const uint32_t prev = csr_items[y];
+                    if (IT_SORTKEY(prev) <= sk) break;
+                    csr_items[y + 1] = prev;
+                    y--;
+                }
+                csr_items[y + 1] = it;
             }
         }
         __syncthreads();
@@ -908,8 +960,10 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
                 if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
             }
-            int n_cur = 3, node_base = 1;
+            int n_cur = 3, node_base = 1, levels = 0;
+            if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
             while (true) {  // pass A
+                levels++;
                 const bool active = have && node_base < N && n_cur > 0;
                 if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
                 const int m = active ? min(n_cur, N - node_base) : 0;
@@ -928,10 +982,13 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                         scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
                     }
                     scr[F_PAR * CAP + idx_node] = c_parent;
-                    scr[F_HGT * CAP + idx_node] = c_act;  // parked here until the adjacency row is written
                 }
                 const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
                 const int n_next = 3 * __popc(exp_mask);
+                if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
+                    const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
+                    scr[F_HGT * CAP + idx_node] = (fc << 2) | (c_act + 1);
+                }
                 // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
                 const int src_rank = gl / 3, which = gl - 3 * src_rank;
                 const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
@@ -950,19 +1007,13 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 }
             }
             team_sync();
-#ifdef FL_OBS_TIMING
-            if (have && gl == 0) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 6], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
-#endif
             team_pass_b<true, 32, CAP>(X, ia, have, gl, have ? node_base : 1, scr);
-#ifdef FL_OBS_TIMING
-            if (have) atomicMax((unsigned long long *)&P.dbg[(size_t)b * 8 + 7], (unsigned long long)((long long)wall_clock64() - P.dbg[(size_t)b * 8 + 4]));
-#endif
             if (have) {  // rows: lane gl writes node gl + 1
-                volatile int *vs = scr;
+                const int *vs = scr;
                 for (int idx = gl + 1; idx < N; idx += 32) {
                     int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
                     if (idx < node_base) {
-                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = vs[F_HGT * CAP + idx];
+                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = (vs[F_HGT * CAP + idx] & 3) - 1;
                         if (vs[F_START * CAP + idx] < 0) {
                             const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
                             scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
@@ -979,25 +1030,30 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                     }
                 }
             }
-            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves; parents precede their
-            // children in BFS numbering, so one reverse sweep settles it
-            team_sync();
-            scr[F_HGT * CAP + gl] = 0;
-            team_sync();
-            if (have && gl == 0) {
-                volatile int *vp = scr + F_PAR * CAP, *vh = scr + F_HGT * CAP;
-                for (int k = N - 1; k >= 1; k--) {
-                    const int p = vp[k];
-                    if (p >= 0) { const int hk = vh[k] + 1; if (vh[p] < hk) vh[p] = hk; }
+            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
+            // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
+            {
+                const int packed = gl < node_base ? scr[F_HGT * CAP + gl] : 0;
+                const int fc = packed >> 2;          // 0 = no children pushed
+                const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
+                const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
+                const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
+                int h = 0;
+                for (int it = 0; it < max_levels; it++) {
+                    const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
+                    int hn = 0;
+                    if (nchild > 0) hn = h0 + 1;
+                    if (nchild > 1) hn = max(hn, h1 + 1);
+                    if (nchild > 2) hn = max(hn, h2 + 1);
+                    h = hn;
                 }
-            }
-            team_sync();
-            if (have) {
-                int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-                volatile int *vp = scr + F_PAR * CAP, *vh = scr + F_HGT * CAP;
-                for (int k = gl; k < N; k += 32) {
-                    NO[k] = k < node_base ? vh[k] : -2;
-                    if (k >= 1) { const int p = vp[k]; EO[k - 1] = p < 0 ? -2 : vh[p]; }
+                const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
+                if (have) {
+                    int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
+                    if (gl < N) {
+                        NO[gl] = gl < node_base ? h : -2;
+                        if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
+                    }
                 }
             }
             team_sync();
