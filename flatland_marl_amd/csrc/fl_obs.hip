@@ -124,7 +124,6 @@ struct WalkDyn {
     int other_agent, pot_conflict, other_target;  // tot_dist of the first hit, INT_MAX = none
     int same_dir, opp_dir, malfunctioning, ready;
     double min_speed;
-    int dbg_items;
 };
 
 // advance k cells along a chain of single-transition cells (no features)
@@ -135,104 +134,84 @@ __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t 
     }
 }
 
-// feature block of `count` consecutive cells of a branch walk starting at (cell, d) with tot_dist `tot`
-// (treeobs.cpp:322-465 / observations.py:296-371)
+// feature block of ONE visited cell of a branch walk (treeobs.cpp:322-465 / observations.py:296-371): cell, walking
+// direction d, tot_dist tot; accumulates into o
 template <bool CUTILS>
-__device__ void walk_cells(const ObsCtx &X, int handle, int cell, uint32_t d, int tot, int count, WalkDyn &o) {
-    const int W = X.W;
-    const int target = X.a_target[handle];
-    o.other_agent = o.pot_conflict = o.other_target = 0x7fffffff;
-    o.same_dir = o.opp_dir = o.malfunctioning = o.ready = 0;
-    o.min_speed = 1.0;
-    o.dbg_items = 0;
-    const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
-    const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
-    for (int v = 0; v < count; v++) {
-        const uint32_t cw = X.cellw[cell];
-        const uint32_t bits = nibble(cw & 0xFFFFu, d);
-        const uint32_t sl = cw >> 16;
-        if (sl != 0xFFFFu) {  // treeobs.cpp:322-357
-            const int ag = X.slot_agent[sl];
-            if (ag >= 0) {
-                if (tot < o.other_agent) o.other_agent = tot;
-                const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
-                if (mf > o.malfunctioning) o.malfunctioning = mf;
-                const int rd = X.slot_ready[sl];
-                if (rd > 0) o.ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
-                if (X.a_dir[ag] == d) {
-                    o.same_dir += 1;
-                    const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
-                    if (sp < o.min_speed) o.min_speed = sp;
-                } else {
-                    o.opp_dir += 1;
-                }
+__device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int target, float tpc_f, double tpc_d, int cell,
+                                          uint32_t d, uint32_t cw, int tot, WalkDyn &o) {
+    const uint32_t bits = nibble(cw & 0xFFFFu, d);
+    const uint32_t sl = cw >> 16;
+    if (sl != 0xFFFFu) {  // treeobs.cpp:322-357
+        const int ag = X.slot_agent[sl];
+        if (ag >= 0) {
+            if (tot < o.other_agent) o.other_agent = tot;
+            const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
+            if (mf > o.malfunctioning) o.malfunctioning = mf;
+            const int rd = X.slot_ready[sl];
+            if (rd > 0) o.ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
+            if (X.a_dir[ag] == d) {
+                o.same_dir += 1;
+                const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
+                if (sp < o.min_speed) o.min_speed = sp;
+            } else {
+                o.opp_dir += 1;
             }
-        }
-#ifdef FL_DBG_NOCONF
-        if (false) {
-#else
-        if (X.Tn > 0 && o.pot_conflict == 0x7fffffff && tot < X.Tn) {  // treeobs.cpp:378-465 / observations.py:329-367
-#endif
-            const int pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
-            if (pt < X.Tn) {
-                const int key = key_of(X, cell);
-                const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
-                if (hi > lo) {
-                    o.dbg_items += hi - lo;
-                    const uint32_t tlast = (uint32_t)(X.Tn - 1);
-                    const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
-                    // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
-                    // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
-                    // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
-                    bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
-                    auto test_item = [&](uint32_t it) {
-                        const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
-                        if (th < t1 || tl > t2) return;
-                        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
-                        const int a = IT_AGENT(it);
-                        // direction the conflict test uses: upstream takes the one at the matching time step
-                        // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
-                        // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is
-                        // not on this waypoint at t0
-                        uint32_t cd = IT_DIR(it);
-                        if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
-                        const bool oth = a != handle;
-                        const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
-                        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
-                        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
-                    };
-                    int e = lo;
-                    for (; e < hi; e++) {  // until-the-end items
-                        const uint32_t it = X.csr_items[e];
-                        if (!IT_TOEND(it)) break;
-                        test_item(it);
-                    }
-                    if (e < hi) {
-                        const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
-                        int l = e, h = hi;  // first item with t_lo >= tmin
-                        while (l < h) {
-                            const int mid = (l + h) >> 1;
-                            if (IT_TLO(X.csr_items[mid]) < tmin) l = mid + 1; else h = mid;
-                        }
-                        for (; l < hi; l++) {
-                            const uint32_t it = X.csr_items[l];
-                            if (IT_TLO(it) > t2) break;
-                            test_item(it);
-                        }
-                    }
-                    const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
-                    if (hit) o.pot_conflict = tot;
-                }
-            }
-        }
-        if (!CUTILS && o.other_target == 0x7fffffff && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target)
-            o.other_target = tot;  // cutils never fills the map (treeobs.cpp:72)
-        if (v + 1 < count) {  // keep walking along the only transition
-            d = first_dir(bits);
-            cell = step_cell(cell, d, W);
-            tot += 1;
         }
     }
+    if (X.Tn > 0 && o.pot_conflict == 0x7fffffff && tot < X.Tn) {  // treeobs.cpp:378-465 / observations.py:329-367
+        const int pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
+        if (pt < X.Tn) {
+            const int key = key_of(X, cell);
+            const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+            if (hi > lo) {
+                const uint32_t tlast = (uint32_t)(X.Tn - 1);
+                const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
+                // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
+                // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
+                // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
+                bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
+                auto test_item = [&](uint32_t it) {
+                    const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
+                    if (th < t1 || tl > t2) return;
+                    const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+                    const int a = IT_AGENT(it);
+                    // direction the conflict test uses: upstream takes the one at the matching time step
+                    // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
+                    // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is not on
+                    // this waypoint at t0
+                    uint32_t cd = IT_DIR(it);
+                    if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
+                    const bool oth = a != handle;
+                    const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
+                    other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
+                    cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+                };
+                int e = lo;
+                for (; e < hi; e++) {  // until-the-end items
+                    const uint32_t it = X.csr_items[e];
+                    if (!IT_TOEND(it)) break;
+                    test_item(it);
+                }
+                if (e < hi) {
+                    const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
+                    int l = e, h = hi;  // first item with t_lo >= tmin
+                    while (l < h) {
+                        const int mid = (l + h) >> 1;
+                        if (IT_TLO(X.csr_items[mid]) < tmin) l = mid + 1; else h = mid;
+                    }
+                    for (; l < hi; l++) {
+                        const uint32_t it = X.csr_items[l];
+                        if (IT_TLO(it) > t2) break;
+                        test_item(it);
+                    }
+                }
+                const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
+                if (hit) o.pot_conflict = tot;
+            }
+        }
+    }
+    if (!CUTILS && o.other_target == 0x7fffffff && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target)
+        o.other_target = tot;  // cutils never fills the map (treeobs.cpp:72)
 }
 
 // per-team node table in LDS: CAP entries per field
@@ -290,18 +269,27 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
             if (vs[F_INCL * CAP + mid] > pos) hi = mid; else lo = mid + 1;
         }
         int node = lo;
-        while (pos < end) {
-            const int nvis = vs[F_VIS * CAP + node];
-            const int incl = vs[F_INCL * CAP + node];
+        const int target = X.a_target[handle];
+        const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
+        const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
+        // state of the piece being walked
+        int left, cell, tot;
+        uint32_t dd;
+        {
+            const int nvis = vs[F_VIS * CAP + node], incl = vs[F_INCL * CAP + node];
             const int k = pos - (incl - nvis);  // offset inside the node's walk
-            const int cnt = min(nvis - k, end - pos);
             const int st = vs[F_START * CAP + node];
-            int cell = st >> 2;
-            uint32_t dd = st & 3;
+            cell = st >> 2; dd = st & 3;
             skip_cells(X, cell, dd, k);
-            WalkDyn w;
-            walk_cells<CUTILS>(X, handle, cell, dd, vs[F_TOT * CAP + node] + k, cnt, w);
-            dbg_items += w.dbg_items; dbg_skip += k;
+            dbg_skip = k;
+            tot = vs[F_TOT * CAP + node] + k;
+            left = nvis - k;
+        }
+        WalkDyn w;
+        w.other_agent = w.pot_conflict = w.other_target = 0x7fffffff;
+        w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
+        w.min_speed = 1.0;
+        auto flush = [&]() {
             if (w.other_agent != 0x7fffffff) atomicMin(&scr[F_OA * CAP + node], w.other_agent);
             if (w.pot_conflict != 0x7fffffff) atomicMin(&scr[F_PC * CAP + node], w.pot_conflict);
             if (w.other_target != 0x7fffffff) atomicMin(&scr[F_OT * CAP + node], w.other_target);
@@ -310,9 +298,30 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
             if (w.malfunctioning) atomicMax(&scr[F_MALF * CAP + node], w.malfunctioning);
             if (w.ready) atomicAdd(&scr[F_READY * CAP + node], w.ready);
             if (w.min_speed < 1.0) atomicMin(&ms[node], (unsigned long long)__double_as_longlong(w.min_speed));
-            pos += cnt;
-            do { node++; } while (pos < end && node < n_nodes && (vs[F_VIS * CAP + node] == 0 || vs[F_START * CAP + node] < 0));
+        };
+        // ONE loop over the lane's cells (lanes of a wave run it in lock step); a node boundary is a rare side branch
+        for (; pos < end; pos++) {
+            if (left == 0) {
+                flush();
+                w.other_agent = w.pot_conflict = w.other_target = 0x7fffffff;
+                w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
+                w.min_speed = 1.0;
+                do { node++; } while (vs[F_VIS * CAP + node] == 0 || vs[F_START * CAP + node] < 0);
+                const int st = vs[F_START * CAP + node];
+                cell = st >> 2; dd = st & 3;
+                tot = vs[F_TOT * CAP + node];
+                left = vs[F_VIS * CAP + node];
+            }
+            const uint32_t cw = X.cellw[cell];
+            walk_cell<CUTILS>(X, handle, target, tpc_f, tpc_d, cell, dd, cw, tot, w);
+            left--;
+            if (left > 0) {  // keep walking along the only transition
+                dd = first_dir(nibble(cw & 0xFFFFu, dd));
+                cell = step_cell(cell, dd, X.W);
+                tot += 1;
+            }
         }
+        flush();
     }
 #ifdef FL_OBS_TIMING
     if (X.dbg) {
