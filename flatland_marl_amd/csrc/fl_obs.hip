@@ -25,7 +25,7 @@
 #define OBS_WAVES (OBS_NT / 64)
 #define OBS_GROUPS (OBS_WAVES * 2)   // cutils trees: two agents per wavefront, 32 lanes each (max_nodes <= 33)
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
-#define OBS_ITEMS_LDS_CAP 8192       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
+#define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
+    uint32_t *stage_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
@@ -880,7 +881,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
         }
         __syncthreads();
-        if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; }
+        uint32_t *stage_items = S.cell_stage + (size_t)b * A * S.pred_cap;
+        if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; stage_items = stage_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
         for (int i = wave; i < A; i += (nt >> 6)) {
@@ -900,25 +902,35 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 }
                 const bool to_end = k == lp || tlo + span - 1 >= tlast;
                 const int slot = atomicAdd(&csr[key_of(X, (int)(w >> 2))], 1);
-                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                stage_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                   ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
             }
         }
         __syncthreads();
-        // sort every key's list (until-the-end items first, then by t_lo): lists are short, one lane per key
-        for (int k = tid; k < K; k += nt) {
-            const int hi = csr[k], lo = k > 0 ? csr[k - 1] : 0;
-            for (int x = lo + 1; x < hi; x++) {
-                const uint32_t it = csr_items[x];
-                const uint32_t sk = IT_SORTKEY(it);
-                int y = x - 1;
-                while (y >= lo) {
-                    const uint32_t prev = csr_items[y];
-                    if (IT_SORTKEY(prev) <= sk) break;
-                    csr_items[y + 1] = prev;
-                    y--;
+        // sort every key's list (until-the-end items first, then by t_lo, ties by staging position): every item -- one
+        // lane each, all in parallel -- finds its rank inside its key's staged list and moves to its final place
+        for (int i = wave; i < A; i += (nt >> 6)) {
+            const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const int lp = a_lp[i];
+            for (int k = lane; k <= lp; k += 64) {
+                const int key = key_of(X, (int)(path[k] >> 2));
+                const int hi = csr[key], lo = key > 0 ? csr[key - 1] : 0;
+                // my staged item is the one of agent i whose waypoint is k: (agent, t_lo) is unique inside a list
+                const uint32_t my_tlo = CUTILS ? (k == 0 ? 0u : (uint32_t)((k - 1) * a_tpc[i] + 1)) : (uint32_t)(k * a_tpc[i]);
+                uint32_t mine = 0, my_sk = 0;
+                for (int y = lo; y < hi; y++) {
+                    const uint32_t it = stage_items[y];
+                    if (IT_AGENT(it) == i && IT_TLO(it) == my_tlo) { mine = it; my_sk = IT_SORTKEY(it); break; }
                 }
-                csr_items[y + 1] = it;
+                int rank = 0;
+                bool seen = false;
+                for (int y = lo; y < hi; y++) {
+                    const uint32_t it = stage_items[y];
+                    const uint32_t sy = IT_SORTKEY(it);
+                    if (it == mine) { seen = true; continue; }
+                    rank += (sy < my_sk) || (sy == my_sk && !seen);
+                }
+                csr_items[lo + rank] = mine;
             }
         }
         __syncthreads();
@@ -1085,6 +1097,8 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.path = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
+    if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
+    o.cell_stage = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 8 * 8) != hipSuccess) return FL_ERR_HIP;
@@ -1105,7 +1119,7 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words)
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
            al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
-           al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
+           2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
