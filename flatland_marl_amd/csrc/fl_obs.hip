@@ -58,7 +58,8 @@ struct ObsCtx {
     const uint32_t *path;         // HBM [A][pcap] cell << 2 | dir
     int pcap;
     const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
-    const uint32_t *csr_items;    // IT_* packed items; LDS or HBM
+    const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
+    const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // HBM env base [Umax][HW][4]
     const uint2 *seg;             // HBM env base [HW * 4] static branch-walk table
@@ -136,7 +137,7 @@ __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t 
 
 // feature block of ONE visited cell of a branch walk (treeobs.cpp:322-465 / observations.py:296-371): cell, walking
 // direction d, tot_dist tot; accumulates into o
-template <bool CUTILS>
+template <bool CUTILS, bool ITL>
 __device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int target, float tpc_f, double tpc_d, int cell,
                                           uint32_t d, uint32_t cw, int tot, WalkDyn &o) {
     const uint32_t bits = nibble(cw & 0xFFFFu, d);
@@ -188,7 +189,7 @@ __device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int targe
                 };
                 int e = lo;
                 for (; e < hi; e++) {  // until-the-end items
-                    const uint32_t it = X.csr_items[e];
+                    const uint32_t it = (ITL ? X.items_lds : X.items_glb)[e];
                     if (!IT_TOEND(it)) break;
                     test_item(it);
                 }
@@ -197,10 +198,10 @@ __device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int targe
                     int l = e, h = hi;  // first item with t_lo >= tmin
                     while (l < h) {
                         const int mid = (l + h) >> 1;
-                        if (IT_TLO(X.csr_items[mid]) < tmin) l = mid + 1; else h = mid;
+                        if (IT_TLO((ITL ? X.items_lds : X.items_glb)[mid]) < tmin) l = mid + 1; else h = mid;
                     }
                     for (; l < hi; l++) {
-                        const uint32_t it = X.csr_items[l];
+                        const uint32_t it = (ITL ? X.items_lds : X.items_glb)[l];
                         if (IT_TLO(it) > t2) break;
                         test_item(it);
                     }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void team_sync() {
 // Pass B of a tree: the visited cells of ALL nodes (node k has n_vis[k] of them) are split evenly over the TEAM lanes;
 // every lane walks its slice (a cheap skip to the slice start, then the feature block per cell) and merges its
 // partial result into the node's accumulators with LDS atomics (min / sum / max are associative).
-template <bool CUTILS, int TEAM, int CAP>
+template <bool CUTILS, int TEAM, int CAP, bool ITL>
 __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool have, int tl, int n_nodes, int *scr) {
     const int *vs = scr;  // plain LDS reads; team_sync() orders them against the other lanes' writes
     unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
@@ -313,7 +314,7 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
                 left = vs[F_VIS * CAP + node];
             }
             const uint32_t cw = X.cellw[cell];
-            walk_cell<CUTILS>(X, handle, target, tpc_f, tpc_d, cell, dd, cw, tot, w);
+            walk_cell<CUTILS, ITL>(X, handle, target, tpc_f, tpc_d, cell, dd, cw, tot, w);
             left--;
             if (left > 0) {  // keep walking along the only transition
                 dd = first_dir(nibble(cw & 0xFFFFu, dd));
@@ -433,7 +434,7 @@ struct ObsArgs {
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
 // (TEAM = 32: two agents per wavefront, depth <= 2; TEAM = 64: depth 3).  Level L of pass A is handled by 4^L lanes;
 // every row that is not a real node is -inf.
-template <int TEAM, int CAP>
+template <int TEAM, int CAP, bool ITL>
 __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                               int nwaves, int *wave_scr_base, const uint32_t *cellw, const int *a_vpos,
                                               const uint8_t *a_dir, const uint16_t *a_malf, const double *a_speed,
@@ -504,7 +505,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             }
         }
         team_sync();
-        team_pass_b<false, TEAM, CAP>(X, ia, have, tl, have ? NN : 1, scr);
+        team_pass_b<false, TEAM, CAP, ITL>(X, ia, have, tl, have ? NN : 1, scr);
         if (have) {  // rows
             const int *vs = scr;
             for (int idx = 1 + tl; idx < NN; idx += TEAM) {
@@ -519,6 +520,153 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             }
         }
         team_sync();
+    }
+}
+
+// flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
+template <bool ITL>
+__device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
+                                             int nwaves, int *wave_scr, const uint32_t *cellw, const int *a_vpos,
+                                             const int *a_pos, const uint8_t *a_dir, const uint8_t *a_state,
+                                             const double *a_speed, const int *a_tslot, float max_dist) {
+    const int A = X.A, W = X.W, HW = X.HW;
+    {
+        // two agents per wavefront, a team of 32 lanes each
+        constexpr int CAP = 32;
+        const int grp = lane >> 5, gl = lane & 31;
+        const int N = P.max_nodes;
+        int *scr = wave_scr + wave * P.scr_words + grp * (F_WORDS * CAP);
+        for (int base = 0; base < A; base += nwaves * 2) {
+            const int i = base + wave * 2 + grp;
+            const bool have = i < A;
+            const int ia = have ? i : 0;
+            const int g = b * A + ia;
+            const int vpos = a_vpos[ia];
+            const uint32_t dir = a_dir[ia];
+            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+            uint32_t orientation = dir;
+            if (__popc(rbits) == 1) orientation = first_dir(rbits);
+            float *F = P.forest + (size_t)g * N * 12;
+            int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
+            if (have && gl == 0) {  // root (treeobs.cpp:171-186)
+                const uint32_t state = a_state[i];
+                double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                uint16_t dv = FL_INF16;
+                if (state == ST_DONE) dv = 0;
+                else dv = X.dm[((size_t)a_tslot[i] * HW + (is_off_map(state) ? d.init_pos[g] : a_pos[i])) * 4 +
+                               (is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
+                root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
+                root[9] = (double)((d.malf[g] >> 16) != 0);
+                root[10] = (double)(float)a_speed[i];
+                scale_and_store(root, max_dist, A, F);
+            }
+            scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
+            scr[F_PAR * CAP + gl] = -2;
+            // level 1: three cells from the root (treeobs.cpp:205-222)
+            int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
+            if (gl < 3) {
+                c_act = gl - 1;
+                const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
+                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
+            }
+            int n_cur = 3, node_base = 1, levels = 0;
+            if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
+            while (true) {  // pass A
+                levels++;
+                const bool active = have && node_base < N && n_cur > 0;
+                if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
+                const int m = active ? min(n_cur, N - node_base) : 0;
+                const bool mine = gl < m;
+                const int idx_node = node_base + gl;
+                int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
+                bool explored = false;
+                if (mine) {
+                    if (c_state >= 0) {
+                        const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                        explored = true;
+                        ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
+                        ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
+                        scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
+                        scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
+                        scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
+                    }
+                    scr[F_PAR * CAP + idx_node] = c_parent;
+                }
+                const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
+                const int n_next = 3 * __popc(exp_mask);
+                if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
+                    const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
+                    scr[F_HGT * CAP + idx_node] = (fc << 2) | (c_act + 1);
+                }
+                // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
+                const int src_rank = gl / 3, which = gl - 3 * src_rank;
+                const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
+                const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
+                const int s_tot = __shfl(ch_tot, src, 32);
+                if (active) {
+                    const int parent_base = node_base;
+                    node_base += m;
+                    n_cur = n_next;
+                    if (gl < n_next) {
+                        c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
+                        c_parent = parent_base + src;
+                        c_tot = s_tot;
+                        c_act = which - 1;
+                    }
+                }
+            }
+            team_sync();
+            team_pass_b<true, 32, CAP, ITL>(X, ia, have, gl, have ? node_base : 1, scr);
+            if (have) {  // rows: lane gl writes node gl + 1
+                const int *vs = scr;
+                for (int idx = gl + 1; idx < N; idx += 32) {
+                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+                    if (idx < node_base) {
+                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = (vs[F_HGT * CAP + idx] & 3) - 1;
+                        if (vs[F_START * CAP + idx] < 0) {
+                            const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                            scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                        } else {
+                            double f[12];
+                            node_row<CAP>(X, i, scr, idx, f);
+                            if (vs[F_FLAGS * CAP + idx] & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
+                            scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
+                        }
+                    } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
+                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                        adj[0] = adj[1] = adj[2] = -2;
+                    }
+                }
+            }
+            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
+            // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
+            {
+                const int packed = gl < node_base ? scr[F_HGT * CAP + gl] : 0;
+                const int fc = packed >> 2;          // 0 = no children pushed
+                const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
+                const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
+                const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
+                int h = 0;
+                for (int it = 0; it < max_levels; it++) {
+                    const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
+                    int hn = 0;
+                    if (nchild > 0) hn = h0 + 1;
+                    if (nchild > 1) hn = max(hn, h1 + 1);
+                    if (nchild > 2) hn = max(hn, h2 + 1);
+                    h = hn;
+                }
+                const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
+                if (have) {
+                    int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
+                    if (gl < N) {
+                        NO[gl] = gl < node_base ? h : -2;
+                        if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
+                    }
+                }
+            }
+            team_sync();
+        }
     }
 }
 
@@ -629,7 +777,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     X.path = S.path + (size_t)b * A * S.pred_cap;
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
-    X.csr_end = csr; X.csr_items = csr_items;
+    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
     X.Tn = P.pred_depth >= 0 ? P.pred_depth + 1 : 0;
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
@@ -882,7 +1030,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         }
         __syncthreads();
         uint32_t *stage_items = S.cell_stage + (size_t)b * A * S.pred_cap;
-        if (CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP) { csr_items = items_lds; X.csr_items = items_lds; stage_items = stage_lds; }
+        const bool fit = CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP;
+        if (fit) { csr_items = items_lds; X.items_lds = items_lds; stage_items = stage_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
         for (int i = wave; i < A; i += (nt >> 6)) {
@@ -942,147 +1091,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     // evenly over the lanes of the team (team_pass_b); then one lane per node writes its row.
     const float max_dist = (float)T;
     const int nwaves = nt >> 6;
+    const bool items_in_lds = X.items_lds != nullptr;
     if (CUTILS) {
-        // two agents per wavefront, a team of 32 lanes each
-        constexpr int CAP = 32;
-        const int grp = lane >> 5, gl = lane & 31;
-        const int N = P.max_nodes;
-        int *scr = wave_scr + wave * P.scr_words + grp * (F_WORDS * CAP);
-        for (int base = 0; base < A; base += nwaves * 2) {
-            const int i = base + wave * 2 + grp;
-            const bool have = i < A;
-            const int ia = have ? i : 0;
-            const int g = b * A + ia;
-            const int vpos = a_vpos[ia];
-            const uint32_t dir = a_dir[ia];
-            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
-            uint32_t orientation = dir;
-            if (__popc(rbits) == 1) orientation = first_dir(rbits);
-            float *F = P.forest + (size_t)g * N * 12;
-            int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
-            if (have && gl == 0) {  // root (treeobs.cpp:171-186)
-                const uint32_t state = a_state[i];
-                double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                uint16_t dv = FL_INF16;
-                if (state == ST_DONE) dv = 0;
-                else dv = X.dm[((size_t)a_tslot[i] * HW + (is_off_map(state) ? d.init_pos[g] : a_pos[i])) * 4 +
-                               (is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
-                root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
-                root[9] = (double)((d.malf[g] >> 16) != 0);
-                root[10] = (double)(float)a_speed[i];
-                scale_and_store(root, max_dist, A, F);
-            }
-            scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
-            scr[F_PAR * CAP + gl] = -2;
-            // level 1: three cells from the root (treeobs.cpp:205-222)
-            int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
-            if (gl < 3) {
-                c_act = gl - 1;
-                const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
-                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
-            }
-            int n_cur = 3, node_base = 1, levels = 0;
-            if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
-            while (true) {  // pass A
-                levels++;
-                const bool active = have && node_base < N && n_cur > 0;
-                if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
-                const int m = active ? min(n_cur, N - node_base) : 0;
-                const bool mine = gl < m;
-                const int idx_node = node_base + gl;
-                int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
-                bool explored = false;
-                if (mine) {
-                    if (c_state >= 0) {
-                        const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
-                        explored = true;
-                        ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
-                        ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
-                        scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
-                        scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
-                        scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
-                    }
-                    scr[F_PAR * CAP + idx_node] = c_parent;
-                }
-                const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
-                const int n_next = 3 * __popc(exp_mask);
-                if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
-                    const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
-                    scr[F_HGT * CAP + idx_node] = (fc << 2) | (c_act + 1);
-                }
-                // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
-                const int src_rank = gl / 3, which = gl - 3 * src_rank;
-                const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
-                const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
-                const int s_tot = __shfl(ch_tot, src, 32);
-                if (active) {
-                    const int parent_base = node_base;
-                    node_base += m;
-                    n_cur = n_next;
-                    if (gl < n_next) {
-                        c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
-                        c_parent = parent_base + src;
-                        c_tot = s_tot;
-                        c_act = which - 1;
-                    }
-                }
-            }
-            team_sync();
-            team_pass_b<true, 32, CAP>(X, ia, have, gl, have ? node_base : 1, scr);
-            if (have) {  // rows: lane gl writes node gl + 1
-                const int *vs = scr;
-                for (int idx = gl + 1; idx < N; idx += 32) {
-                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
-                    if (idx < node_base) {
-                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = (vs[F_HGT * CAP + idx] & 3) - 1;
-                        if (vs[F_START * CAP + idx] < 0) {
-                            const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                            scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                        } else {
-                            double f[12];
-                            node_row<CAP>(X, i, scr, idx, f);
-                            if (vs[F_FLAGS * CAP + idx] & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
-                            scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
-                        }
-                    } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
-                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                        adj[0] = adj[1] = adj[2] = -2;
-                    }
-                }
-            }
-            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
-            // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
-            {
-                const int packed = gl < node_base ? scr[F_HGT * CAP + gl] : 0;
-                const int fc = packed >> 2;          // 0 = no children pushed
-                const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
-                const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
-                const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
-                int h = 0;
-                for (int it = 0; it < max_levels; it++) {
-                    const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
-                    int hn = 0;
-                    if (nchild > 0) hn = h0 + 1;
-                    if (nchild > 1) hn = max(hn, h1 + 1);
-                    if (nchild > 2) hn = max(hn, h2 + 1);
-                    h = hn;
-                }
-                const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
-                if (have) {
-                    int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-                    if (gl < N) {
-                        NO[gl] = gl < node_base ? h : -2;
-                        if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
-                    }
-                }
-            }
-            team_sync();
-        }
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
     } else if (P.max_depth <= 2) {
-        tree_upstream<32, 32>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     } else {
-        tree_upstream<64, 88>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     }
     OBS_STAMP(5);
 }
