@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--tree-depth", type=int, default=2)
     ap.add_argument("--tree-pred", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dm-rebuild", action="store_true", help="also rebuild all distance maps every step (BASELINE configs[4])")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +90,8 @@ def main():
         if args.tree_depth > 0:
             env.obs_tree(args.tree_depth, args.tree_pred)
         if ev: ev[3].record()
+        if args.dm_rebuild:
+            env.rebuild_distance_maps()
 
     for _ in range(args.warmup):
         step_all()

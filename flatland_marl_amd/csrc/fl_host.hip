@@ -359,6 +359,15 @@ int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *t
     return FL_OK;
 }
 
+int fl_distance_map_rebuild(fl_batch *h) {
+    NEED_COMMIT(h);
+    fl_launch_distance_maps(h->d, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_segments(h->d, h->stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_positions_map(fl_batch *h, int b, int32_t *out) {
     NEED_COMMIT(h);
     if (b < 0 || b >= h->B || !out) { set_err("fl_positions_map: bad argument"); return FL_ERR_ARG; }

@@ -25,7 +25,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
-           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_positions_map",
+           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -77,6 +77,7 @@ def lib():
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
         L.fl_get_state.argtypes = [vp, vp, vp]
         L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
+        L.fl_distance_map_rebuild.argtypes = [vp]
         L.fl_positions_map.argtypes = [vp, i32, vp]
         L.fl_algorithmic_bytes_per_agent_step.argtypes = [vp, i32, i32]
         L.fl_algorithmic_bytes_per_agent_step.restype = C.c_double
@@ -261,6 +262,10 @@ class BatchedRailEnv:
         dm = np.zeros((n.value, self.H, self.W, 4), dtype=np.uint16)
         _chk(lib().fl_distance_map(self.h, b, C.byref(n), _p(dm), _p(slot)))
         return dm, slot
+
+    def rebuild_distance_maps(self):
+        """DistanceMap.reset() + _compute() for every env, on the GPU (asynchronous on the handle's stream)."""
+        _chk(lib().fl_distance_map_rebuild(self.h))
 
     def positions_map(self, b):
         out = np.zeros((self.H, self.W), dtype=np.int32)

@@ -111,6 +111,9 @@ int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed);
 /* distance map of env b: returns number of unique targets in *n_targets; dm u16[n][H][W][4] (0xFFFF = inf),
  * target_slot int32[A].  dm may be NULL to query n only. */
 int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot);
+/* Rebuild the distance maps (and the static branch-walk tables) of all envs on the GPU from the resident grids:
+ * DistanceMap.reset() + _compute() (distance_map.py:47-79), e.g. inside the step loop at every auto-reset. */
+int fl_distance_map_rebuild(fl_batch *h);
 /* RailEnv.agent_positions (rail_env.py:360-367) of env b: int32[H][W], -1 = free */
 int fl_positions_map(fl_batch *h, int b, int32_t *out);
 /* ALGORITHMIC bytes per agent-step the bench prices the roofline with, for the given obs mix */

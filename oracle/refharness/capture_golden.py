@@ -47,7 +47,10 @@ def csv_row(test_id, level):
     return row
 
 
-def make_env(row, malfunction_interval=None, obs=None):
+def make_env(row, malfunction_interval=None, obs=None, dims=None):
+    if dims is not None:
+        row = dict(row)
+        row["x_dim"], row["y_dim"] = dims
     interval = malfunction_interval or row["malfunction_interval"]
     mp = MalfunctionParameters(malfunction_rate=1 / interval,
                                min_duration=int(row["malfunction_duration_min"]),
@@ -198,10 +201,10 @@ def sp_follow_actions(env, rng, p_stop=0.03):
 
 
 def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=1,
-                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False):
+                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False, dims=None):
     """stream in {"uniform", "sparse", "spfollow", "fwd"}."""
     row = csv_row(test_id, level)
-    env, mp = make_env(row, malfunction_interval)
+    env, mp = make_env(row, malfunction_interval, dims=dims)
     obs0, _ = env.reset()
     A = env.get_num_agents()
     out = static_arrays(env, mp)
@@ -330,6 +333,11 @@ JOBS = {
                                         pytree=[(3, 30)], pytree_every=150),
     "cfg3_spfollow_malf100": lambda: run_episode("cfg3_spfollow_malf100", "Test_4", "Level_0", "spfollow", seed=22,
                                                  malfunction_interval=100, obs_every=32),
+    # a TALL map (width 26 < height 40): the reference's prediction keys col * width + row collide there (tool.h:391-398)
+    "tall_spfollow": lambda: run_episode("cfg0_tall_spfollow", "Test_2", "Level_3", "spfollow", seed=51, obs_every=2,
+                                         dims=(26, 40), pytree=[(2, 30)], pytree_every=40, malfunction_interval=300),
+    "tall_uniform": lambda: run_episode("cfg0_tall_uniform", "Test_2", "Level_4", "uniform", seed=52, obs_every=3,
+                                        dims=(26, 40), max_steps=300),
     # cfg4 = Test_8 (60x60, 80 agents): first 120 steps
     "cfg4_fwd_head": lambda: run_episode("cfg4_fwd_head", "Test_8", "Level_0", "fwd", seed=31, max_steps=120,
                                          obs_every=40),
