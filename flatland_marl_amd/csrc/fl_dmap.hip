@@ -172,6 +172,56 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d) {
     d.seg[(size_t)b * NS + s0] = out;
 }
 
+// ---------------------------------------------------------------------------------------------- next-hop table
+// The shortest-path predictors (predictions.cpp:78-144, rail_env_shortest_paths.py:203-274) descend the distance map
+// greedily: among the valid move actions in the order left, forward, right (a dead end only offers its reverse exit)
+// they take the first one with the smallest distance, if it is finite.  On a BFS map that choice is static per
+// (target, cell, orientation); it is tabulated here, 3 bits per orientation (4 = nothing closer), 12 bits per cell.
+__global__ __launch_bounds__(256) void k_nexthop(FlDev d) {
+    const int HW = d.H * d.W, W = d.W;
+    const long long n = (long long)d.B * d.Umax * HW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int cell = (int)(idx % HW);
+    const int bu = (int)(idx / HW);
+    const int b = bu / d.Umax, u = bu % d.Umax;
+    uint32_t out = 0x924;  // 4 | 4<<3 | 4<<6 | 4<<9
+    const uint32_t g = d.grid[(size_t)b * HW + cell];
+    if (u < d.U[b] && g != 0) {
+        const uint16_t *dm = d.dm + ((size_t)bu * HW) * 4;
+        out = 0;
+        for (uint32_t dd = 0; dd < 4; dd++) {
+            const uint32_t bits = nibble(g, dd);
+            uint32_t best = 4, bestv = FL_INF16;
+            if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
+                const uint32_t ex = (dd + 2u) & 3u;
+                if ((bits >> (3 - ex)) & 1) {
+                    const uint32_t v = dm[(size_t)step_cell(cell, ex, W) * 4 + ex];
+                    if (v != FL_INF16) { best = ex; bestv = v; }
+                }
+            } else {
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t nd = (dd + (uint32_t)(j + 3)) & 3u;
+                    if ((bits >> (3 - nd)) & 1) {
+                        const uint32_t v = dm[(size_t)step_cell(cell, nd, W) * 4 + nd];
+                        if (v != FL_INF16 && v < bestv) { best = nd; bestv = v; }
+                    }
+                }
+            }
+            // strict descent: the hop must be closer than the state itself (always true on a consistent map)
+            const uint32_t here = dm[(size_t)cell * 4 + dd];
+            if (best != 4 && !(bestv < here)) best = 4;
+            out |= best << (3 * dd);
+        }
+    }
+    d.nh[idx] = (uint16_t)out;
+}
+
+void fl_launch_nexthop(const FlDev &d, hipStream_t s) {
+    const long long n = (long long)d.B * d.Umax * d.H * d.W;
+    hipLaunchKernelGGL(k_nexthop, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+}
+
 void fl_launch_segments(const FlDev &d, hipStream_t s) {
     const int NS = d.H * d.W * 4;
     hipLaunchKernelGGL(k_segments, dim3(d.B * ((NS + 255) / 256)), dim3(256), 0, s, d);

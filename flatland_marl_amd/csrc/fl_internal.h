@@ -60,6 +60,7 @@ struct FlDev {
     uint16_t *dm;    // [B][Umax][H*W][4]
     int *ut;         // [B][Umax] unique target cells
     uint2 *seg;      // [B][H*W*4] static branch-walk table per (cell, orientation), see fl_dmap.hip k_segments
+    uint16_t *nh;    // [B][Umax][H*W] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
     uint32_t *spk;
@@ -115,6 +116,7 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 // kernel launchers (defined in the .hip files)
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
 void fl_launch_segments(const FlDev &d, hipStream_t s);
+void fl_launch_nexthop(const FlDev &d, hipStream_t s);
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,

@@ -429,6 +429,7 @@ struct ObsArgs {
     int n_tree_nodes;
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
     int scr_words;   // ints of tree scratch per wavefront
+    int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
 };
 
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
     uint32_t *stage_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
+    uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);  // next-hop tables of the env's targets when they fit
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
@@ -719,6 +721,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
     for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
+    const uint16_t *gnh = d.nh + (size_t)b * d.Umax * HW;
+    const int nh_n = d.U[b] * HW;
+    const bool nh_in_lds = P.nh_lds_words >= nh_n && P.pred_depth >= 0;
+    if (nh_in_lds) for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
+    const uint16_t *nh_env = nh_in_lds ? (const uint16_t *)nh_lds : gnh;
     for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
@@ -925,16 +932,17 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         for (int k = tid; k <= K; k += nt) csr[k] = 0;
         __syncthreads();
         const int pred_depth = P.pred_depth;
-        // one walker per agent, spread over the wavefronts first: walkers that share a wavefront serialise each other's
-        // divergent steps (a lane at a switch makes the whole wave wait for its distance gathers)
-        for (int i = lane * (nt >> 6) + wave; i < A; i += nt) {
+        // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
+        // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
+        // walkers would share four
+        const int nw_walk = max(4, (A + 63) / 64);
+        for (int i = lane * nw_walk + wave; wave < nw_walk && i < A; i += 64 * nw_walk) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
             uint32_t dd = a_dir[i];
             const int target = a_target[i];
-            const size_t dmb = (size_t)a_tslot[i] * HW;
+            const uint16_t *nh_u = nh_env + (size_t)a_tslot[i] * HW;
             int n = 0;
-            bool none = false;
             // last waypoint that can be occupied within the horizon; only those enter the per-key index
             const int tpc = a_tpc[i];
             const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
@@ -942,49 +950,19 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 atomicAdd(&csr[key_of(X, cell)], 1);
                 path[n++] = ((uint32_t)cell << 2) | dd;
             } else {
-                // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265).
-                // On a BFS distance map dm[state] = 1 + min over its transitions, so a state with a single candidate
-                // always descends to dm - 1: only switches need distance gathers, the rest is walked on the LDS bitmap.
-                uint32_t distance = X.dm[(dmb + cell) * 4 + dd];  // finite <=> some candidate is strictly closer
-                // consume the gather here: inside the loop its wait would also wait for the previous iteration's path
-                // store (loads and stores retire in order on vmcnt), i.e. one HBM round trip per step
-                const bool reachable = distance != FL_INF16;
-                asm volatile("" :: "v"(reachable));
+                // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265):
+                // the choice at every (cell, orientation) is static, see k_nexthop.  cutils walks max_depth iterations and
+                // stops where nothing is strictly closer (i.e. on the target); upstream stops at the target.
                 int depth = 0;
-                // cutils walks max_depth iterations and stops where nothing is strictly closer;
-                // upstream stops at the target
+                bool none = false;
                 while (depth < pred_depth && (CUTILS || cell != target)) {
-                    const uint32_t g = cellw[cell] & 0xFFFFu;
-                    const uint32_t bits = nibble(g, dd);
-                    int best = -1;
-                    if (cell != target && reachable) {
-                        if (__popc(g) == 1) {  // is_dead_end: only the reverse exit
-                            const uint32_t ex = (dd + 2u) & 3u;
-                            if ((bits >> (3 - ex)) & 1) best = (int)ex;
-                        } else {
-                            const uint32_t fwd3 = bits & ~(1u << (3 - ((dd + 2u) & 3u)));  // L, F, R candidates
-                            if (__popc(fwd3) == 1 && fwd3 == bits) best = (int)first_dir(fwd3);
-                            else {
-                                // L, F, R in the reference's iteration order; ties go to the first minimum
-                                uint32_t v3[3], bestv = distance;
-#pragma unroll
-                                for (int j = 0; j < 3; j++) {
-                                    const uint32_t nd = (dd + (uint32_t)(j + 3)) & 3u;
-                                    v3[j] = ((bits >> (3 - nd)) & 1) ? (uint32_t)X.dm[(dmb + step_cell(cell, nd, W)) * 4 + nd] : FL_INF16;
-                                }
-#pragma unroll
-                                for (int j = 0; j < 3; j++)
-                                    if (v3[j] != FL_INF16 && v3[j] < bestv) { best = (int)((dd + (uint32_t)(j + 3)) & 3u); bestv = v3[j]; }
-                            }
-                        }
-                    }
+                    const uint32_t hop = ((uint32_t)nh_u[cell] >> (3u * dd)) & 7u;
                     if (n <= horizon) atomicAdd(&csr[key_of(X, cell)], 1);
                     path[n++] = ((uint32_t)cell << 2) | dd;
                     depth++;
-                    if (best < 0) { none = true; break; }
-                    cell = step_cell(cell, (uint32_t)best, W);
-                    dd = (uint32_t)best;
-                    distance -= 1;
+                    if (hop == 4u) { none = true; break; }
+                    cell = step_cell(cell, hop, W);
+                    dd = hop;
                 }
                 // the final waypoint (predictions.cpp:131-133; rail_env_shortest_paths.py:266-267 when not cut by max_depth)
                 if (!none && (CUTILS || depth < pred_depth)) {
@@ -1131,25 +1109,29 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words, int nh_words) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
            al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
-           2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + 64;
+           2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)nh_words * 2) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, int scr_words, bool &csr_lds, int &nt, size_t &lds) {
+static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
-    for (int c = 0; c < 2; c++) {
-        csr_lds = c == 0 && K <= OBS_CSR_LDS_MAX_KEYS;
-        if (c == 0 && !csr_lds) continue;
+    // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
+    // of an env, else they are read from HBM anyway), then the prediction index
+    const int nh_fit = (size_t)d.Umax * d.H * d.W * 2 <= 24 * 1024 ? d.Umax * d.H * d.W : 0;
+    for (int c = 0; c < 4; c++) {
+        csr_lds = (c < 2) && K <= OBS_CSR_LDS_MAX_KEYS;
+        nh_words = (c % 2 == 0) ? nh_fit : 0;
+        if ((c < 2 && !csr_lds) || (c % 2 == 0 && nh_fit == 0)) continue;
         for (int k = 0; k < 3; k++) {
             nt = nts[k];
-            lds = obs_lds_bytes(d, csr_lds, nt, scr_words);
+            lds = obs_lds_bytes(d, csr_lds, nt, scr_words, nh_words);
             if (lds <= 160 * 1024) return true;
         }
     }
@@ -1172,7 +1154,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.scr_words = 2 * F_WORDS * 32;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
@@ -1186,6 +1168,6 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.n_tree_nodes = n;
     P.scr_words = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
