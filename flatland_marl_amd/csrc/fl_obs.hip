@@ -725,7 +725,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     const int nh_n = d.U[b] * HW;
     const bool nh_in_lds = P.nh_lds_words >= nh_n && P.pred_depth >= 0;
     if (nh_in_lds) for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
-    const uint16_t *nh_env = nh_in_lds ? (const uint16_t *)nh_lds : gnh;
+
     for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
@@ -941,15 +941,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             int cell = a_vpos[i];
             uint32_t dd = a_dir[i];
             const int target = a_target[i];
-            const uint16_t *nh_u = nh_env + (size_t)a_tslot[i] * HW;
             int n = 0;
             // last waypoint that can be occupied within the horizon; only those enter the per-key index
             const int tpc = a_tpc[i];
             const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
-            if (cell == target) {  // holds at its position (DONE agents): predictions.cpp:208-214
-                atomicAdd(&csr[key_of(X, cell)], 1);
-                path[n++] = ((uint32_t)cell << 2) | dd;
-            } else {
+            auto walk = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
+                if (cell == target) {  // holds at its position (DONE agents): predictions.cpp:208-214
+                    atomicAdd(&csr[key_of(X, cell)], 1);
+                    path[n++] = ((uint32_t)cell << 2) | dd;
+                    return;
+                }
                 // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265):
                 // the choice at every (cell, orientation) is static, see k_nexthop.  cutils walks max_depth iterations and
                 // stops where nothing is strictly closer (i.e. on the target); upstream stops at the target.
@@ -971,7 +972,10 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
                 }
                 // upstream: a None path (nothing strictly closer) means the agent stands still (predictions.py:150-156);
                 // that only happens on the first step, where exactly one waypoint was counted
-            }
+            };
+            // two call sites so that each keeps a static address space (LDS copy vs HBM table)
+            if (nh_in_lds) walk(nh_lds + (size_t)a_tslot[i] * HW);
+            else walk(gnh + (size_t)a_tslot[i] * HW);
             int lp = n - 1;
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
