@@ -225,22 +225,18 @@ __device__ __forceinline__ void team_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Pass B of a tree: the visited cells of ALL nodes (node k has n_vis[k] of them) are split evenly over the TEAM lanes;
-// every lane walks its slice (a cheap skip to the slice start, then the feature block per cell) and merges its
-// partial result into the node's accumulators with LDS atomics (min / sum / max are associative).
-template <bool CUTILS, int TEAM, int CAP, bool ITL>
-__device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool have, int tl, int n_nodes, int *scr) {
-    const int *vs = scr;  // plain LDS reads; team_sync() orders them against the other lanes' writes
+// Pass B of the trees.  team_prepare: per team (= one agent's tree), inclusive prefix of the nodes' visit counts and
+// reset of the node accumulators.  wg_pass_b: the visited cells of ALL nodes of ALL trees of the batch are split evenly
+// over ALL lanes of the workgroup; every lane walks its slice (binary search for its first team / node, a cheap skip
+// to the slice start, then ONE lock-step loop over its cells) and merges partial results into the nodes' accumulators
+// with LDS atomics (min / sum / max are associative).
+template <int TEAM, int CAP>
+__device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int *scr) {
     unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
-#ifdef FL_OBS_TIMING
-    const long long dbg_t0 = (long long)wall_clock64();
-#endif
-    // accumulators + inclusive prefix of the visit counts
     int run_base = 0;
     for (int k0 = 0; k0 < CAP; k0 += TEAM) {
         const int k = k0 + tl;
-        int v = (k < n_nodes && k < CAP) ? vs[F_VIS * CAP + k] : 0;
-        if (k < CAP && (k >= n_nodes || vs[F_START * CAP + k] < 0)) v = 0;
+        int v = (have && k < n_nodes && k < CAP && scr[F_START * CAP + k] >= 0) ? scr[F_VIS * CAP + k] : 0;
         int incl = v;
 #pragma unroll
         for (int off = 1; off < TEAM; off <<= 1) { const int u = __shfl_up(incl, off, TEAM); if (tl >= off) incl += u; }
@@ -253,36 +249,65 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
         }
         run_base = __shfl(incl, TEAM - 1, TEAM);
     }
-    team_sync();
+    return run_base;
+}
+
+// team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1)
+template <bool CUTILS, int CAP, bool ITL>
+__device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int n_teams, int *scr0, int team_words,
+                                          const int *team_meta) {
+    __syncthreads();
+    const int lane = tid & 63;
+    // inclusive prefix over the teams' cell counts, one team per lane (n_teams <= 64); every wavefront computes it
+    const int tv = lane < n_teams ? team_meta[lane] : 0;
+    int tincl = tv;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(tincl, off); if (lane >= off) tincl += u; }
+    const int total = __shfl(tincl, 63);
+    const int q = (total + nt - 1) / nt;
+    int pos = tid * q;
+    const int end = min(pos + q, total);
+    // first team whose inclusive prefix exceeds pos (all lanes take part in the shuffles)
+    int tlo = 0, thi = n_teams - 1;
+    const int ppos = min(pos, max(total - 1, 0));
+    for (int it = 0; it < 6; it++) {
+        const int mid = (tlo + thi) >> 1;
+        const int v = __shfl(tincl, mid);
+        if (tlo < thi) { if (v > ppos) thi = mid; else tlo = mid + 1; }
+    }
+    int team = tlo;
+    const int t_excl = __shfl(tincl, team) - __shfl(tv, team);
 #ifdef FL_OBS_TIMING
     const long long dbg_t1 = (long long)wall_clock64();
+    int dbg_skip = 0;
 #endif
-    const int total = have ? run_base : 0;
-    const int q = (total + TEAM - 1) / TEAM;
-    int pos = tl * q;
-    const int end = min(pos + q, total);
-    int dbg_items = 0, dbg_skip = 0;
     if (pos < end) {
-        // first node whose inclusive prefix exceeds pos
-        int lo = 0, hi = n_nodes - 1;
+        const int *vs = scr0 + team * team_words;
+        int nn = team_meta[64 + team];
+        int handle = team_meta[128 + team];
+        // first node of the team whose inclusive prefix exceeds the team-local position
+        const int lpos = pos - t_excl;
+        int lo = 0, hi = nn - 1;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (vs[F_INCL * CAP + mid] > pos) hi = mid; else lo = mid + 1;
+            if (vs[F_INCL * CAP + mid] > lpos) hi = mid; else lo = mid + 1;
         }
         int node = lo;
-        const int target = X.a_target[handle];
-        const float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
-        const double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
+        int target = X.a_target[handle];
+        float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
+        double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
         // state of the piece being walked
         int left, cell, tot;
         uint32_t dd;
         {
             const int nvis = vs[F_VIS * CAP + node], incl = vs[F_INCL * CAP + node];
-            const int k = pos - (incl - nvis);  // offset inside the node's walk
+            const int k = lpos - (incl - nvis);  // offset inside the node's walk
             const int st = vs[F_START * CAP + node];
             cell = st >> 2; dd = st & 3;
             skip_cells(X, cell, dd, k);
+#ifdef FL_OBS_TIMING
             dbg_skip = k;
+#endif
             tot = vs[F_TOT * CAP + node] + k;
             left = nvis - k;
         }
@@ -291,23 +316,41 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
         w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
         w.min_speed = 1.0;
         auto flush = [&]() {
-            if (w.other_agent != 0x7fffffff) atomicMin(&scr[F_OA * CAP + node], w.other_agent);
-            if (w.pot_conflict != 0x7fffffff) atomicMin(&scr[F_PC * CAP + node], w.pot_conflict);
-            if (w.other_target != 0x7fffffff) atomicMin(&scr[F_OT * CAP + node], w.other_target);
-            if (w.same_dir) atomicAdd(&scr[F_SAME * CAP + node], w.same_dir);
-            if (w.opp_dir) atomicAdd(&scr[F_OPP * CAP + node], w.opp_dir);
-            if (w.malfunctioning) atomicMax(&scr[F_MALF * CAP + node], w.malfunctioning);
-            if (w.ready) atomicAdd(&scr[F_READY * CAP + node], w.ready);
+            int *sc = scr0 + team * team_words;
+            unsigned long long *ms = reinterpret_cast<unsigned long long *>(sc + F_MS * CAP);
+            if (w.other_agent != 0x7fffffff) atomicMin(&sc[F_OA * CAP + node], w.other_agent);
+            if (w.pot_conflict != 0x7fffffff) atomicMin(&sc[F_PC * CAP + node], w.pot_conflict);
+            if (w.other_target != 0x7fffffff) atomicMin(&sc[F_OT * CAP + node], w.other_target);
+            if (w.same_dir) atomicAdd(&sc[F_SAME * CAP + node], w.same_dir);
+            if (w.opp_dir) atomicAdd(&sc[F_OPP * CAP + node], w.opp_dir);
+            if (w.malfunctioning) atomicMax(&sc[F_MALF * CAP + node], w.malfunctioning);
+            if (w.ready) atomicAdd(&sc[F_READY * CAP + node], w.ready);
             if (w.min_speed < 1.0) atomicMin(&ms[node], (unsigned long long)__double_as_longlong(w.min_speed));
         };
-        // ONE loop over the lane's cells (lanes of a wave run it in lock step); a node boundary is a rare side branch
+        // ONE loop over the lane's cells (lanes of a wave run it in lock step); node / team boundaries are side branches
         for (; pos < end; pos++) {
             if (left == 0) {
                 flush();
                 w.other_agent = w.pot_conflict = w.other_target = 0x7fffffff;
                 w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
                 w.min_speed = 1.0;
-                do { node++; } while (vs[F_VIS * CAP + node] == 0 || vs[F_START * CAP + node] < 0);
+                while (true) {  // next node with cells, possibly in the next team(s)
+                    node++;
+                    if (node >= nn) {
+                        team++;
+                        vs = scr0 + team * team_words;
+                        nn = team_meta[64 + team];
+                        handle = team_meta[128 + team];
+                        node = 0;
+                        if (handle >= 0) {
+                            target = X.a_target[handle];
+                            tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);
+                            tpc_d = 1.0 / X.a_speed[handle];
+                        }
+                        continue;
+                    }
+                    if (vs[F_START * CAP + node] >= 0 && vs[F_VIS * CAP + node] > 0) break;
+                }
                 const int st = vs[F_START * CAP + node];
                 cell = st >> 2; dd = st & 3;
                 tot = vs[F_TOT * CAP + node];
@@ -327,12 +370,12 @@ __device__ __forceinline__ void team_pass_b(const ObsCtx &X, int handle, bool ha
 #ifdef FL_OBS_TIMING
     if (X.dbg) {
         const long long dbg_t2 = (long long)wall_clock64();
-        // slowest lane of the env: slice-loop ticks << 40 | items scanned << 20 | (cells walked + skipped)
-        atomicMax((unsigned long long *)&X.dbg[6], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)dbg_items << 20) | (unsigned long long)(dbg_skip + (end > tl * q ? end - tl * q : 0)));
+        // slowest lane of the env: slice-loop ticks << 40 | cells per lane << 20 | cells skipped
+        atomicMax((unsigned long long *)&X.dbg[6], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)q << 20) | (unsigned long long)dbg_skip);
         atomicMax((unsigned long long *)&X.dbg[7], (unsigned long long)total);
     }
 #endif
-    team_sync();
+    __syncthreads();
 }
 
 // the 12 features of node k from its descriptor and accumulators (treeobs.cpp:546-573 / observations.py:433-461)
@@ -437,9 +480,10 @@ struct ObsArgs {
 // every row that is not a real node is -inf.
 template <int TEAM, int CAP, bool ITL>
 __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                              int nwaves, int *wave_scr_base, const uint32_t *cellw, const int *a_vpos,
-                                              const uint8_t *a_dir, const uint16_t *a_malf, const double *a_speed,
-                                              const int *a_tslot) {
+                                              int nwaves, int *wave_scr0, int *team_meta, const uint32_t *cellw,
+                                              const int *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
+                                              const double *a_speed, const int *a_tslot) {
+    int *wave_scr_base = wave_scr0 + wave * (64 / TEAM) * (F_WORDS * CAP);
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
     const int A = X.A, W = X.W, HW = X.HW;
     const int team = lane / TEAM, tl = lane % TEAM;
@@ -506,7 +550,12 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             }
         }
         team_sync();
-        team_pass_b<false, TEAM, CAP, ITL>(X, ia, have, tl, have ? NN : 1, scr);
+        {
+            const int tot_cells = team_prepare<TEAM, CAP>(have, tl, have ? NN : 1, scr);
+            const int team_id = wave * TPW + team;
+            if (tl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? NN : 1; team_meta[128 + team_id] = have ? i : -1; }
+        }
+        wg_pass_b<false, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr0, F_WORDS * CAP, team_meta);
         if (have) {  // rows
             const int *vs = scr;
             for (int idx = 1 + tl; idx < NN; idx += TEAM) {
@@ -527,9 +576,10 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
 template <bool ITL>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                             int nwaves, int *wave_scr, const uint32_t *cellw, const int *a_vpos,
-                                             const int *a_pos, const uint8_t *a_dir, const uint8_t *a_state,
-                                             const double *a_speed, const int *a_tslot, float max_dist) {
+                                             int nwaves, int *wave_scr, int *team_meta, const uint32_t *cellw,
+                                             const int *a_vpos, const int *a_pos, const uint8_t *a_dir,
+                                             const uint8_t *a_state, const double *a_speed, const int *a_tslot,
+                                             float max_dist) {
     const int A = X.A, W = X.W, HW = X.HW;
     {
         // two agents per wavefront, a team of 32 lanes each
@@ -617,7 +667,12 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                 }
             }
             team_sync();
-            team_pass_b<true, 32, CAP, ITL>(X, ia, have, gl, have ? node_base : 1, scr);
+            {
+                const int tot_cells = team_prepare<32, CAP>(have, gl, have ? node_base : 1, scr);
+                const int team_id = wave * 2 + grp;
+                if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; }
+            }
+            wg_pass_b<true, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, F_WORDS * CAP, team_meta);
             if (have) {  // rows: lane gl writes node gl + 1
                 const int *vs = scr;
                 for (int idx = gl + 1; idx < N; idx += 32) {
@@ -700,6 +755,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
+    int *team_meta = (int *)carve(192 * 4);
     int *wave_scr = (int *)carve((size_t)(nt >> 6) * P.scr_words * 4);  // per-wave tree scratch (node tables)
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
@@ -1075,14 +1131,14 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (CUTILS) {
-        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
-        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
     } else if (P.max_depth <= 2) {
-        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     } else {
-        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr + wave * P.scr_words, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     }
     OBS_STAMP(5);
 }
@@ -1117,7 +1173,7 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words,
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) +
+    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
            al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)nh_words * 2) + 64;
 }
