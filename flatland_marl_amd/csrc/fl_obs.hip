@@ -52,11 +52,8 @@ struct ObsCtx {
     const uint16_t *a_malf;       // real down counter
     const double *a_speed;
     const uint16_t *a_tpc;        // times per cell of the predictor
-    const uint16_t *a_lp;         // last reachable waypoint index (0 = holds at its virtual position)
     const int *a_tslot;
     const int *a_target;
-    const uint32_t *path;         // HBM [A][pcap] cell << 2 | dir
-    int pcap;
     const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
@@ -70,17 +67,6 @@ __device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
     if (X.keycell) return cell;
     const int r = cell / X.W;
     return (cell - r * X.W) * X.W + r;
-}
-
-// waypoint index of agent a at predicted time t
-template <bool CUTILS>
-__device__ __forceinline__ int waypoint_at(const ObsCtx &X, int a, int t) {
-    const int lp = X.a_lp[a], tpc = X.a_tpc[a];
-    if (CUTILS) {  // predictions.cpp:207-227: entry t >= 1 is produced by loop index t-1, first advance at index 0
-        if (t == 0) return 0;
-        return min((t - 1) / tpc + 1, lp);
-    }
-    return min(t / tpc, lp);  // predictions.py:159-174: advance when index % times_per_cell == 0, index >= 1
 }
 
 // One node of a tree = one branch walk (_explore_branch: treeobs.cpp:258-610 / observations.py:256-494).
@@ -835,9 +821,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     X.seg = d.seg + (size_t)b * HW * 4;
     X.dbg = P.dbg ? P.dbg + (size_t)b * 8 : nullptr;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
-    X.a_tpc = a_tpc; X.a_lp = a_lp; X.a_tslot = a_tslot; X.a_target = a_target;
-    X.pcap = S.pred_cap;
-    X.path = S.path + (size_t)b * A * S.pred_cap;
+    X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;

@@ -83,9 +83,7 @@ def test_batched_step_matches_oracle_with_synth_stream_and_autoreset(bases, B, s
     seed = 99
     tcount = np.zeros(B, dtype=np.int64)
     for it in range(steps):
-        for kind in (0,):
-            pass
-        rew, done, done_all = env.step_synth(seed, stream_base=1000, kind=it % 2 if False else 0, auto_reset=True)
+        rew, done, done_all = env.step_synth(seed, stream_base=1000, kind=0, auto_reset=True)
         st, el = env.state()
         rew, done, done_all = rew.cpu().numpy(), done.cpu().numpy(), done_all.cpu().numpy()
         for b in range(B):
