@@ -173,23 +173,36 @@ __device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int targe
                     other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
                     cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
                 };
-                int e = lo;
-                for (; e < hi; e++) {  // until-the-end items
-                    const uint32_t it = (ITL ? X.items_lds : X.items_glb)[e];
-                    if (!IT_TOEND(it)) break;
-                    test_item(it);
-                }
-                if (e < hi) {
-                    const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
-                    int l = e, h = hi;  // first item with t_lo >= tmin
-                    while (l < h) {
-                        const int mid = (l + h) >> 1;
-                        if (IT_TLO((ITL ? X.items_lds : X.items_glb)[mid]) < tmin) l = mid + 1; else h = mid;
-                    }
-                    for (; l < hi; l++) {
-                        const uint32_t it = (ITL ? X.items_lds : X.items_glb)[l];
-                        if (IT_TLO(it) > t2) break;
+                if (ITL) {
+                    int e = lo;
+                    for (; e < hi; e++) {  // until-the-end items
+                        const uint32_t it = X.items_lds[e];
+                        if (!IT_TOEND(it)) break;
                         test_item(it);
+                    }
+                    if (e < hi) {
+                        const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
+                        int l = e, h = hi;  // first item with t_lo >= tmin
+                        while (l < h) {
+                            const int mid = (l + h) >> 1;
+                            if (IT_TLO(X.items_lds[mid]) < tmin) l = mid + 1; else h = mid;
+                        }
+                        for (; l < hi; l++) {
+                            const uint32_t it = X.items_lds[l];
+                            if (IT_TLO(it) > t2) break;
+                            test_item(it);
+                        }
+                    }
+                } else {
+                    // large maps: the lists stay unsorted in HBM scratch (sorting them costs more than scanning them);
+                    // four independent loads in flight, most items fall out at the interval test
+                    for (int e0 = lo; e0 < hi; e0 += 4) {
+                        uint32_t itv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) itv[q] = X.items_glb[min(e0 + q, hi - 1)];
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (e0 + q < hi) test_item(itv[q]);
                     }
                 }
                 const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
@@ -324,6 +337,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                     node++;
                     if (node >= nn) {
                         team++;
+                        if (team >= n_teams) { team = n_teams - 1; node = nn - 1; pos = end; break; }  // cannot happen: the prefix says cells remain
                         vs = scr0 + team * team_words;
                         nn = team_meta[64 + team];
                         handle = team_meta[128 + team];
@@ -337,6 +351,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                     }
                     if (vs[F_START * CAP + node] >= 0 && vs[F_VIS * CAP + node] > 0) break;
                 }
+                if (pos >= end) break;
                 const int st = vs[F_START * CAP + node];
                 cell = st >> 2; dd = st & 3;
                 tot = vs[F_TOT * CAP + node];
@@ -1054,6 +1069,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         uint32_t *stage_items = S.cell_stage + (size_t)b * A * S.pred_cap;
         const bool fit = CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP;
         if (fit) { csr_items = items_lds; X.items_lds = items_lds; stage_items = stage_lds; }
+        else stage_items = csr_items;  // no sort: the fill writes the final (unsorted) lists
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
         for (int i = wave; i < A; i += (nt >> 6)) {
@@ -1080,7 +1096,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         __syncthreads();
         // sort every key's list (until-the-end items first, then by t_lo, ties by staging position): every item -- one
         // lane each, all in parallel -- finds its rank inside its key's staged list and moves to its final place
-        for (int i = wave; i < A; i += (nt >> 6)) {
+        for (int i = wave; fit && i < A; i += (nt >> 6)) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i];
             for (int k = lane; k <= lp; k += 64) {
