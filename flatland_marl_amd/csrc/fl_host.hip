@@ -315,6 +315,17 @@ int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset) {
     return FL_OK;
 }
 
+int fl_policy_pack(int B, int A, int E, const int32_t *adjacency_dev, const int32_t *node_order_dev,
+                   const int32_t *edge_order_dev, int64_t *adjacency_out_dev, int64_t *node_order_out_dev,
+                   int64_t *edge_order_out_dev, void *hip_stream) {
+    if (B <= 0 || A <= 0 || E <= 0 || !adjacency_dev || !node_order_dev || !edge_order_dev || !adjacency_out_dev ||
+        !node_order_out_dev || !edge_order_out_dev) { set_err("fl_policy_pack: bad argument"); return FL_ERR_ARG; }
+    fl_launch_policy_pack(B, A, E, adjacency_dev, node_order_dev, edge_order_dev, (long long *)adjacency_out_dev,
+                          (long long *)node_order_out_dev, (long long *)edge_order_out_dev, (hipStream_t)hip_stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed) {
     NEED_COMMIT(h);
     const size_t BA = (size_t)h->B * h->A;

@@ -118,6 +118,8 @@ void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
 void fl_launch_segments(const FlDev &d, hipStream_t s);
 void fl_launch_nexthop(const FlDev &d, hipStream_t s);
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
+void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
+                           long long *no_out, long long *eo_out, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s);

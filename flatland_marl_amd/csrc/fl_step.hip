@@ -417,6 +417,31 @@ void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s
     hipLaunchKernelGGL(k_metrics, dim3(1), dim3(256), 0, s, d, out4, reset);
 }
 
+// plfActor.get_feature casts + Network.modify_adjacency (solution/plfActor.py:48-74, nn/net_tree.py:105-116)
+__global__ void k_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo,
+                              long long *adj_out, long long *no_out, long long *eo_out) {
+    const long long n_adj = (long long)B * A * E * 3, n_no = (long long)B * A * (E + 1), n_eo = (long long)B * A * E;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_adj; k += stride) {
+        const long long tree = k / (3ll * E);  // b * A + a
+        const int col = (int)(k % 3);
+        long long v = adj[k];
+        // -2 -> -(B*A*N) so that the offset cannot make it non-negative; offsets on parent / child; negatives -> -2
+        if (v == -2) v = -(long long)B * A * (E + 1);
+        if (col < 2) v += tree * (E + 1);
+        adj_out[k] = v < 0 ? -2 : v;
+    }
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_no; k += stride) no_out[k] = no[k];
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_eo; k += stride) eo_out[k] = eo[k];
+}
+
+void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
+                           long long *no_out, long long *eo_out, hipStream_t s) {
+    const long long n = (long long)B * A * E * 3;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_policy_pack, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, B, A, E, adj, no, eo, adj_out, no_out, eo_out);
+}
+
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s) {
     const int n = d.B * d.A;
     hipLaunchKernelGGL(k_reset, dim3((n + 255) / 256), dim3(256), 0, s, d, mask_dev, fresh);

@@ -25,7 +25,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
-           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
+           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -75,6 +75,7 @@ def lib():
         L.fl_metrics.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        L.fl_policy_pack.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.fl_get_state.argtypes = [vp, vp, vp]
         L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
         L.fl_distance_map_rebuild.argtypes = [vp]
@@ -104,6 +105,15 @@ def malf_threshold(rate):
         return 0
     p = float(1 - np.exp(-rate))
     return int(math.ceil(p * 2.0 ** 53))
+
+
+def policy_pack(adjacency, node_order, edge_order, adj_out, no_out, eo_out):
+    """int32 device tensors [B,A,E,3] / [B,A,E+1] / [B,A,E] -> int64 outputs (fl_policy_pack) on torch's current stream."""
+    import torch
+    B, A, E = adjacency.shape[:3]
+    s = torch.cuda.current_stream(adjacency.device).cuda_stream
+    _chk(lib().fl_policy_pack(B, A, E, adjacency.data_ptr(), node_order.data_ptr(), edge_order.data_ptr(),
+                              adj_out.data_ptr(), no_out.data_ptr(), eo_out.data_ptr(), C.c_void_p(s)))
 
 
 class BatchedRailEnv:
@@ -225,6 +235,21 @@ class BatchedRailEnv:
                                  o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
                                  o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
         return o
+
+    def policy_inputs(self, obs=None):
+        """(agents_attr f32[B,A,83], forest f32[B,A,N,12], adjacency i64[B,A,N-1,3], node_order i64[B,A,N],
+        edge_order i64[B,A,N-1]) on the device, exactly what Network.forward consumes after its own
+        modify_adjacency (solution/nn/net_tree.py:72-116); adjacency is already modified."""
+        t = self.torch
+        o = obs if obs is not None else self.obs_cutils()
+        B, A, E = o["adjacency"].shape[:3]
+        if not hasattr(self, "_pol"):
+            self._pol = (t.empty((B, A, E, 3), dtype=t.int64, device=self.device),
+                         t.empty((B, A, E + 1), dtype=t.int64, device=self.device),
+                         t.empty((B, A, E), dtype=t.int64, device=self.device))
+        adj, no, eo = self._pol
+        policy_pack(o["adjacency"], o["node_order"], o["edge_order"], adj, no, eo)
+        return o["agent_attr"], o["forest"], adj, no, eo
 
     def obs_tree(self, max_depth=2, pred_depth=30):
         """upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense tensor."""

@@ -1,0 +1,109 @@
+"""Ingest of the reference's on-disk env format (RailEnvPersister.save, flatland/envs/persistence.py:24-64:
+a pickled dict {"grid", "agents", "malfunction", "max_episode_steps", optional "distance_map"}) without the
+reference installed: the Round-2 test files (solution/debug-environments/generate_test_cases.py:14-68) load straight
+into the batched env.
+
+The pickle refers to flatland classes (the Agent namedtuple of agent_utils.py:18-34, SpeedCounter, TrainStateMachine,
+...).  A restricted Unpickler maps every `flatland.*` global to an inert stand-in and refuses anything else that is not
+numpy / builtins, so loading a file never executes reference or third-party code.
+
+The MT19937 state of the env is NOT part of the format (the reference re-seeds at load); the caller supplies it.
+"""
+import io
+import pickle
+
+import numpy as np
+
+# field order of flatland.envs.agent_utils.Agent (agent_utils.py:18-34)
+AGENT_FIELDS = ("initial_position", "initial_direction", "direction", "target", "moving", "earliest_departure",
+                "latest_arrival", "handle", "position", "arrival_time", "old_direction", "old_position",
+                "speed_counter", "action_saver", "state_machine", "malfunction_handler")
+
+
+class _Bag:
+    """stand-in for plain flatland objects (SpeedCounter, ActionSaver, TrainStateMachine, ...): keeps their __dict__."""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):
+            state = {**(state[0] or {}), **state[1]}
+        self.__dict__.update(state or {})
+
+
+class _Agent(tuple):
+    def __new__(cls, *args):
+        return super().__new__(cls, args)
+
+    def __getattr__(self, name):
+        try:
+            return self[AGENT_FIELDS.index(name)]
+        except ValueError:
+            raise AttributeError(name)
+
+
+class _Tuple(tuple):
+    """other flatland namedtuples (MalfunctionProcessData = (malfunction_rate, min_duration, max_duration))."""
+
+    def __new__(cls, *args):
+        return super().__new__(cls, args)
+
+
+def _int_enum(value):
+    return int(value)
+
+
+_SAFE_BUILTINS = {"tuple", "list", "dict", "set", "frozenset", "int", "float", "bool", "complex", "str", "bytes",
+                  "bytearray", "slice", "range", "object"}
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith("flatland."):
+            if name == "Agent":
+                return _Agent
+            if name in ("Grid4TransitionsEnum", "TrainState", "RailEnvActions"):
+                return _int_enum
+            if name in ("MalfunctionProcessData", "MalfunctionParameters", "Malfunction"):
+                return _Tuple
+            return type(name, (_Bag,), {})
+        if module in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric",
+                      "numpy._core.numeric", "numpy.dtypes"):
+            return getattr(__import__(module, fromlist=[name]), name)
+        if module == "builtins" and name in _SAFE_BUILTINS:
+            return getattr(__import__("builtins"), name)
+        if (module, name) in (("copyreg", "_reconstructor"), ("collections", "OrderedDict")):
+            return getattr(__import__(module, fromlist=[name]), name)
+        raise pickle.UnpicklingError("refusing to load %s.%s from an env file" % (module, name))
+
+
+def load_env_dict(path_or_bytes):
+    """RailEnvPersister.load_env_dict (persistence.py:132-162) for .pkl files."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    return _Unpickler(io.BytesIO(data)).load()
+
+
+def static_from_env_dict(env_dict, mt_key, mt_pos):
+    """static description for BatchedRailEnv / RailEnv from a loaded env dict (what set_full_state restores,
+    persistence.py:164-202, plus the schedule fields the Agent tuples carry)."""
+    grid = np.array(env_dict["grid"], dtype=np.uint16)
+    agents = env_dict["agents"]
+    malf = env_dict.get("malfunction")
+    rate, mn, mx = (malf[0], malf[1], malf[2]) if malf is not None else (0.0, 0, 0)
+    speed = [float(a.speed_counter._speed) for a in agents]
+    return dict(
+        grid=grid,
+        init_pos=np.array([a.initial_position for a in agents], dtype=np.int32),
+        init_dir=np.array([int(a.initial_direction) for a in agents], dtype=np.int32),
+        target=np.array([a.target for a in agents], dtype=np.int32),
+        speed=np.array(speed, dtype=np.float64),
+        earliest=np.array([a.earliest_departure for a in agents], dtype=np.int32),
+        latest=np.array([a.latest_arrival for a in agents], dtype=np.int32),
+        T=np.int32(env_dict["max_episode_steps"]),
+        malf_rate=np.float64(rate), malf_min=np.int32(mn), malf_max=np.int32(mx),
+        mt_key=np.asarray(mt_key, dtype=np.uint32), mt_pos=np.int32(mt_pos),
+    )
+
+
+def distance_map_from_env_dict(env_dict):
+    """the saved float64 [A, H, W, 4] distance map, or None."""
+    dm = env_dict.get("distance_map")
+    return None if dm is None else np.asarray(dm, dtype=np.float64)

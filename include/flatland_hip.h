@@ -106,6 +106,15 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
  * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);
 
+/* Policy-input boundary, stateless (device pointers, enqueued on hip_stream): the int64 tensors
+ * plfActor.get_feature builds (solution/plfActor.py:48-74) with Network.modify_adjacency already applied
+ * (solution/nn/net_tree.py:105-116: parent/child get the offset (b*A + a) * num_nodes, every negative entry -- the
+ * -2 padding AND the action code -1 -- becomes -2).  adjacency i32[B][A][E][3] -> i64, node_order i32[B][A][E+1] -> i64,
+ * edge_order i32[B][A][E] -> i64. */
+int fl_policy_pack(int B, int A, int E, const int32_t *adjacency_dev, const int32_t *node_order_dev,
+                   const int32_t *edge_order_dev, int64_t *adjacency_out_dev, int64_t *node_order_out_dev,
+                   int64_t *edge_order_out_dev, void *hip_stream);
+
 /* Host read-backs (synchronising). state int32[B][A][FL_STATE_COLS]; elapsed int32[B]. */
 int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed);
 /* distance map of env b: returns number of unique targets in *n_targets; dm u16[n][H][W][4] (0xFFFF = inf),

@@ -126,3 +126,34 @@ def test_distance_map_rebuild_is_idempotent():
     env.step_synth(1, 0, 1, auto_reset=True)
     env.obs_cutils()
     env.check()
+
+
+def test_policy_inputs_match_reference_modify_adjacency():
+    """golden: Network.modify_adjacency of the real reference on four cutils outputs stacked as a batch."""
+    import torch
+    from flatland_marl_amd.hip_backend import policy_pack
+    fx = util.load("cfg2_uniform")
+    g = util.load("policy_inputs")
+    idx = g["obs_index"]
+    adj = torch.from_numpy(np.stack([fx["o_adjacency"][k] for k in idx]).astype(np.int32)).cuda()
+    no = torch.from_numpy(np.stack([fx["o_node_order"][k] for k in idx]).astype(np.int32)).cuda()
+    eo = torch.from_numpy(np.stack([fx["o_edge_order"][k] for k in idx]).astype(np.int32)).cuda()
+    B, A, E = adj.shape[:3]
+    out = (torch.empty((B, A, E, 3), dtype=torch.int64, device="cuda"), torch.empty((B, A, E + 1), dtype=torch.int64, device="cuda"),
+           torch.empty((B, A, E), dtype=torch.int64, device="cuda"))
+    policy_pack(adj, no, eo, *out)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), g["adjacency_mod"])
+    np.testing.assert_array_equal(out[1].cpu().numpy(), no.cpu().numpy().astype(np.int64))
+    np.testing.assert_array_equal(out[2].cpu().numpy(), eo.cpu().numpy().astype(np.int64))
+    # and through the env: same transformation of its own observation
+    env = _env([util.static_of(fx)] * 3)
+    attr, forest, adj64, no64, eo64 = env.policy_inputs()
+    raw = env.obs_cutils()["adjacency"].cpu().numpy().astype(np.int64)
+    exp = raw.copy()
+    exp[exp == -2] = -3 * env.A * 31
+    ids = (np.arange(3)[:, None] * env.A + np.arange(env.A)[None, :])[:, :, None] * 31
+    exp[..., 0] += ids
+    exp[..., 1] += ids
+    exp[exp < 0] = -2
+    np.testing.assert_array_equal(adj64.cpu().numpy(), exp)
+    assert attr.dtype == torch.float32 and forest.dtype == torch.float32 and no64.dtype == torch.int64
