@@ -193,7 +193,7 @@ int fl_commit(fl_batch *h) {
     FlDev &d = h->d;
     d.Umax = Umax;
     DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
-    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4);
+    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
     DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
     DALLOC(d.seg, (size_t)B * HW * 4);
     DALLOC(d.nh, (size_t)B * Umax * HW);
@@ -311,6 +311,13 @@ int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset) {
     NEED_COMMIT(h);
     if (!out4_dev) { set_err("fl_metrics: null buffer"); return FL_ERR_ARG; }
     fl_launch_metrics(h->d, (long long *)out4_dev, reset, h->stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_info(fl_batch *h, uint8_t *action_required_dev, int32_t *malfunction_dev, uint8_t *state_dev, double *scores_dev) {
+    NEED_COMMIT(h);
+    fl_launch_info(h->d, action_required_dev, malfunction_dev, state_dev, scores_dev, h->stream);
     HIPCHK(hipGetLastError());
     return FL_OK;
 }

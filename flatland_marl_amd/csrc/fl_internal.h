@@ -56,6 +56,7 @@ struct FlDev {
     int *U;
     int *err;  // [B] first error code raised by a kernel for env b (0 = none)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
+    int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
     uint16_t *grid;  // [B][H*W]
     uint16_t *dm;    // [B][Umax][H*W][4]
     int *ut;         // [B][Umax] unique target cells
@@ -120,6 +121,7 @@ void fl_launch_nexthop(const FlDev &d, hipStream_t s);
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
                            long long *no_out, long long *eo_out, hipStream_t s);
+void fl_launch_info(const FlDev &d, uint8_t *action_required, int32_t *malfunction, uint8_t *state, double *scores, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s);

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
 
     int t = d.t[b];
     int was_done = d.done_all[b];
+    const bool filter_required = (auto_reset & 2) != 0;  // flags: bit 0 auto reset, bit 1 eval_env.parse_actions filter
+    auto_reset &= 1;
     if (was_done && !auto_reset) {  // rail_env.py:508-509
         if (tid == 0) atomicCAS(&d.err[b], 0, FL_ERR_EPISODE_DONE);
         return;
@@ -222,6 +224,9 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
         old_pos = pos; old_dir = dir;  // :521-522
         uint32_t raw = SYNTH ? synth_action(seed, stream_base + (uint32_t)b, (uint32_t)(t - 1), (uint32_t)i, synth_kind)
                              : (uint32_t)actions[g];
+        // eval_env.parse_actions (solution/eval_env.py:33-39): an agent without action_required (rail_env.py:243-258) is
+        // dropped from the action dict
+        if (filter_required && !(state == ST_READY || (is_on_map(state) && scount == 0))) raw = 255u;
         if (raw > 4u) raw = ACT_NOTHING;  // absent (255) or illegal -> DO_NOTHING (:527, action_preprocessing.py:7-11)
         a = raw;
         if (a == ACT_NOTHING) a = (state == ST_MOVING) ? (uint32_t)ACT_FORWARD : (saved ? saved : (uint32_t)ACT_NOTHING);
@@ -352,10 +357,11 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
             reward = is_off_map(state) ? -travel : (latest - t) - travel;
         }
         done = 1;
-        if (reward != 0) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward);
-        if (state == ST_DONE) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull);
+        if (reward != 0) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward); atomicAdd(&L.misc[5], reward); }
+        if (state == ST_DONE) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull); atomicAdd(&L.misc[6], 1); }
     }
 
+    __syncthreads();
     // ---- write back
     if (act) {
         d.pos[g] = pos; d.old_pos[g] = old_pos; d.arrival[g] = arrival;
@@ -378,7 +384,11 @@ __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restric
             d.done_all[b] = ended ? 1 : 0;
             done_all_out[b] = ended ? 1 : 0;
             d.metrics[(size_t)b * 4 + 2] += A;              // only this workgroup touches env b's counters
-            if (ended) atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
+            if (ended) {
+                atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
+                d.last_episode[(size_t)b * 2 + 0] = L.misc[5];  // evaluator scoring inputs (service.py:875-879,900-913)
+                d.last_episode[(size_t)b * 2 + 1] = L.misc[6];
+            }
             if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
         }
     }
@@ -440,6 +450,28 @@ void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_
     const long long n = (long long)B * A * E * 3;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_policy_pack, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, B, A, E, adj, no, eo, adj_out, no_out, eo_out);
+}
+
+// RailEnv.get_info_dict (rail_env.py:452-468) as tensors + the evaluator's per-episode scores
+__global__ void k_info(FlDev d, uint8_t *action_required, int32_t *malfunction, uint8_t *state, double *scores) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.B * d.A) {
+        const uint32_t pk = d.pk[g];
+        const uint32_t st = PK_STATE(pk);
+        if (action_required) action_required[g] = (st == ST_READY || (is_on_map(st) && PK_SCOUNT(pk) == 0)) ? 1 : 0;
+        if (malfunction) malfunction[g] = (int32_t)(d.malf[g] & 0xFFFFu);
+        if (state) state[g] = (uint8_t)st;
+    }
+    if (scores && g < d.B) {
+        // normalized reward = sum(rewards) / (max_episode_steps * n_agents) + 1, completion = arrived / n_agents
+        scores[(size_t)g * 2 + 0] = 1.0 + (double)d.last_episode[(size_t)g * 2 + 0] / ((double)d.T[g] * (double)d.A);
+        scores[(size_t)g * 2 + 1] = (double)d.last_episode[(size_t)g * 2 + 1] / (double)d.A;
+    }
+}
+
+void fl_launch_info(const FlDev &d, uint8_t *action_required, int32_t *malfunction, uint8_t *state, double *scores, hipStream_t s) {
+    const int n = d.B * d.A;
+    hipLaunchKernelGGL(k_info, dim3((n + 255) / 256), dim3(256), 0, s, d, action_required, malfunction, state, scores);
 }
 
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s) {

@@ -25,7 +25,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
-           "fl_metrics", "fl_obs_cutils", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
+           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -75,6 +75,7 @@ def lib():
         L.fl_metrics.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        L.fl_info.argtypes = [vp, vp, vp, vp, vp]
         L.fl_policy_pack.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.fl_get_state.argtypes = [vp, vp, vp]
         L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
@@ -184,16 +185,31 @@ class BatchedRailEnv:
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _chk(lib().fl_reset(self.h, None if m is None else _p(m), int(fresh)))
 
-    def step(self, actions, auto_reset=False):
-        """actions: uint8 tensor [B, A] on the device (255 = agent not in the action dict)."""
+    def step(self, actions, auto_reset=False, filter_required=False):
+        """actions: uint8 tensor [B, A] on the device (255 = agent not in the action dict).
+        filter_required: ignore the actions of agents without action_required (eval_env.parse_actions)."""
         t = self.torch
         if not (isinstance(actions, t.Tensor) and actions.is_cuda):
             actions = t.as_tensor(np.ascontiguousarray(actions, dtype=np.uint8)).to(self.device)
         actions = actions.contiguous()
         assert actions.dtype == t.uint8 and actions.shape == (self.B, self.A)
         _chk(lib().fl_step(self.h, actions.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(),
-                           self.done_all.data_ptr(), int(auto_reset)))
+                           self.done_all.data_ptr(), int(bool(auto_reset)) | (2 if filter_required else 0)))
         return self.rewards, self.dones, self.done_all
+
+    def info(self):
+        """get_info_dict as device tensors + evaluator scores of each env's last finished episode."""
+        t = self.torch
+        if not hasattr(self, "_info"):
+            B, A = self.B, self.A
+            self._info = dict(action_required=t.zeros((B, A), dtype=t.uint8, device=self.device),
+                              malfunction=t.zeros((B, A), dtype=t.int32, device=self.device),
+                              state=t.zeros((B, A), dtype=t.uint8, device=self.device),
+                              scores=t.zeros((B, 2), dtype=t.float64, device=self.device))
+        i = self._info
+        _chk(lib().fl_info(self.h, i["action_required"].data_ptr(), i["malfunction"].data_ptr(), i["state"].data_ptr(),
+                           i["scores"].data_ptr()))
+        return i
 
     def step_synth(self, seed, stream_base=0, kind=0, auto_reset=True):
         _chk(lib().fl_step_synth(self.h, int(seed), int(stream_base), int(kind), self.rewards.data_ptr(),

@@ -259,6 +259,12 @@ def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=
             a[h % 10 == 0] = ABSENT           # 10 %: not in the dict
             a[h % 23 == 1] = 7                # illegal action value
             ad = {i: int(a[i]) for i in range(A) if a[i] != ABSENT}
+        elif stream == "filtered":
+            # eval_env.parse_actions (solution/eval_env.py:33-39): keep only the actions of agents with action_required
+            a = synth.uniform_actions(seed, 0, t, A).astype(np.int64)
+            req = {i: env.action_required(ag) for i, ag in enumerate(env.agents)}
+            ad = {i: int(a[i]) for i in range(A) if req[i]}
+            out.setdefault("_req", []).append(np.array([req[i] for i in range(A)], dtype=np.uint8))
         elif stream == "spfollow":
             ad = sp_follow_actions(env, rng)
             a = np.array([ad[i] for i in range(A)])
@@ -277,6 +283,8 @@ def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=
             rec_obs(t, obs)
         if py_builders and (t % pytree_every == 0) and not dones["__all__"]:
             rec_py(t)
+    if "_req" in out:
+        out["action_required"] = np.stack(out.pop("_req"))
     out["actions"] = np.stack(actions)
     for k, v in per_step.items():
         out["s_" + k] = np.stack(v)
@@ -333,6 +341,7 @@ JOBS = {
                                         pytree=[(3, 30)], pytree_every=150),
     "cfg3_spfollow_malf100": lambda: run_episode("cfg3_spfollow_malf100", "Test_4", "Level_0", "spfollow", seed=22,
                                                  malfunction_interval=100, obs_every=32),
+    "cfg2_filtered": lambda: run_episode("cfg2_filtered", "Test_2", "Level_2", "filtered", seed=61, obs_every=16),
     # a TALL map (width 26 < height 40): the reference's prediction keys col * width + row collide there (tool.h:391-398)
     "tall_spfollow": lambda: run_episode("cfg0_tall_spfollow", "Test_2", "Level_3", "spfollow", seed=51, obs_every=2,
                                          dims=(26, 40), pytree=[(2, 30)], pytree_every=40, malfunction_interval=300),

@@ -17,7 +17,7 @@ def test_bench_replica0_equals_golden_episode(workload, B):
     fx = util.load(name)
     assert seed == fseed == int(fx["stream_seed"])
     env = BatchedRailEnv(envs)
-    n = len(fx["actions"])
+    n = len(util.actions_of(fx))
     for t in range(n):
         rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=True)
         st, _ = env.state()

@@ -86,7 +86,7 @@ def test_masked_and_non_fresh_reset():
     fx = util.load("cfg1_spfollow")
     st = util.static_of(fx)
     env = _env([st, st, st])
-    acts = fx["actions"]
+    acts = util.actions_of(fx)
     for a in acts:
         env.step(torch.from_numpy(np.stack([a, a, a])).cuda())
     s_end, el = env.state()
@@ -157,3 +157,31 @@ def test_policy_inputs_match_reference_modify_adjacency():
     exp[exp < 0] = -2
     np.testing.assert_array_equal(adj64.cpu().numpy(), exp)
     assert attr.dtype == torch.float32 and forest.dtype == torch.float32 and no64.dtype == torch.int64
+
+
+def test_action_required_filter_info_and_scores_match_reference():
+    """golden episode captured through eval_env.parse_actions: RAW policy actions + the fused filter must reproduce it;
+    fl_info gives get_info_dict's tensors and the evaluator's normalized reward of the finished episode."""
+    import torch
+    fx = util.load("cfg2_filtered")
+    env = _env([util.static_of(fx)])
+    raw = np.array(fx["actions"], dtype=np.uint8)
+    req = np.asarray(fx["action_required"])
+    assert (raw[req == 0] != 255).any()                         # the raw stream really contains actions to drop
+    info = env.info()
+    np.testing.assert_array_equal(info["action_required"].cpu().numpy()[0], req[0])
+    for t in range(len(raw)):
+        rew, done, done_all = env.step(torch.from_numpy(raw[t][None, :].copy()).cuda(), filter_required=True)
+        st, _ = env.state()
+        np.testing.assert_array_equal(st[0], util.golden_state(fx, t), err_msg=f"step {t}")
+        np.testing.assert_array_equal(rew.cpu().numpy()[0], fx["s_reward"][t])
+        info = env.info()
+        np.testing.assert_array_equal(info["state"].cpu().numpy()[0], fx["s_state"][t])
+        np.testing.assert_array_equal(info["malfunction"].cpu().numpy()[0], fx["s_malf"][t])
+        if t + 1 < len(raw):
+            np.testing.assert_array_equal(info["action_required"].cpu().numpy()[0], req[t + 1], err_msg=f"required after {t}")
+    env.check()
+    assert bool(done_all.cpu().numpy()[0])
+    scores = env.info()["scores"].cpu().numpy()[0]
+    assert scores[0] == fx["final_metric"][2]                   # 1 + sum(rewards) / T / A (eval_env.py:92, service.py:875-879)
+    assert scores[1] == (fx["s_state"][-1] == 6).sum() / env.A

@@ -23,7 +23,7 @@ def test_facade_episode_matches_reference(name):
     assert set(info) == {"action_required", "malfunction", "speed", "state"}
     np.testing.assert_array_equal(np.array(obs[0], dtype=np.float32), fx["o_attr"][0])
     A = env.get_num_agents()
-    for t, row in enumerate(fx["actions"]):
+    for t, row in enumerate(util.actions_of(fx)):
         # eval_env.parse_actions keeps only the actions of agents with action_required
         req = {i: (fx["s_state"][t - 1][i] == 1 or (fx["s_state"][t - 1][i] in (3, 4, 5) and fx["s_scount"][t - 1][i] == 0))
                if t > 0 else False for i in range(A)}

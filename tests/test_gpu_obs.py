@@ -52,7 +52,7 @@ def test_obs_match_reference_golden(name):
                 _assert_same(got, fx[pk][k], f"{name} t={t} {pk}")
 
     check(0)
-    for t, a in enumerate(fx["actions"]):
+    for t, a in enumerate(util.actions_of(fx)):
         env.step(torch.from_numpy(a[None, :].copy()).cuda())
         check(t + 1)
     env.check()

@@ -18,7 +18,7 @@ def test_step_matches_reference_golden(name):
     import torch
     fx = util.load(name)
     env = _env([util.static_of(fx)])
-    acts = fx["actions"]
+    acts = util.actions_of(fx)
     for t in range(len(acts)):
         rew, done, done_all = env.step(torch.from_numpy(acts[t][None, :].copy()).cuda())
         st, el = env.state()
@@ -44,7 +44,7 @@ def test_step_after_done_raises_like_reference():
     from flatland_marl_amd.hip_backend import EpisodeDoneError
     fx = util.load("cfg1_spfollow")
     env = _env([util.static_of(fx)])
-    for a in fx["actions"]:
+    for a in util.actions_of(fx):
         env.step(torch.from_numpy(a[None, :].copy()).cuda())
     env.check()
     env.step(torch.from_numpy(fx["actions"][0][None, :].copy()).cuda())

@@ -11,7 +11,7 @@ from tests import util
 def test_step_trajectory_matches_reference(name):
     fx = util.load(name)
     e = orc.OracleEnv(fx)
-    acts = fx["actions"]
+    acts = util.actions_of(fx)
     for t in range(len(acts)):
         rew, done, done_all = e.step(acts[t])
         np.testing.assert_array_equal(e.state(), util.golden_state(fx, t), err_msg=f"{name} step {t}")
@@ -50,7 +50,7 @@ def test_motion_check_known_answers():
 def test_step_after_done_raises():
     fx = util.load("cfg1_spfollow")
     e = orc.OracleEnv(fx)
-    for a in fx["actions"]:
+    for a in util.actions_of(fx):
         e.step(a)
     with pytest.raises(RuntimeError, match="Episode is done"):
         e.step(fx["actions"][0])

@@ -38,7 +38,7 @@ def test_obs_match_reference(name):
                 np.testing.assert_array_equal(e.obs_pytree(depth, pdepth), fx[pk][k], err_msg=f"{name} t={t} {pk}")
 
     check(0)
-    for t, a in enumerate(fx["actions"]):
+    for t, a in enumerate(util.actions_of(fx)):
         e.step(a)
         # the deadlock flags of flatland_cutils are sticky and updated once per get_many(), i.e. once per step
         if (t + 1) not in obs_steps:

@@ -32,3 +32,13 @@ def static_of(fx, mt_key=None, mt_pos=None):
     if mt_key is not None:
         d["mt_key"], d["mt_pos"] = mt_key, mt_pos
     return d
+
+
+def actions_of(fx):
+    """[steps, A] uint8 actions as the env saw them: fixtures captured through eval_env.parse_actions store the RAW
+    policy actions plus the action_required mask; agents without action_required were dropped from the dict (255)."""
+    a = np.array(fx["actions"], dtype=np.uint8)
+    if "action_required" in getattr(fx, "files", fx):
+        a = a.copy()
+        a[np.asarray(fx["action_required"]) == 0] = 255
+    return a
