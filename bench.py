@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--tree-depth", type=int, default=2)
     ap.add_argument("--tree-pred", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate", action="store_true", help="launch the two observation builders separately")
     ap.add_argument("--dm-rebuild", action="store_true", help="also rebuild all distance maps every step (BASELINE configs[4])")
     args = ap.parse_args()
 
@@ -81,14 +82,20 @@ def main():
     A = env.A
     stream_base = rank * B
 
+    fused = args.tree_depth > 0 and 0 <= args.tree_pred <= env.pred_depth and not args.separate
+
     def step_all(ev=None):
         if ev: ev[0].record()
         env.step_synth(seed, stream_base, 0, auto_reset=True)
         if ev: ev[1].record()
-        env.obs_cutils()
-        if ev: ev[2].record()
-        if args.tree_depth > 0:
-            env.obs_tree(args.tree_depth, args.tree_pred)
+        if fused:
+            env.obs_both(args.tree_depth, args.tree_pred)
+            if ev: ev[2].record()
+        else:
+            env.obs_cutils()
+            if ev: ev[2].record()
+            if args.tree_depth > 0:
+                env.obs_tree(args.tree_depth, args.tree_pred)
         if ev: ev[3].record()
         if args.dm_rebuild:
             env.rebuild_distance_maps()
@@ -114,11 +121,12 @@ def main():
         K = args.steps
         seg = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])  # ms
         ms_step, ms_cutils, ms_tree = seg.mean(0)
-        names = ["k_step<synth>", "k_obs<cutils>", "k_obs<tree>"]
-        per_agent_bytes = [env.algorithmic_bytes_per_agent_step(False, 0),
-                           env.algorithmic_bytes_per_agent_step(True, 0) - env.algorithmic_bytes_per_agent_step(False, 0),
-                           (env.algorithmic_bytes_per_agent_step(False, args.tree_depth)
-                            - env.algorithmic_bytes_per_agent_step(False, 0)) if args.tree_depth > 0 else 0.0]
+        names = ["k_step<synth>", "k_obs<cutils+tree>" if fused else "k_obs<cutils>", "k_obs<tree>"]
+        b_step = env.algorithmic_bytes_per_agent_step(False, 0)
+        b_cut = env.algorithmic_bytes_per_agent_step(True, 0) - b_step
+        b_tree = (env.algorithmic_bytes_per_agent_step(False, args.tree_depth) - b_step) if args.tree_depth > 0 else 0.0
+        # fused launch: both outputs, the rail bitmap is read once
+        per_agent_bytes = [b_step, b_cut + b_tree - 2.0 * env.H * env.W / A, 0.0] if fused else [b_step, b_cut, b_tree]
         dom = int(np.argmax(seg.mean(0)))
         bytes_per_launch = per_agent_bytes[dom] * B * A
         achieved = bytes_per_launch / (seg.mean(0)[dom] * 1e-3) / 1e9
@@ -142,12 +150,13 @@ def main():
                        "actions": "counter-hash uniform 0..4 generated on device, auto-reset at episode end",
                        "parallelism": "envs sharded over %d GPU(s), metrics all-reduce only" % world},
             "tree_obs_ms_per_step": float(ms_cutils + ms_tree),
-            "kernel_ms": {"step": float(ms_step), "obs_cutils": float(ms_cutils), "obs_tree": float(ms_tree)},
+            "kernel_ms": ({"step": float(ms_step), "obs_cutils_tree_fused": float(ms_cutils)} if fused else
+                          {"step": float(ms_step), "obs_cutils": float(ms_cutils), "obs_tree": float(ms_tree)}),
             "episodes": int(m[3]), "arrived_agents": int(m[1]), "sum_terminal_reward": int(m[0]), "agent_steps": int(m[2]),
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": 8000.0, "unit": "GB/s",
                          "frac": float(achieved / 8000.0), "traffic": traffic,
-                         "algorithmic_bytes_per_agent_step": {"step": per_agent_bytes[0], "obs_cutils": per_agent_bytes[1],
-                                                              "obs_tree": per_agent_bytes[2]},
+                         "algorithmic_bytes_per_agent_step": {"step": per_agent_bytes[0], names[1]: per_agent_bytes[1],
+                                                              "obs_tree_separate": per_agent_bytes[2]},
                          "note": "dependent-gather/latency-bound integer kernel; achieved = algorithmic bytes per launch / mean launch time"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -423,6 +423,27 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
     return FL_OK;
 }
 
+int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev, int32_t *adjacency_dev,
+                       int32_t *node_order_dev, int32_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev,
+                       int tree_max_depth, int tree_pred_depth, double *tree_out_dev) {
+    NEED_COMMIT(h);
+    if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED || tree_max_depth < 1 ||
+        tree_max_depth > 3 || tree_pred_depth < 0 || tree_pred_depth > pred_depth) {
+        set_err("fl_obs_cutils_tree: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [1,3], 0 <= tree_pred_depth <= pred_depth",
+                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev || !tree_out_dev) {
+        set_err("fl_obs_cutils_tree: null output buffer");
+        return FL_ERR_ARG;
+    }
+    int rc = fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
+                                edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev, h->stream);
+    if (rc != FL_OK) { set_err("fl_obs_cutils_tree: launch failed"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     NEED_COMMIT(h);
     if (max_depth < 1 || max_depth > 3 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {

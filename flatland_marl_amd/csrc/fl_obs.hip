@@ -462,9 +462,9 @@ __device__ __forceinline__ int road_type_of(uint32_t cell) {  // loader.cpp:122-
 
 
 // ---------------------------------------------------------------------------------------------- kernel
-// MODE 0 = flatland_cutils outputs, MODE 1 = upstream dense tree.
+// outputs of the flatland_cutils builder and of the upstream dense tree builder (k_obs MODE 0 / 1 / 2 = both)
 struct ObsArgs {
-    int max_nodes, pred_depth, max_depth;
+    int max_nodes, pred_depth, max_depth, tree_pred;  // pred_depth: cutils predictor, tree_pred: upstream predictor
     float *attr, *forest;
     int32_t *adjacency, *node_order, *edge_order;
     uint8_t *valid;
@@ -587,7 +587,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
         constexpr int CAP = 32;
         const int grp = lane >> 5, gl = lane & 31;
         const int N = P.max_nodes;
-        int *scr = wave_scr + wave * P.scr_words + grp * (F_WORDS * CAP);
+        int *scr = wave_scr + (wave * 2 + grp) * (F_WORDS * CAP);  // team t at wave_scr + t * team_words (wg_pass_b)
         for (int base = 0; base < A; base += nwaves * 2) {
             const int i = base + wave * 2 + grp;
             const bool have = i < A;
@@ -727,9 +727,12 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
     }
 }
 
-template <int MODE, bool CSR_LDS>
-__global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
-    constexpr bool CUTILS = MODE == 0;
+// One observation build for the workgroup's env.  STAGE 0: stand-alone; the fused launch (both builders) runs STAGE 1
+// (cutils; also prepares what the second stage needs) and then STAGE 2 (upstream tree), which reuses the LDS-resident
+// rail bitmap / occupancy table / next-hop tables and the predicted paths of stage 1: the upstream predictor's path
+// is a prefix of the cutils one (same greedy descent, it only stops at the target and after fewer steps).
+template <bool CUTILS, bool CSR_LDS, int STAGE>
+__device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, H = d.H, W = d.W, HW = H * W;
     const bool keycell = H <= W;  // col * W + row is injective over the grid: use the cell id as prediction key
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     uint16_t *a_malf = (uint16_t *)carve((size_t)A * 2);
     uint16_t *a_tpc = (uint16_t *)carve((size_t)A * 2);
     uint16_t *a_lp = (uint16_t *)carve((size_t)A * 2);
+    uint16_t *a_n = (uint16_t *)carve((size_t)A * 2);  // waypoints of the agent's predicted path
     uint8_t *a_dir = (uint8_t *)carve((size_t)A);
     uint8_t *a_state = (uint8_t *)carve((size_t)A);
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
@@ -776,11 +780,13 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 #endif
     OBS_STAMP(0);
 
+    const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
     // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
-    for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
     const uint16_t *gnh = d.nh + (size_t)b * d.Umax * HW;
     const int nh_n = d.U[b] * HW;
-    const bool nh_in_lds = P.nh_lds_words >= nh_n && P.pred_depth >= 0;
+    const bool nh_in_lds = P.nh_lds_words >= nh_n && (STAGE == 0 ? my_pred_depth >= 0 : true);
+    if (STAGE != 2) {
+    for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
     if (nh_in_lds) for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
 
     for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
@@ -826,7 +832,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (on) atomicMax(&slot_agent[slot], i);
             else atomicAdd(&slot_ready[slot], 1);
         }
-        if (!CUTILS) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
+        if (!CUTILS || STAGE == 1) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
+    }
+    } else {
+        // second stage: only the predictor's times-per-cell differ (int(np.reciprocal(speed)), predictions.py:139)
+        for (int i = tid; i < A; i += nt) a_tpc[i] = (uint16_t)(int)(1.0 / a_speed[i]);
     }
     __syncthreads();
 
@@ -840,12 +850,12 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
-    X.Tn = P.pred_depth >= 0 ? P.pred_depth + 1 : 0;
+    X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
     OBS_STAMP(1);
     // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows
-    if (CUTILS) {
+    if (CUTILS && STAGE != 2) {
         // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
         // its exits leads to an empty cell or to a free, not yet deadlocked agent (or it has no exit at all);
         // every other active agent becomes (and stays) deadlocked.  Equivalent to the reference's DFS + _fix_deps.
@@ -986,7 +996,8 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     if (X.Tn > 0) {
         for (int k = tid; k <= K; k += nt) csr[k] = 0;
         __syncthreads();
-        const int pred_depth = P.pred_depth;
+        const int pred_depth = my_pred_depth;
+        if (STAGE != 2) {
         // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
         // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
         // walkers would share four
@@ -1035,6 +1046,23 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
+            a_n[i] = (uint16_t)n;
+        }
+        } else {
+            // second stage: the upstream path is the prefix of the cutils path kept by stage 1 -- it stops at the target
+            // (which ends the cutils path too) and after pred_depth waypoints (rail_env_shortest_paths.py:245-267)
+            for (int i = tid; i < A; i += nt) {
+                const int n_c = a_n[i];
+                const int n_py = (n_c - 1 < pred_depth) ? n_c : pred_depth;
+                const int horizon = (X.Tn - 1) / a_tpc[i];
+                a_lp[i] = (uint16_t)max(0, min(n_py - 1, horizon));
+            }
+            __syncthreads();
+            for (int i = wave; i < A; i += (nt >> 6)) {
+                const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const int lp = a_lp[i];
+                for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
+            }
         }
         __syncthreads();
         OBS_STAMP(3);
@@ -1143,6 +1171,19 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     OBS_STAMP(5);
 }
 
+// MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch
+template <int MODE, bool CSR_LDS>
+__global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
+    if (MODE == 0) obs_body<true, CSR_LDS, 0>(d, S, P);
+    else if (MODE == 1) obs_body<false, CSR_LDS, 0>(d, S, P);
+    else {
+        obs_body<true, CSR_LDS, 1>(d, S, P);
+        __syncthreads();
+        obs_body<false, CSR_LDS, 2>(d, S, P);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------- host side
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
@@ -1173,7 +1214,7 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words,
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 3 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
+    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
            al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)nh_words * 2) + 64;
 }
@@ -1218,11 +1259,30 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
+int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
+                       int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
+                       int max_depth, int tree_pred, double *tree_out, hipStream_t s) {
+    if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
+    if (max_depth > 3 || tree_pred > pred_depth || tree_pred < 0) return FL_ERR_ARG;  // the upstream path must be a prefix
+    ObsArgs P = {};
+    P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
+    P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
+    P.max_depth = max_depth; P.tree_pred = tree_pred; P.tree_out = tree_out;
+    int n = 0, p = 1;
+    for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
+    P.n_tree_nodes = n;
+    const int w_c = 2 * F_WORDS * 32, w_t = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
+    P.scr_words = w_c > w_t ? w_c : w_t;
+    bool csr_lds; int nt; size_t lds;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
+}
+
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
     if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
     ObsArgs P = {};
-    P.max_depth = max_depth; P.pred_depth = pred_depth; P.tree_out = out; P.dbg = o.dbg;
+    P.max_depth = max_depth; P.tree_pred = pred_depth; P.tree_out = out; P.dbg = o.dbg;
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;

@@ -25,7 +25,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
-           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
+           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -75,6 +75,7 @@ def lib():
         L.fl_metrics.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        L.fl_obs_cutils_tree.argtypes = [vp, i32, i32] + [vp] * 7 + [i32, i32, vp]
         L.fl_info.argtypes = [vp, vp, vp, vp, vp]
         L.fl_policy_pack.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.fl_get_state.argtypes = [vp, vp, vp]
@@ -251,6 +252,20 @@ class BatchedRailEnv:
                                  o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
                                  o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
         return o
+
+    def obs_both(self, max_depth=2, pred_depth=30):
+        """obs_cutils() and obs_tree(max_depth, pred_depth) in one launch; returns (cutils dict, tree tensor)."""
+        o = self._obs_buffers()
+        n = (4 ** (max_depth + 1) - 1) // 3
+        key = (max_depth,)
+        if key not in self._tree:
+            self._tree[key] = self.torch.zeros((self.B, self.A, n, 12), dtype=self.torch.float64, device=self.device)
+        out = self._tree[key]
+        _chk(lib().fl_obs_cutils_tree(self.h, self.max_nodes, self.pred_depth, o["agent_attr"].data_ptr(),
+                                      o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
+                                      o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr(),
+                                      max_depth, pred_depth, out.data_ptr()))
+        return o, out
 
     def policy_inputs(self, obs=None):
         """(agents_attr f32[B,A,83], forest f32[B,A,N,12], adjacency i64[B,A,N-1,3], node_order i64[B,A,N],

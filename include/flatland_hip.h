@@ -92,6 +92,14 @@ int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8
  * kind 0 = uniform 0..4, 1 = forward-biased; env b uses stream id stream_base + b and its own step counter. */
 int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
                   uint8_t *dones_dev, uint8_t *done_all_dev, int auto_reset);
+/* fl_obs_cutils + fl_obs_tree in ONE launch (same outputs, bit for bit): the second builder reuses the first one's
+ * LDS-resident maps and predicted paths (the upstream predictor's path is a prefix of the cutils one).
+ * Requires 0 <= tree_pred_depth <= pred_depth. */
+int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev,
+                       int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
+                       uint8_t *valid_actions_dev, double *props_dev, int tree_max_depth, int tree_pred_depth,
+                       double *tree_out_dev);
+
 /* Running sums over all envs since the last reset of the counters, written to out4_dev int64[4] (device):
  * (sum of terminal rewards, arrived agents, agent-steps, finished episodes) -- the scalars the multi-GPU
  * harness all-reduces; mirrors eval_env.final_metric's inputs (solution/eval_env.py:81-94). */

@@ -185,3 +185,24 @@ def test_action_required_filter_info_and_scores_match_reference():
     scores = env.info()["scores"].cpu().numpy()[0]
     assert scores[0] == fx["final_metric"][2]                   # 1 + sum(rewards) / T / A (eval_env.py:92, service.py:875-879)
     assert scores[1] == (fx["s_state"][-1] == 6).sum() / env.A
+
+
+@pytest.mark.parametrize("name,B,depth,pred", [("cfg2_spfollow", 6, 2, 30), ("cfg0_tall_spfollow", 3, 3, 30),
+                                               ("cfg3_uniform", 3, 2, 500), ("cfg5_fwd_head", 1, 2, 30)])
+def test_fused_observation_launch_equals_separate_launches(name, B, depth, pred):
+    fx = util.load(name)
+    st = util.static_of(fx)
+    env = _env([st] * B)
+    for t in range(90):
+        env.step_synth(4, 0, 1, auto_reset=True)
+        if t % 6 == 0:
+            sep = {k: v.clone() for k, v in env.obs_cutils().items()}
+            sep_tree = env.obs_tree(depth, pred).clone()
+            # the deadlock flags are sticky: a second cutils build in the same step must not change anything either
+            fo, ft = env.obs_both(depth, pred)
+            for k in sep:
+                _same(fo[k].cpu().numpy(), sep[k].cpu().numpy(), f"{name} t={t} {k}")
+            _same(ft.cpu().numpy(), sep_tree.cpu().numpy(), f"{name} t={t} tree")
+        else:
+            env.obs_both(depth, pred)
+    env.check()
