@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--tree-depth", type=int, default=2)
     ap.add_argument("--tree-pred", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=1, help="bracket the kernels of every n-th timed step with HIP events")
     ap.add_argument("--separate", action="store_true", help="launch the two observation builders separately")
     ap.add_argument("--dm-rebuild", action="store_true", help="also rebuild all distance maps every step (BASELINE configs[4])")
     args = ap.parse_args()
@@ -103,7 +104,8 @@ def main():
     for _ in range(args.warmup):
         step_all()
     env.metrics(reset=True)
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] if k % args.event_every == 0 else None
+              for k in range(args.steps)]
     dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -119,7 +121,7 @@ def main():
 
     if rank == 0:
         K = args.steps
-        seg = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])  # ms
+        seg = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events if e])  # ms
         ms_step, ms_cutils, ms_tree = seg.mean(0)
         names = ["k_step<synth>", "k_obs<cutils+tree>" if fused else "k_obs<cutils>", "k_obs<tree>"]
         b_step = env.algorithmic_bytes_per_agent_step(False, 0)

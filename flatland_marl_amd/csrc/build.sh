@@ -2,7 +2,7 @@
 # Builds the C-ABI shared library for gfx950 in-tree (travels to the GPU box with the snapshot).
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/libflatland_hip.so"
+OUT="${OUT:-$HERE/libflatland_hip.so}"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 SRCS=("$HERE/fl_host.hip" "$HERE/fl_step.hip" "$HERE/fl_dmap.hip" "$HERE/fl_obs.hip")
 newest=0

@@ -79,8 +79,9 @@ __device__ __forceinline__ uint32_t tbit(uint32_t cell, uint32_t dir, uint32_t m
 // first set transition in N,E,S,W order of a non-zero nibble
 __device__ __forceinline__ uint32_t first_dir(uint32_t bits) { return (uint32_t)__clz((int)bits) - 28u; }
 __device__ __forceinline__ int step_cell(int cell, uint32_t dir, int W) {
-    // N(-1,0) E(0,1) S(1,0) W(0,-1)
-    return cell + (dir == 0 ? -W : dir == 1 ? 1 : dir == 2 ? W : -1);
+    // N(-1,0) E(0,1) S(1,0) W(0,-1), branch-free: sign = +1 for N/E, -1 for S/W; magnitude -W for N/S, 1 for E/W
+    const int sgn = 1 - (int)(dir & 2u), ew = (int)(dir & 1u);
+    return cell + __mul24(sgn, __mul24(ew, W + 1) - W);
 }
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {

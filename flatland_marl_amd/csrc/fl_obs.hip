@@ -60,7 +60,14 @@ struct ObsCtx {
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // HBM env base [Umax][HW][4]
     const uint2 *seg;             // HBM env base [HW * 4] static branch-walk table
+    // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
+    uint2 *wl_occ, *wl_cf;
+    int wl_occ_cap, wl_cf_cap;
+    int *wl_cnt;                  // LDS [2] entries pushed to wl_occ / wl_cf
+    const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
+    int tshift;
     long long *dbg;               // diagnostic builds
+    int dbg_base;
 };
 
 __device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
@@ -105,14 +112,6 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, i
     return n;
 }
 
-// the agent-dependent features of (a slice of) a walk: everything that depends on where the other agents are and
-// are predicted to be
-struct WalkDyn {
-    int other_agent, pot_conflict, other_target;  // tot_dist of the first hit, INT_MAX = none
-    int same_dir, opp_dir, malfunctioning, ready;
-    double min_speed;
-};
-
 // advance k cells along a chain of single-transition cells (no features)
 __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t &d, int k) {
     for (int v = 0; v < k; v++) {
@@ -121,102 +120,120 @@ __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t 
     }
 }
 
-// feature block of ONE visited cell of a branch walk (treeobs.cpp:322-465 / observations.py:296-371): cell, walking
-// direction d, tot_dist tot; accumulates into o
-template <bool CUTILS, bool ITL>
-__device__ __forceinline__ void walk_cell(const ObsCtx &X, int handle, int target, float tpc_f, double tpc_d, int cell,
-                                          uint32_t d, uint32_t cw, int tot, WalkDyn &o) {
-    const uint32_t bits = nibble(cw & 0xFFFFu, d);
-    const uint32_t sl = cw >> 16;
-    if (sl != 0xFFFFu) {  // treeobs.cpp:322-357
-        const int ag = X.slot_agent[sl];
-        if (ag >= 0) {
-            if (tot < o.other_agent) o.other_agent = tot;
-            const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
-            if (mf > o.malfunctioning) o.malfunctioning = mf;
-            const int rd = X.slot_ready[sl];
-            if (rd > 0) o.ready += CUTILS ? rd - 1 : rd;  // cutils starts the count at 0 (treeobs.cpp:82-91)
-            if (X.a_dir[ag] == d) {
-                o.same_dir += 1;
-                const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
-                if (sp < o.min_speed) o.min_speed = sp;
-            } else {
-                o.opp_dir += 1;
-            }
-        }
-    }
-    if (X.Tn > 0 && o.pot_conflict == 0x7fffffff && tot < X.Tn) {  // treeobs.cpp:378-465 / observations.py:329-367
-        const int pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
-        if (pt < X.Tn) {
-            const int key = key_of(X, cell);
-            const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
-            if (hi > lo) {
-                const uint32_t tlast = (uint32_t)(X.Tn - 1);
-                const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
-                // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
-                // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
-                // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
-                bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
-                auto test_item = [&](uint32_t it) {
-                    const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
-                    if (th < t1 || tl > t2) return;
-                    const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
-                    const int a = IT_AGENT(it);
-                    // direction the conflict test uses: upstream takes the one at the matching time step
-                    // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
-                    // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is not on
-                    // this waypoint at t0
-                    uint32_t cd = IT_DIR(it);
-                    if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
-                    const bool oth = a != handle;
-                    const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
-                    other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
-                    cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
-                };
-                if (ITL) {
-                    int e = lo;
-                    for (; e < hi; e++) {  // until-the-end items
-                        const uint32_t it = X.items_lds[e];
-                        if (!IT_TOEND(it)) break;
-                        test_item(it);
-                    }
-                    if (e < hi) {
-                        const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
-                        int l = e, h = hi;  // first item with t_lo >= tmin
-                        while (l < h) {
-                            const int mid = (l + h) >> 1;
-                            if (IT_TLO(X.items_lds[mid]) < tmin) l = mid + 1; else h = mid;
-                        }
-                        for (; l < hi; l++) {
-                            const uint32_t it = X.items_lds[l];
-                            if (IT_TLO(it) > t2) break;
-                            test_item(it);
-                        }
-                    }
-                } else {
-                    // large maps: the lists stay unsorted in HBM scratch (sorting them costs more than scanning them);
-                    // four independent loads in flight, most items fall out at the interval test
-                    for (int e0 = lo; e0 < hi; e0 += 4) {
-                        uint32_t itv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) itv[q] = X.items_glb[min(e0 + q, hi - 1)];
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (e0 + q < hi) test_item(itv[q]);
-                    }
-                }
-                const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
-                if (hit) o.pot_conflict = tot;
-            }
-        }
-    }
-    if (!CUTILS && o.other_target == 0x7fffffff && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target)
-        o.other_target = tot;  // cutils never fills the map (treeobs.cpp:72)
-}
-
 // per-team node table in LDS: CAP entries per field
 enum { F_START = 0, F_TOT, F_VIS, F_END, F_FLAGS, F_UNUS, F_PAR, F_HGT, F_INCL, F_OA, F_PC, F_OT, F_SAME, F_OPP, F_MALF,
        F_READY, F_MS /* u64: two ints per node */, F_WORDS = 18 };
+
+// The feature block of ONE visited cell of a branch walk (treeobs.cpp:322-465 / observations.py:296-371) is split in
+// two event handlers that merge straight into the node's accumulators (sc = the team's node table) with LDS atomics:
+// min / sum / max are associative and tot_dist grows along a walk, so "first hit" = minimum.
+//
+// occupant of the cell (treeobs.cpp:322-357 / observations.py:296-327)
+template <bool CUTILS, int CAP>
+__device__ __forceinline__ void occ_event(const ObsCtx &X, int *sc, int node, uint32_t sl, uint32_t d, int tot) {
+    const int ag = X.slot_agent[sl];
+    if (ag < 0) return;
+    atomicMin(&sc[F_OA * CAP + node], tot);
+    const int mf = CUTILS ? (X.a_malf[ag] != 0) : (int)X.a_malf[ag];
+    if (mf > 0) atomicMax(&sc[F_MALF * CAP + node], mf);
+    const int rd = X.slot_ready[sl];
+    const int radd = rd > 0 ? (CUTILS ? rd - 1 : rd) : 0;  // cutils starts the count at 0 (treeobs.cpp:82-91)
+    if (radd) atomicAdd(&sc[F_READY * CAP + node], radd);
+    if (X.a_dir[ag] == d) {
+        atomicAdd(&sc[F_SAME * CAP + node], 1);
+        const double sp = CUTILS ? (double)(float)X.a_speed[ag] : X.a_speed[ag];
+        unsigned long long *ms = reinterpret_cast<unsigned long long *>(sc + F_MS * CAP);
+        if (sp < 1.0) atomicMin(&ms[node], (unsigned long long)__double_as_longlong(sp));  // positive doubles order like their bits
+    } else {
+        atomicAdd(&sc[F_OPP * CAP + node], 1);
+    }
+}
+
+// potential conflict at predicted time pt (treeobs.cpp:378-465 / observations.py:329-367); the caller checked
+// Tn > 0, tot < Tn and pt < Tn
+template <bool CUTILS, int CAP, bool ITL>
+__device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
+    const int key = key_of(X, cell);
+    const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+    if (hi <= lo) return;
+    const uint32_t bits = nibble(X.cellw[cell] & 0xFFFFu, d);
+    const uint32_t tlast = (uint32_t)(X.Tn - 1);
+    const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
+    // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
+    // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
+    // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
+    bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
+    auto test_item = [&](uint32_t it) {
+        const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
+        if (th < t1 || tl > t2) return;
+        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+        const int a = IT_AGENT(it);
+        // direction the conflict test uses: upstream takes the one at the matching time step
+        // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
+        // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is not on
+        // this waypoint at t0
+        uint32_t cd = IT_DIR(it);
+        if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
+        const bool oth = a != handle;
+        const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
+        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
+        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+    };
+    if (ITL) {
+        int e = lo;
+        for (; e < hi; e++) {  // until-the-end items
+            const uint32_t it = X.items_lds[e];
+            if (!IT_TOEND(it)) break;
+            test_item(it);
+        }
+        if (e < hi) {
+            const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
+            int l = e, h = hi;  // first item with t_lo >= tmin
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (IT_TLO(X.items_lds[mid]) < tmin) l = mid + 1; else h = mid;
+            }
+            for (; l < hi; l++) {
+                const uint32_t it = X.items_lds[l];
+                if (IT_TLO(it) > t2) break;
+                test_item(it);
+            }
+        }
+    } else {
+        // large maps: the lists stay unsorted in HBM scratch (sorting them costs more than scanning them);
+        // four independent loads in flight, most items fall out at the interval test
+        for (int e0 = lo; e0 < hi; e0 += 4) {
+            uint32_t itv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) itv[q] = X.items_glb[min(e0 + q, hi - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e0 + q < hi) test_item(itv[q]);
+        }
+    }
+    const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
+    if (hit) atomicMin(&sc[F_PC * CAP + node], tot);
+}
+
+// append e to a work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
+__device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool want, uint2 e) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return true;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (want && idx < cap) list[idx] = e;
+    return !want || idx < cap;
+}
+
+#ifdef FL_OBS_TIMING
+#define TREE_STAMP(X, k) do { __syncthreads(); if (threadIdx.x == 0 && (X).dbg) (X).dbg[(X).dbg_base + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define TREE_STAMP(X, k) do {} while (0)
+#endif
 
 __device__ __forceinline__ void team_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -227,8 +244,7 @@ __device__ __forceinline__ void team_sync() {
 // Pass B of the trees.  team_prepare: per team (= one agent's tree), inclusive prefix of the nodes' visit counts and
 // reset of the node accumulators.  wg_pass_b: the visited cells of ALL nodes of ALL trees of the batch are split evenly
 // over ALL lanes of the workgroup; every lane walks its slice (binary search for its first team / node, a cheap skip
-// to the slice start, then ONE lock-step loop over its cells) and merges partial results into the nodes' accumulators
-// with LDS atomics (min / sum / max are associative).
+// to the slice start, then ONE lock-step loop over its cells).
 template <int TEAM, int CAP>
 __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int *scr) {
     unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
@@ -252,9 +268,15 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 }
 
 // team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1)
+//
+// Step 1: every lane walks its slice of the visited cells and only CLASSIFIES them (three cheap tests per cell: has the
+// cell an occupant; does the time-bucket mask of its key say that somebody is predicted there around the queried time;
+// is it somebody's target) -- cells that need work go to two LDS work lists.  Step 2: the lists are processed one entry
+// per lane, so the expensive handlers run on densely packed wavefronts instead of as rare side branches of a lock-step loop.
 template <bool CUTILS, int CAP, bool ITL>
 __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int n_teams, int *scr0, int team_words,
                                           const int *team_meta) {
+    if (tid == 0) { X.wl_cnt[0] = 0; X.wl_cnt[1] = 0; }
     __syncthreads();
     const int lane = tid & 63;
     // inclusive prefix over the teams' cell counts, one team per lane (n_teams <= 64); every wavefront computes it
@@ -310,29 +332,12 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             tot = vs[F_TOT * CAP + node] + k;
             left = nvis - k;
         }
-        WalkDyn w;
-        w.other_agent = w.pot_conflict = w.other_target = 0x7fffffff;
-        w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
-        w.min_speed = 1.0;
-        auto flush = [&]() {
-            int *sc = scr0 + team * team_words;
-            unsigned long long *ms = reinterpret_cast<unsigned long long *>(sc + F_MS * CAP);
-            if (w.other_agent != 0x7fffffff) atomicMin(&sc[F_OA * CAP + node], w.other_agent);
-            if (w.pot_conflict != 0x7fffffff) atomicMin(&sc[F_PC * CAP + node], w.pot_conflict);
-            if (w.other_target != 0x7fffffff) atomicMin(&sc[F_OT * CAP + node], w.other_target);
-            if (w.same_dir) atomicAdd(&sc[F_SAME * CAP + node], w.same_dir);
-            if (w.opp_dir) atomicAdd(&sc[F_OPP * CAP + node], w.opp_dir);
-            if (w.malfunctioning) atomicMax(&sc[F_MALF * CAP + node], w.malfunctioning);
-            if (w.ready) atomicAdd(&sc[F_READY * CAP + node], w.ready);
-            if (w.min_speed < 1.0) atomicMin(&ms[node], (unsigned long long)__double_as_longlong(w.min_speed));
-        };
+#ifdef FL_OBS_TIMING
+        if (X.dbg && lane == 0) atomicMax((unsigned long long *)&X.dbg[12], (unsigned long long)((long long)wall_clock64() - dbg_t1));
+#endif
         // ONE loop over the lane's cells (lanes of a wave run it in lock step); node / team boundaries are side branches
         for (; pos < end; pos++) {
             if (left == 0) {
-                flush();
-                w.other_agent = w.pot_conflict = w.other_target = 0x7fffffff;
-                w.same_dir = w.opp_dir = w.malfunctioning = w.ready = 0;
-                w.min_speed = 1.0;
                 while (true) {  // next node with cells, possibly in the next team(s)
                     node++;
                     if (node >= nn) {
@@ -358,7 +363,35 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 left = vs[F_VIS * CAP + node];
             }
             const uint32_t cw = X.cellw[cell];
-            walk_cell<CUTILS, ITL>(X, handle, target, tpc_f, tpc_d, cell, dd, cw, tot, w);
+            int *sc = scr0 + team * team_words;
+            const uint2 entry = make_uint2(((uint32_t)cell << 2) | dd | ((uint32_t)team << 24), (uint32_t)tot | ((uint32_t)node << 24));
+            // occupant?
+            const uint32_t sl = cw >> 16;
+            const bool occ = sl != 0xFFFFu;
+            if (!wl_push(X.wl_occ, X.wl_occ_cap, &X.wl_cnt[0], occ, entry)) occ_event<CUTILS, CAP>(X, sc, node, sl, dd, tot);
+            // somebody predicted on this key around the queried time?
+            bool cand = false;
+            int pt = 0;
+            if (X.Tn > 0 && tot < X.Tn) {
+                pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
+                if (pt < X.Tn) {
+                    const int key = key_of(X, cell);
+                    if (X.tmask) {
+                        const int b1 = min(max(pt - 1, 0) >> X.tshift, 63), b2 = min(min(pt + 1, X.Tn - 1) >> X.tshift, 63);
+                        const unsigned long long qm = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
+                        cand = (X.tmask[key] & qm) != 0ull;
+                    } else {
+                        cand = X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);
+                    }
+                }
+            }
+            if (X.tmask) {
+                if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], cand, entry)) conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
+            } else if (cand) {
+                conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
+            }
+            // somebody's target (upstream only: cutils never fills the map, treeobs.cpp:72)
+            if (!CUTILS && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target) atomicMin(&sc[F_OT * CAP + node], tot);
             left--;
             if (left > 0) {  // keep walking along the only transition
                 dd = first_dir(nibble(cw & 0xFFFFu, dd));
@@ -366,16 +399,35 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 tot += 1;
             }
         }
-        flush();
     }
 #ifdef FL_OBS_TIMING
-    if (X.dbg) {
+    if (X.dbg && lane == 0) {
         const long long dbg_t2 = (long long)wall_clock64();
+        if (tid == 0) X.dbg[X.dbg_base + 13] = dbg_t1;  // wavefront 0 enters the slice code
         // slowest lane of the env: slice-loop ticks << 40 | cells per lane << 20 | cells skipped
-        atomicMax((unsigned long long *)&X.dbg[6], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)q << 20) | (unsigned long long)dbg_skip);
-        atomicMax((unsigned long long *)&X.dbg[7], (unsigned long long)total);
+        atomicMax((unsigned long long *)&X.dbg[14], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)q << 20) | (unsigned long long)dbg_skip);
+        atomicMax((unsigned long long *)&X.dbg[15], (unsigned long long)total);
     }
 #endif
+    __syncthreads();
+    TREE_STAMP(X, 11);
+    // step 2: one list entry per lane
+    const int n_occ = min(X.wl_cnt[0], X.wl_occ_cap), n_cf = min(X.wl_cnt[1], X.wl_cf_cap);
+#ifdef FL_OBS_TIMING
+    if (X.dbg && tid == 0) { X.dbg[X.dbg_base + 9] = n_occ; X.dbg[X.dbg_base + 10] = n_cf; }
+#endif
+    for (int e = tid; e < n_occ; e += nt) {
+        const uint2 w = X.wl_occ[e];
+        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
+        occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), X.cellw[cell] >> 16, w.x & 3u, (int)(w.y & 0xFFFFFFu));
+    }
+    for (int e = tid; e < n_cf; e += nt) {
+        const uint2 w = X.wl_cf[e];
+        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24), tot = (int)(w.y & 0xFFFFFFu);
+        const int handle = team_meta[128 + team];
+        const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
+        conflict_event<CUTILS, CAP, ITL>(X, scr0 + team * team_words, (int)(w.y >> 24), handle, cell, w.x & 3u, tot, pt);
+    }
     __syncthreads();
 }
 
@@ -474,6 +526,8 @@ struct ObsArgs {
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
     int scr_words;   // ints of tree scratch per wavefront
     int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
+    int wl_bytes;      // LDS bytes of the sort staging area / pass B work lists
+    int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
 };
 
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
@@ -551,12 +605,14 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             }
         }
         team_sync();
+        TREE_STAMP(X, 6);
         {
             const int tot_cells = team_prepare<TEAM, CAP>(have, tl, have ? NN : 1, scr);
             const int team_id = wave * TPW + team;
             if (tl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? NN : 1; team_meta[128 + team_id] = have ? i : -1; }
         }
         wg_pass_b<false, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr0, F_WORDS * CAP, team_meta);
+        TREE_STAMP(X, 7);
         if (have) {  // rows
             const int *vs = scr;
             for (int idx = 1 + tl; idx < NN; idx += TEAM) {
@@ -668,12 +724,14 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                 }
             }
             team_sync();
+            TREE_STAMP(X, 6);
             {
                 const int tot_cells = team_prepare<32, CAP>(have, gl, have ? node_base : 1, scr);
                 const int team_id = wave * 2 + grp;
                 if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; }
             }
             wg_pass_b<true, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, F_WORDS * CAP, team_meta);
+            TREE_STAMP(X, 7);
             if (have) {  // rows: lane gl writes node gl + 1
                 const int *vs = scr;
                 for (int idx = gl + 1; idx < N; idx += 32) {
@@ -696,6 +754,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                     }
                 }
             }
+            TREE_STAMP(X, 8);
             // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
             // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
             {
@@ -765,18 +824,19 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
-    uint32_t *stage_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
+    uint32_t *stage_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // sort staging, then the pass B work lists
+    unsigned long long *tmask = (unsigned long long *)carve(CSR_LDS && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
     uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);  // next-hop tables of the env's targets when they fit
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
 #ifdef FL_OBS_TIMING
-#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 32 + (STAGE == 2 ? 16 : 0) + (k)] = (long long)wall_clock64(); } while (0)
 #else
 #define OBS_STAMP(k) do {} while (0)
 #endif
 #ifdef FL_OBS_TIMING
-    if (tid == 0) { P.dbg[(size_t)b * 8 + 6] = 0; P.dbg[(size_t)b * 8 + 7] = 0; }
+    if (tid == 0 && STAGE != 2) { P.dbg[(size_t)b * 32 + 12] = 0; P.dbg[(size_t)b * 32 + 14] = 0; P.dbg[(size_t)b * 32 + 15] = 0; }
 #endif
     OBS_STAMP(0);
 
@@ -844,13 +904,20 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.A = A; X.H = H; X.W = W; X.HW = HW;
     X.keycell = keycell; X.cellw = cellw; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
     X.seg = d.seg + (size_t)b * HW * 4;
-    X.dbg = P.dbg ? P.dbg + (size_t)b * 8 : nullptr;
+    X.dbg = P.dbg ? P.dbg + (size_t)b * 32 : nullptr;
+    X.dbg_base = STAGE == 2 ? 16 : 0;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
+    // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
+    X.tmask = (CSR_LDS && P.use_tmask && X.Tn > 0) ? tmask : nullptr;
+    X.wl_occ = reinterpret_cast<uint2 *>(stage_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / 24 : P.wl_bytes / 8;  // a third of the entries
+    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = P.wl_bytes / 8 - X.wl_occ_cap;
+    X.wl_cnt = misc + 8;
+    X.tshift = X.Tn <= 64 ? 0 : 2;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
     OBS_STAMP(1);
@@ -995,13 +1062,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
     if (X.Tn > 0) {
         for (int k = tid; k <= K; k += nt) csr[k] = 0;
+        if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
         // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
         // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
         // walkers would share four
-        const int nw_walk = max(4, (A + 63) / 64);
+        const int nw_walk = min(nt >> 6, max(4, (A + 63) / 64));
         for (int i = lane * nw_walk + wave; wave < nw_walk && i < A; i += 64 * nw_walk) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
@@ -1013,18 +1081,18 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
             auto walk = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
                 if (cell == target) {  // holds at its position (DONE agents): predictions.cpp:208-214
-                    atomicAdd(&csr[key_of(X, cell)], 1);
                     path[n++] = ((uint32_t)cell << 2) | dd;
                     return;
                 }
                 // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265):
                 // the choice at every (cell, orientation) is static, see k_nexthop.  cutils walks max_depth iterations and
-                // stops where nothing is strictly closer (i.e. on the target); upstream stops at the target.
+                // stops where nothing is strictly closer (i.e. on the target); upstream stops at the target.  This is a
+                // chain of dependent loads on one lane: the loop only chases and records, everything else happens afterwards
+                // with one lane per waypoint.
                 int depth = 0;
                 bool none = false;
                 while (depth < pred_depth && (CUTILS || cell != target)) {
                     const uint32_t hop = ((uint32_t)nh_u[cell] >> (3u * dd)) & 7u;
-                    if (n <= horizon) atomicAdd(&csr[key_of(X, cell)], 1);
                     path[n++] = ((uint32_t)cell << 2) | dd;
                     depth++;
                     if (hop == 4u) { none = true; break; }
@@ -1032,21 +1100,26 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     dd = hop;
                 }
                 // the final waypoint (predictions.cpp:131-133; rail_env_shortest_paths.py:266-267 when not cut by max_depth)
-                if (!none && (CUTILS || depth < pred_depth)) {
-                    if (n <= horizon) atomicAdd(&csr[key_of(X, cell)], 1);
-                    path[n++] = ((uint32_t)cell << 2) | dd;
-                }
+                if (!none && (CUTILS || depth < pred_depth)) path[n++] = ((uint32_t)cell << 2) | dd;
                 // upstream: a None path (nothing strictly closer) means the agent stands still (predictions.py:150-156);
-                // that only happens on the first step, where exactly one waypoint was counted
+                // that only happens on the first step, where exactly one waypoint was recorded
             };
             // two call sites so that each keeps a static address space (LDS copy vs HBM table)
             if (nh_in_lds) walk(nh_lds + (size_t)a_tslot[i] * HW);
             else walk(gnh + (size_t)a_tslot[i] * HW);
+            if (n == 0) path[n++] = ((uint32_t)a_vpos[i] << 2) | a_dir[i];  // zero-step predictor: prediction[0] is the current position (predictions.py:126)
             int lp = n - 1;
             if (lp > horizon) lp = horizon;
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
             a_n[i] = (uint16_t)n;
+        }
+        __syncthreads();
+        // waypoints per key: only those that can be occupied within the horizon enter the index
+        for (int i = wave; i < A; i += (nt >> 6)) {
+            const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const int lp = a_lp[i];
+            for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
         }
         } else {
             // second stage: the upstream path is the prefix of the cutils path kept by stage 1 -- it stops at the target
@@ -1116,7 +1189,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     span = tpc;
                 }
                 const bool to_end = k == lp || tlo + span - 1 >= tlast;
-                const int slot = atomicAdd(&csr[key_of(X, (int)(w >> 2))], 1);
+                const int key = key_of(X, (int)(w >> 2));
+                if (X.tmask) {  // time buckets this item covers
+                    const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
+                    atomicOr(&tmask[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
+                }
+                const int slot = atomicAdd(&csr[key], 1);
                 stage_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                   ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
             }
@@ -1198,7 +1276,7 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.cell_stage = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * 8 * 8) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * 32 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);
     (void)s;
     return FL_OK;
@@ -1210,17 +1288,18 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words, int nh_words) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words, int nh_words, int wl_bytes, bool use_tmask) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
            al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
-           2 * al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)nh_words * 2) + 64;
+           al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
+           al((size_t)nh_words * 2) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, bool &csr_lds, int &nt, size_t &lds) {
+static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, int &wl_bytes, int &use_tmask, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
     // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
@@ -1232,8 +1311,13 @@ static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, bool &
         if ((c < 2 && !csr_lds) || (c % 2 == 0 && nh_fit == 0)) continue;
         for (int k = 0; k < 3; k++) {
             nt = nts[k];
-            lds = obs_lds_bytes(d, csr_lds, nt, scr_words, nh_words);
-            if (lds <= 160 * 1024) return true;
+            // the staging area must hold every LDS-resident item; as a pure work list a third of it still does
+            for (wl_bytes = OBS_ITEMS_LDS_CAP * 4; wl_bytes >= (csr_lds ? OBS_ITEMS_LDS_CAP * 4 : OBS_ITEMS_LDS_CAP * 4 / 3); wl_bytes /= 3) {
+                for (use_tmask = csr_lds ? 1 : 0; use_tmask >= 0; use_tmask--) {  // the masks are the first thing to go
+                    lds = obs_lds_bytes(d, csr_lds, nt, scr_words, nh_words, wl_bytes, use_tmask != 0);
+                    if (lds <= 160 * 1024) return true;
+                }
+            }
         }
     }
     return false;
@@ -1255,7 +1339,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.scr_words = 2 * F_WORDS * 32;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
@@ -1274,7 +1358,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     const int w_c = 2 * F_WORDS * 32, w_t = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
     P.scr_words = w_c > w_t ? w_c : w_t;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
 }
 
@@ -1288,6 +1372,6 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.n_tree_nodes = n;
     P.scr_words = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }

@@ -40,7 +40,7 @@ def test_cutils_other_sizes_match_oracle(max_nodes, pred_depth):
     env.check()
 
 
-@pytest.mark.parametrize("depth,pred", [(1, 30), (2, -1), (3, -1), (3, 10), (2, 500)])
+@pytest.mark.parametrize("depth,pred", [(1, 30), (2, -1), (3, -1), (3, 10), (2, 500), (2, 0), (2, 1)])
 def test_upstream_tree_variants_match_oracle(depth, pred):
     from oracle import orc
     from flatland_marl_amd import synth
