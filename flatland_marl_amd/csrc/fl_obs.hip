@@ -921,12 +921,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
     OBS_STAMP(1);
-    // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows
-    if (CUTILS && STAGE != 2) {
+    // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  ONE wavefront does all of it (wave-level
+    // synchronisation only), so it can run beside the path walkers of phase 2, which occupy the first wavefronts.
+    auto phase1 = [&]() __attribute__((always_inline)) {
         // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
         // its exits leads to an empty cell or to a free, not yet deadlocked agent (or it has no exit at all);
         // every other active agent becomes (and stays) deadlocked.  Equivalent to the reference's DFS + _fix_deps.
-        for (int i = tid; i < A; i += nt) {
+        for (int i = lane; i < A; i += 64) {
             bool fr = false;
             if (is_on_map(a_state[i]) && !a_dead[i]) {
                 const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
@@ -942,9 +943,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             a_free[i] = fr;
         }
-        __syncthreads();
-        while (true) {
-            for (int i = tid; i < A; i += nt) {
+        team_sync();
+        while (true) {  // monotone: any evaluation order reaches the same least fixpoint
+            bool changed = false;
+            for (int i = lane; i < A; i += 64) {
                 if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
                     const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
                     bool fr = false;
@@ -954,17 +956,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
                         if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
                     }
-                    if (fr) { a_free[i] = 1; misc[0] = 1; }
+                    if (fr) { a_free[i] = 1; changed = true; }
                 }
             }
-            __syncthreads();
-            const int ch = misc[0];
-            __syncthreads();
-            if (!ch) break;
-            if (tid == 0) misc[0] = 0;
-            __syncthreads();
+            team_sync();
+            if (!__any(changed)) break;
         }
-        for (int i = tid; i < A; i += nt) {
+        for (int i = lane; i < A; i += 64) {
             const int g = b * A + i;
             const uint32_t state = a_state[i];
             if (is_on_map(state) && !a_dead[i] && !a_free[i]) {
@@ -1056,8 +1054,18 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             o[n++] = (float)malf01 / 10;
             o[n++] = isinf(init_dist) ? 8.0f : init_dist / max_dist_target;
         }
-    }
+    };
 
+    // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
+    // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
+    // walkers would share four
+    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min(nt >> 6, max(4, (A + 63) / 64)) : 0;
+    const bool do_p1 = CUTILS && STAGE != 2;
+    const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
+    if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
+        if (wave == 0) phase1();
+        __syncthreads();
+    }
     OBS_STAMP(2);
     // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
     if (X.Tn > 0) {
@@ -1066,10 +1074,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
-        // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
-        // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
-        // walkers would share four
-        const int nw_walk = min(nt >> 6, max(4, (A + 63) / 64));
+        if (do_p1 && p1_beside_walk && wave == nw_walk) phase1();
         for (int i = lane * nw_walk + wave; wave < nw_walk && i < A; i += 64 * nw_walk) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
