@@ -124,6 +124,13 @@ __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t 
 enum { F_START = 0, F_TOT, F_VIS, F_END, F_FLAGS, F_UNUS, F_PAR, F_HGT, F_INCL, F_OA, F_PC, F_OT, F_SAME, F_OPP, F_MALF,
        F_READY, F_MS /* u64: two ints per node */, F_WORDS = 18 };
 
+// LDS words of the trees' node tables: one slot per team that can hold an agent plus one dummy slot that the idle teams share
+__host__ __device__ inline int obs_scr_words(int nwaves, int A, int tw_c, int tw_t, int tpw_t) {
+    const int n_c = 2 * nwaves <= A ? 2 * nwaves : A + 1, n_t = tpw_t * nwaves <= A ? tpw_t * nwaves : A + 1;
+    const int w_c = n_c * tw_c, w_t = n_t * tw_t;
+    return w_c > w_t ? w_c : w_t;
+}
+
 // The feature block of ONE visited cell of a branch walk (treeobs.cpp:322-465 / observations.py:296-371) is split in
 // two event handlers that merge straight into the node's accumulators (sc = the team's node table) with LDS atomics:
 // min / sum / max are associative and tot_dist grows along a walk, so "first hit" = minimum.
@@ -524,7 +531,7 @@ struct ObsArgs {
     double *tree_out;
     int n_tree_nodes;
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
-    int scr_words;   // ints of tree scratch per wavefront
+    int tw_c, tw_t, tpw_t;  // node-table words per team of the cutils / upstream builder (0 = builder not in this launch), upstream teams per wavefront
     int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
     int wl_bytes;      // LDS bytes of the sort staging area / pass B work lists
     int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
@@ -538,14 +545,15 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
                                               int nwaves, int *wave_scr0, int *team_meta, const uint32_t *cellw,
                                               const int *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
                                               const double *a_speed, const int *a_tslot) {
-    int *wave_scr_base = wave_scr0 + wave * (64 / TEAM) * (F_WORDS * CAP);
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
     const int A = X.A, W = X.W, HW = X.HW;
     const int team = lane / TEAM, tl = lane % TEAM;
     const int D = P.max_depth, NN = P.n_tree_nodes;
     int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
     { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
-    int *scr = wave_scr_base + team * (F_WORDS * CAP);
+    // team t's node table is slot t; teams that can never hold an agent share the dummy slot behind the real ones
+    const int n_slots = min(nwaves * TPW, A);
+    int *scr = wave_scr0 + min(wave * TPW + team, n_slots) * (F_WORDS * CAP);
     for (int base = 0; base < A; base += nwaves * TPW) {
         const int i = base + wave * TPW + team;
         const bool have = i < A;
@@ -643,7 +651,8 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
         constexpr int CAP = 32;
         const int grp = lane >> 5, gl = lane & 31;
         const int N = P.max_nodes;
-        int *scr = wave_scr + (wave * 2 + grp) * (F_WORDS * CAP);  // team t at wave_scr + t * team_words (wg_pass_b)
+        // team t's node table is slot t (wg_pass_b); teams that can never hold an agent share the dummy slot behind the real ones
+        int *scr = wave_scr + min(wave * 2 + grp, min(nwaves * 2, A)) * (F_WORDS * CAP);
         for (int base = 0; base < A; base += nwaves * 2) {
             const int i = base + wave * 2 + grp;
             const bool have = i < A;
@@ -820,7 +829,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
     int *team_meta = (int *)carve(192 * 4);
-    int *wave_scr = (int *)carve((size_t)(nt >> 6) * P.scr_words * 4);  // per-wave tree scratch (node tables)
+    int *wave_scr = (int *)carve((size_t)obs_scr_words(nt >> 6, A, P.tw_c, P.tw_t, P.tpw_t) * 4);  // the teams' node tables
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
@@ -1293,18 +1302,18 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, int scr_words, int nh_words, int wl_bytes, bool use_tmask) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
-           al((size_t)(nt / 64) * scr_words * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
+           al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
            al((size_t)nh_words * 2) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, int &wl_bytes, int &use_tmask, bool &csr_lds, int &nt, size_t &lds) {
+static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
     // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
@@ -1319,7 +1328,7 @@ static bool obs_pick_config(const FlDev &d, int scr_words, int &nh_words, int &w
             // the staging area must hold every LDS-resident item; as a pure work list a third of it still does
             for (wl_bytes = OBS_ITEMS_LDS_CAP * 4; wl_bytes >= (csr_lds ? OBS_ITEMS_LDS_CAP * 4 : OBS_ITEMS_LDS_CAP * 4 / 3); wl_bytes /= 3) {
                 for (use_tmask = csr_lds ? 1 : 0; use_tmask >= 0; use_tmask--) {  // the masks are the first thing to go
-                    lds = obs_lds_bytes(d, csr_lds, nt, scr_words, nh_words, wl_bytes, use_tmask != 0);
+                    lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0);
                     if (lds <= 160 * 1024) return true;
                 }
             }
@@ -1342,9 +1351,9 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
-    P.scr_words = 2 * F_WORDS * 32;
+    P.tw_c = F_WORDS * 32;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
@@ -1360,10 +1369,11 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;
-    const int w_c = 2 * F_WORDS * 32, w_t = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
-    P.scr_words = w_c > w_t ? w_c : w_t;
+    P.tw_c = F_WORDS * 32;
+    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
+    P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
 }
 
@@ -1375,8 +1385,9 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     int n = 0, p = 1;
     for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
     P.n_tree_nodes = n;
-    P.scr_words = max_depth <= 2 ? 2 * F_WORDS * 32 : F_WORDS * 88;
+    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
+    P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P.scr_words, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
