@@ -10,12 +10,10 @@
 struct FlObsScratch {
     int pred_cap;      // waypoints kept per agent (pred_depth + 2)
     uint32_t *path;    // [B][A][pred_cap] predicted waypoints: cell << 2 | dir
-    int *path_len;     // [B][A]
     int keys;          // prediction keys per env: (W - 1) * W + H (key = col * W + row, tool.h:391-398)
     int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index (used when they do not fit LDS)
-    long long *dbg;    // [B][8] phase clocks of diagnostic builds (-DFL_OBS_TIMING)
-    uint32_t *cell_items;
-    uint32_t *cell_stage;  // [B][A * pred_cap] unsorted staging copy of the items  // [B][A * pred_cap] agent << 20 | t_lo << 11 | t_hi << 2 | dir
+    long long *dbg;    // [B][32] phase clocks of diagnostic builds (-DFL_OBS_TIMING)
+    uint32_t *cell_items;  // [B][A * pred_cap] prediction items (IT_* packing, fl_obs.hip) when they do not fit LDS
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);

@@ -36,7 +36,6 @@
 #define IT_THI(it, tlast) ((((it) >> 10) & 1u) ? (uint32_t)(tlast) : IT_TLO(it) + (((it) >> 6) & 15u))
 #define IT_TLO(it) (((it) >> 11) & 511u)
 #define IT_TOEND(it) (((it) >> 10) & 1u)
-#define IT_SORTKEY(it) (IT_TOEND(it) ? 0u : IT_TLO(it) + 1u)
 #define IT_AGENT(it) ((int)((it) >> 20))
 
 // ---------------------------------------------------------------------------------------------- context
@@ -167,8 +166,7 @@ __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int nod
     const uint32_t tlast = (uint32_t)(X.Tn - 1);
     const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
     // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
-    // (self included) satisfy the conflict condition.  The key's items are sorted: first the ones that
-    // last until the end of the horizon, then by t_lo; an interval is at most 16 steps long.
+    // (self included) satisfy the conflict condition
     bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
     auto test_item = [&](uint32_t it) {
         const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
@@ -186,38 +184,21 @@ __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int nod
         other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
         cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
     };
-    if (ITL) {
-        int e = lo;
-        for (; e < hi; e++) {  // until-the-end items
-            const uint32_t it = X.items_lds[e];
-            if (!IT_TOEND(it)) break;
-            test_item(it);
-        }
-        if (e < hi) {
-            const uint32_t tmin = t1 > 15u ? t1 - 15u : 0u;
-            int l = e, h = hi;  // first item with t_lo >= tmin
-            while (l < h) {
-                const int mid = (l + h) >> 1;
-                if (IT_TLO(X.items_lds[mid]) < tmin) l = mid + 1; else h = mid;
-            }
-            for (; l < hi; l++) {
-                const uint32_t it = X.items_lds[l];
-                if (IT_TLO(it) > t2) break;
-                test_item(it);
-            }
-        }
-    } else {
-        // large maps: the lists stay unsorted in HBM scratch (sorting them costs more than scanning them);
-        // four independent loads in flight, most items fall out at the interval test
+    // the key's list is short and unsorted: scan it with four independent loads in flight, most items fall out at the
+    // interval test (sorting the lists costs more than it saves)
+    auto scan = [&](const uint32_t *items) __attribute__((always_inline)) {
         for (int e0 = lo; e0 < hi; e0 += 4) {
             uint32_t itv[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) itv[q] = X.items_glb[min(e0 + q, hi - 1)];
+            for (int q = 0; q < 4; q++) itv[q] = items[min(e0 + q, hi - 1)];
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (e0 + q < hi) test_item(itv[q]);
         }
-    }
+    };
+    // two call sites so that each keeps a static address space (LDS vs HBM scratch)
+    if (ITL) scan(X.items_lds);
+    else scan(X.items_glb);
     const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
     if (hit) atomicMin(&sc[F_PC * CAP + node], tot);
 }
@@ -533,7 +514,7 @@ struct ObsArgs {
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
     int tw_c, tw_t, tpw_t;  // node-table words per team of the cutils / upstream builder (0 = builder not in this launch), upstream teams per wavefront
     int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
-    int wl_bytes;      // LDS bytes of the sort staging area / pass B work lists
+    int wl_bytes;      // LDS bytes of the pass B work lists
     int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
 };
 
@@ -833,7 +814,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
-    uint32_t *stage_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // sort staging, then the pass B work lists
+    uint32_t *wl_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // pass B work lists
     unsigned long long *tmask = (unsigned long long *)carve(CSR_LDS && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
     uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);  // next-hop tables of the env's targets when they fit
 
@@ -923,7 +904,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (CSR_LDS && P.use_tmask && X.Tn > 0) ? tmask : nullptr;
-    X.wl_occ = reinterpret_cast<uint2 *>(stage_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / 24 : P.wl_bytes / 8;  // a third of the entries
+    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / 24 : P.wl_bytes / 8;  // a third of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = P.wl_bytes / 8 - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
     X.tshift = X.Tn <= 64 ? 0 : 2;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
@@ -1181,10 +1162,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
         }
         __syncthreads();
-        uint32_t *stage_items = S.cell_stage + (size_t)b * A * S.pred_cap;
         const bool fit = CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP;
-        if (fit) { csr_items = items_lds; X.items_lds = items_lds; stage_items = stage_lds; }
-        else stage_items = csr_items;  // no sort: the fill writes the final (unsorted) lists
+        if (fit) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
         for (int i = wave; i < A; i += (nt >> 6)) {
@@ -1209,35 +1188,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     atomicOr(&tmask[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
                 }
                 const int slot = atomicAdd(&csr[key], 1);
-                stage_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                   ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
-            }
-        }
-        __syncthreads();
-        // sort every key's list (until-the-end items first, then by t_lo, ties by staging position): every item -- one
-        // lane each, all in parallel -- finds its rank inside its key's staged list and moves to its final place
-        for (int i = wave; fit && i < A; i += (nt >> 6)) {
-            const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
-            const int lp = a_lp[i];
-            for (int k = lane; k <= lp; k += 64) {
-                const int key = key_of(X, (int)(path[k] >> 2));
-                const int hi = csr[key], lo = key > 0 ? csr[key - 1] : 0;
-                // my staged item is the one of agent i whose waypoint is k: (agent, t_lo) is unique inside a list
-                const uint32_t my_tlo = CUTILS ? (k == 0 ? 0u : (uint32_t)((k - 1) * a_tpc[i] + 1)) : (uint32_t)(k * a_tpc[i]);
-                uint32_t mine = 0, my_sk = 0;
-                for (int y = lo; y < hi; y++) {
-                    const uint32_t it = stage_items[y];
-                    if (IT_AGENT(it) == i && IT_TLO(it) == my_tlo) { mine = it; my_sk = IT_SORTKEY(it); break; }
-                }
-                int rank = 0;
-                bool seen = false;
-                for (int y = lo; y < hi; y++) {
-                    const uint32_t it = stage_items[y];
-                    const uint32_t sy = IT_SORTKEY(it);
-                    if (it == mine) { seen = true; continue; }
-                    rank += (sy < my_sk) || (sy == my_sk && !seen);
-                }
-                csr_items[lo + rank] = mine;
             }
         }
         __syncthreads();
@@ -1286,8 +1238,6 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.path = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
-    if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
-    o.cell_stage = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 32 * 8) != hipSuccess) return FL_ERR_HIP;
@@ -1325,8 +1275,7 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
         if ((c < 2 && !csr_lds) || (c % 2 == 0 && nh_fit == 0)) continue;
         for (int k = 0; k < 3; k++) {
             nt = nts[k];
-            // the staging area must hold every LDS-resident item; as a pure work list a third of it still does
-            for (wl_bytes = OBS_ITEMS_LDS_CAP * 4; wl_bytes >= (csr_lds ? OBS_ITEMS_LDS_CAP * 4 : OBS_ITEMS_LDS_CAP * 4 / 3); wl_bytes /= 3) {
+            for (wl_bytes = 24 * 1024; wl_bytes >= 8 * 1024; wl_bytes /= 3) {  // a third of the work-list space still does
                 for (use_tmask = csr_lds ? 1 : 0; use_tmask >= 0; use_tmask--) {  // the masks are the first thing to go
                     lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0);
                     if (lds <= 160 * 1024) return true;
