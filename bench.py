@@ -62,12 +62,16 @@ def main():
     ap.add_argument("--tree-pred", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=1, help="bracket the kernels of every n-th timed step with HIP events")
+    ap.add_argument("--lib", default=None, help="diagnostic: load this build of the C-ABI library instead of the in-tree one (A/B runs)")
     ap.add_argument("--separate", action="store_true", help="launch the two observation builders separately")
     ap.add_argument("--dm-rebuild", action="store_true", help="also rebuild all distance maps every step (BASELINE configs[4])")
     args = ap.parse_args()
 
     import torch
     from flatland_marl_amd import dist_utils, workload as wl
+    from flatland_marl_amd import hip_backend
+    if args.lib:
+        hip_backend.LIB_PATH = os.path.abspath(args.lib)
     from flatland_marl_amd.hip_backend import BatchedRailEnv
 
     rank, world, local_rank = dist_utils.init_from_env()
