@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--tree-depth", type=int, default=2)
     ap.add_argument("--tree-pred", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-every", type=int, default=1, help="bracket the kernels of every n-th timed step with HIP events")
+    ap.add_argument("--event-every", type=int, default=8, help="bracket the kernels of every n-th timed step with HIP events")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the C-ABI library instead of the in-tree one (A/B runs)")
     ap.add_argument("--separate", action="store_true", help="launch the two observation builders separately")
     ap.add_argument("--dm-rebuild", action="store_true", help="also rebuild all distance maps every step (BASELINE configs[4])")
