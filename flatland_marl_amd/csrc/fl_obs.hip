@@ -25,6 +25,8 @@
 #define OBS_WAVES (OBS_NT / 64)
 #define OBS_GROUPS (OBS_WAVES * 2)   // cutils trees: two agents per wavefront, 32 lanes each (max_nodes <= 33)
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
+#define CF_CHUNK 8                   // items of a key's list scanned per conflict work-list entry
+#define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
@@ -62,7 +64,7 @@ struct ObsCtx {
     // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
-    int *wl_cnt;                  // LDS [2] entries pushed to wl_occ / wl_cf
+    int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
     const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
     int tshift;
     long long *dbg;               // diagnostic builds
@@ -156,33 +158,28 @@ __device__ __forceinline__ void occ_event(const ObsCtx &X, int *sc, int node, ui
 }
 
 // potential conflict at predicted time pt (treeobs.cpp:378-465 / observations.py:329-367); the caller checked
-// Tn > 0, tot < Tn and pt < Tn
-template <bool CUTILS, int CAP, bool ITL>
-__device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
-    const int key = key_of(X, cell);
-    const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
-    if (hi <= lo) return;
+// Tn > 0, tot < Tn and pt < Tn.  conflict_flags scans items [lo, hi) of the cell's key and returns six bits:
+// bit k (k = 0, 1, 2 for the times pt, pt - 1, pt + 1): some OTHER agent is predicted there then; bit 3 + k: some agent
+// predicted there then (self included) satisfies the conflict condition.  Flags of sub-ranges of a list simply OR.
+template <bool CUTILS, bool ITL>
+__device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, int cell, uint32_t d, int pt, int lo, int hi) {
     const uint32_t bits = nibble(X.cellw[cell] & 0xFFFFu, d);
     const uint32_t tlast = (uint32_t)(X.Tn - 1);
     const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
-    // is some OTHER agent predicted on this key at t0 / t1 / t2, and does any agent predicted there
-    // (self included) satisfy the conflict condition
-    bool other0 = false, other1 = false, other2 = false, cond0 = false, cond1 = false, cond2 = false;
+    uint32_t flags = 0;
     auto test_item = [&](uint32_t it) {
         const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
         if (th < t1 || tl > t2) return;
-        const bool in0 = tl <= t0 && t0 <= th, in1 = tl <= t1 && t1 <= th, in2 = tl <= t2 && t2 <= th;
+        const uint32_t in = (uint32_t)(tl <= t0 && t0 <= th) | ((uint32_t)(tl <= t1 && t1 <= th) << 1) | ((uint32_t)(tl <= t2 && t2 <= th) << 2);
         const int a = IT_AGENT(it);
         // direction the conflict test uses: upstream takes the one at the matching time step
         // (observations.py:351-363); cutils indexes predicted_dir with predicted_time in all three branches
         // (treeobs.cpp:429-433, 449-453), i.e. the neighbouring waypoint's direction when the agent is not on
         // this waypoint at t0
         uint32_t cd = IT_DIR(it);
-        if (CUTILS && !in0) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
-        const bool oth = a != handle;
+        if (CUTILS && !(in & 1u)) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
         const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
-        other0 |= in0 & oth; other1 |= in1 & oth; other2 |= in2 & oth;
-        cond0 |= in0 & cnd; cond1 |= in1 & cnd; cond2 |= in2 & cnd;
+        flags |= (a != handle ? in : 0u) | (cnd ? in << 3 : 0u);
     };
     // the key's list is short and unsorted: scan it with four independent loads in flight, most items fall out at the
     // interval test (sorting the lists costs more than it saves)
@@ -199,12 +196,21 @@ __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int nod
     // two call sites so that each keeps a static address space (LDS vs HBM scratch)
     if (ITL) scan(X.items_lds);
     else scan(X.items_glb);
-    const bool hit = other0 ? cond0 : (other1 ? cond1 : (other2 ? cond2 : false));
-    if (hit) atomicMin(&sc[F_PC * CAP + node], tot);
+    return flags;
+}
+// the other-agent test takes the first time (pt, pt - 1, pt + 1) at which somebody else is predicted on the cell
+__device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f >> 3) & 1u : ((f & 2u) ? (f >> 4) & 1u : ((f & 4u) ? (f >> 5) & 1u : false)); }
+
+template <bool CUTILS, int CAP, bool ITL>
+__device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
+    const int key = key_of(X, cell);
+    const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+    if (hi <= lo) return;
+    if (conflict_hit(conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi))) atomicMin(&sc[F_PC * CAP + node], tot);
 }
 
 // append e to a work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
-__device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool want, uint2 e) {
+__device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool want, uint2 e, int *idx_out = nullptr) {
     const unsigned long long m = __ballot(want);
     if (m == 0) return true;
     const int lane = (int)__lane_id();
@@ -214,6 +220,7 @@ __device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool w
     base = __shfl(base, leader);
     const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
     if (want && idx < cap) list[idx] = e;
+    if (idx_out) *idx_out = idx;
     return !want || idx < cap;
 }
 
@@ -264,7 +271,7 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 template <bool CUTILS, int CAP, bool ITL>
 __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int n_teams, int *scr0, int team_words,
                                           const int *team_meta) {
-    if (tid == 0) { X.wl_cnt[0] = 0; X.wl_cnt[1] = 0; }
+    if (tid == 0) { X.wl_cnt[0] = 0; X.wl_cnt[1] = 0; X.wl_cnt[2] = 0; }
     __syncthreads();
     const int lane = tid & 63;
     // inclusive prefix over the teams' cell counts, one team per lane (n_teams <= 64); every wavefront computes it
@@ -374,7 +381,30 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 }
             }
             if (X.tmask) {
-                if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], cand, entry)) conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
+                // One entry per CF_CHUNK items of the key's list, so that no lane of step 2 scans a long list alone.  The
+                // first entry: tot | chunks << 9 | flags << 15 (accumulated in step 2) | node << 24; the others:
+                // chunk | index of the first entry << 6 | CF_MORE.
+                int nch = 0, lo_k = 0, hi_k = 0;
+                if (cand) {
+                    const int key = key_of(X, cell);
+                    hi_k = X.csr_end[key]; lo_k = key > 0 ? X.csr_end[key - 1] : 0;
+                    nch = (hi_k - lo_k + CF_CHUNK - 1) / CF_CHUNK;
+                }
+                int first_idx = -1;
+                const bool chunked = cand && nch <= 63;
+                const bool ok = wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], chunked,
+                                        make_uint2(entry.x, (uint32_t)tot | ((uint32_t)nch << 9) | ((uint32_t)node << 24)), &first_idx);
+                if (cand && (!chunked || !ok)) {
+                    conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);  // list full (or an absurdly long key list)
+                } else {
+                    for (int j = 1; __any(chunked && j < nch); j++) {
+                        const bool want = chunked && j < nch;
+                        if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], want, make_uint2(entry.x, (uint32_t)j | ((uint32_t)first_idx << 6) | CF_MORE), nullptr)) {
+                            const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, dd, pt, lo_k + j * CF_CHUNK, min(hi_k, lo_k + (j + 1) * CF_CHUNK));
+                            if (f) atomicOr(&X.wl_cf[first_idx].y, f << 15);
+                        }
+                    }
+                }
             } else if (cand) {
                 conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
             }
@@ -409,12 +439,34 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), X.cellw[cell] >> 16, w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
+    bool any_multi = false;
     for (int e = tid; e < n_cf; e += nt) {
         const uint2 w = X.wl_cf[e];
-        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24), tot = (int)(w.y & 0xFFFFFFu);
+        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
+        const bool more = (w.y & CF_MORE) != 0;
+        const int first = more ? (int)((w.y >> 6) & 0xFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
+        const uint32_t fy = more ? X.wl_cf[first].y : w.y;
+        const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
         const int handle = team_meta[128 + team];
         const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
-        conflict_event<CUTILS, CAP, ITL>(X, scr0 + team * team_words, (int)(w.y >> 24), handle, cell, w.x & 3u, tot, pt);
+        const int key = key_of(X, cell);
+        const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+        const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, min(hi, lo + (chunk + 1) * CF_CHUNK));
+        if (nch == 1) {
+            if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(fy >> 24)], tot);
+        } else {
+            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
+            any_multi = true;
+        }
+    }
+    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
+    __syncthreads();
+    if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
+        for (int e = tid; e < n_cf; e += nt) {
+            const uint2 w = X.wl_cf[e];
+            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
+            if (conflict_hit((w.y >> 15) & 63u)) atomicMin(&(scr0 + (int)(w.x >> 24) * team_words)[F_PC * CAP + (int)(w.y >> 24)], (int)(w.y & 511u));
+        }
     }
     __syncthreads();
 }
