@@ -381,30 +381,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 }
             }
             if (X.tmask) {
-                // One entry per CF_CHUNK items of the key's list, so that no lane of step 2 scans a long list alone.  The
-                // first entry: tot | chunks << 9 | flags << 15 (accumulated in step 2) | node << 24; the others:
-                // chunk | index of the first entry << 6 | CF_MORE.
-                int nch = 0, lo_k = 0, hi_k = 0;
-                if (cand) {
-                    const int key = key_of(X, cell);
-                    hi_k = X.csr_end[key]; lo_k = key > 0 ? X.csr_end[key - 1] : 0;
-                    nch = (hi_k - lo_k + CF_CHUNK - 1) / CF_CHUNK;
-                }
-                int first_idx = -1;
-                const bool chunked = cand && nch <= 63;
-                const bool ok = wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], chunked,
-                                        make_uint2(entry.x, (uint32_t)tot | ((uint32_t)nch << 9) | ((uint32_t)node << 24)), &first_idx);
-                if (cand && (!chunked || !ok)) {
-                    conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);  // list full (or an absurdly long key list)
-                } else {
-                    for (int j = 1; __any(chunked && j < nch); j++) {
-                        const bool want = chunked && j < nch;
-                        if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], want, make_uint2(entry.x, (uint32_t)j | ((uint32_t)first_idx << 6) | CF_MORE), nullptr)) {
-                            const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, dd, pt, lo_k + j * CF_CHUNK, min(hi_k, lo_k + (j + 1) * CF_CHUNK));
-                            if (f) atomicOr(&X.wl_cf[first_idx].y, f << 15);
-                        }
-                    }
-                }
+                if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], cand, make_uint2(entry.x, (uint32_t)tot | ((uint32_t)node << 24))))
+                    conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);  // list full
             } else if (cand) {
                 conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
             }
@@ -439,8 +417,36 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), X.cellw[cell] >> 16, w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
+    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes
+    // further entries for the rest of its list.  First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) |
+    // node << 24; the others: chunk | index of the first entry << 6 | CF_MORE.
+    for (int e0 = 0; e0 < n_cf; e0 += nt) {
+        const int e = e0 + tid;
+        int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0;
+        uint2 w = make_uint2(0u, 0u);
+        if (e < n_cf) {
+            w = X.wl_cf[e];
+            cell = (int)((w.x & 0xFFFFFFu) >> 2);
+            const int key = key_of(X, cell);
+            hi = X.csr_end[key]; lo = key > 0 ? X.csr_end[key - 1] : 0;
+            nch = min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63);  // an absurdly long list: the last chunk takes the rest
+            X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
+        }
+        for (int j = 1; __any(j < nch); j++) {
+            if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
+                // list full: this chunk is scanned here
+                handle = team_meta[128 + (int)(w.x >> 24)];
+                tot = (int)(w.y & 511u);
+                const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
+                const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + j * CF_CHUNK, j == 62 ? hi : min(hi, lo + (j + 1) * CF_CHUNK));
+                if (f) atomicOr(&X.wl_cf[e].y, f << 15);
+            }
+        }
+    }
+    __syncthreads();
+    const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
     bool any_multi = false;
-    for (int e = tid; e < n_cf; e += nt) {
+    for (int e = tid; e < n_cf2; e += nt) {
         const uint2 w = X.wl_cf[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         const bool more = (w.y & CF_MORE) != 0;
@@ -451,7 +457,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
         const int key = key_of(X, cell);
         const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
-        const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, min(hi, lo + (chunk + 1) * CF_CHUNK));
+        const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
         if (nch == 1) {
             if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(fy >> 24)], tot);
         } else {
@@ -462,7 +468,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
     __syncthreads();
     if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
-        for (int e = tid; e < n_cf; e += nt) {
+        for (int e = tid; e < n_cf2; e += nt) {
             const uint2 w = X.wl_cf[e];
             if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) atomicMin(&(scr0 + (int)(w.x >> 24) * team_words)[F_PC * CAP + (int)(w.y >> 24)], (int)(w.y & 511u));
