@@ -262,7 +262,7 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
     return run_base;
 }
 
-// team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1)
+// team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1), [192,256) BFS levels (cutils)
 //
 // Step 1: every lane walks its slice of the visited cells and only CLASSIFIES them (three cheap tests per cell: has the
 // cell an occupant; does the time-bucket mask of its key say that somebody is predicted there around the queried time;
@@ -677,14 +677,103 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
     }
 }
 
+// Pass A of one flatland_cutils tree (treeobs.cpp:154-256): root row, node topology level by level (BFS), one team of 32
+// lanes per agent, two teams per wavefront.  Only wave-level synchronisation, so a wavefront can run it whenever the
+// rail bitmap and the agent snapshot are in LDS (the workgroup overlaps it with the path walk of phase 2).
+__device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
+                                              int gl, int *scr, const uint32_t *cellw, const int *a_vpos, const int *a_pos,
+                                              const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
+                                              const int *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
+    constexpr int CAP = 32;
+    const int A = X.A, W = X.W, HW = X.HW, N = P.max_nodes;
+    const int ia = have ? i : 0;
+    const int g = b * A + ia;
+    const int vpos = a_vpos[ia];
+    const uint32_t dir = a_dir[ia];
+    const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+    uint32_t orientation = dir;
+    if (__popc(rbits) == 1) orientation = first_dir(rbits);
+    float *F = P.forest + (size_t)g * N * 12;
+    if (have && gl == 0) {  // root (treeobs.cpp:171-186)
+        const uint32_t state = a_state[i];
+        double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint16_t dv = FL_INF16;
+        if (state == ST_DONE) dv = 0;
+        else dv = X.dm[((size_t)a_tslot[i] * HW + (is_off_map(state) ? d.init_pos[g] : a_pos[i])) * 4 +
+                       (is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
+        root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
+        root[9] = (double)((d.malf[g] >> 16) != 0);
+        root[10] = (double)(float)a_speed[i];
+        scale_and_store(root, max_dist, A, F);
+    }
+    scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
+    scr[F_PAR * CAP + gl] = -2;
+    // level 1: three cells from the root (treeobs.cpp:205-222)
+    int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
+    if (gl < 3) {
+        c_act = gl - 1;
+        const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
+        if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
+    }
+    int n_cur = 3, node_base = 1, levels = 0;
+    if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
+    while (true) {  // pass A
+        levels++;
+        const bool active = have && node_base < N && n_cur > 0;
+        if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
+        const int m = active ? min(n_cur, N - node_base) : 0;
+        const bool mine = gl < m;
+        const int idx_node = node_base + gl;
+        int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
+        bool explored = false;
+        if (mine) {
+            if (c_state >= 0) {
+                const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                explored = true;
+                ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
+                ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
+                scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
+                scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
+                scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
+            }
+            scr[F_PAR * CAP + idx_node] = c_parent;
+        }
+        const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
+        const int n_next = 3 * __popc(exp_mask);
+        if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
+            const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
+            scr[F_HGT * CAP + idx_node] = (fc << 2) | (c_act + 1);
+        }
+        // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
+        const int src_rank = gl / 3, which = gl - 3 * src_rank;
+        const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
+        const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
+        const int s_tot = __shfl(ch_tot, src, 32);
+        if (active) {
+            const int parent_base = node_base;
+            node_base += m;
+            n_cur = n_next;
+            if (gl < n_next) {
+                c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
+                c_parent = parent_base + src;
+                c_tot = s_tot;
+                c_act = which - 1;
+            }
+        }
+    }
+    team_sync();
+    node_base_out = node_base;
+    levels_out = levels;
+}
+
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
 template <bool ITL>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                              int nwaves, int *wave_scr, int *team_meta, const uint32_t *cellw,
                                              const int *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const int *a_tslot,
-                                             float max_dist) {
-    const int A = X.A, W = X.W, HW = X.HW;
+                                             float max_dist, bool hoisted) {
+    const int A = X.A;
     {
         // two agents per wavefront, a team of 32 lanes each
         constexpr int CAP = 32;
@@ -704,74 +793,13 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
             if (__popc(rbits) == 1) orientation = first_dir(rbits);
             float *F = P.forest + (size_t)g * N * 12;
             int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
-            if (have && gl == 0) {  // root (treeobs.cpp:171-186)
-                const uint32_t state = a_state[i];
-                double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                uint16_t dv = FL_INF16;
-                if (state == ST_DONE) dv = 0;
-                else dv = X.dm[((size_t)a_tslot[i] * HW + (is_off_map(state) ? d.init_pos[g] : a_pos[i])) * 4 +
-                               (is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
-                root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
-                root[9] = (double)((d.malf[g] >> 16) != 0);
-                root[10] = (double)(float)a_speed[i];
-                scale_and_store(root, max_dist, A, F);
+            int node_base, levels;
+            if (hoisted && base == 0) {  // pass A of the first round already ran beside the path walk
+                node_base = team_meta[64 + wave * 2 + grp];
+                levels = team_meta[192 + wave * 2 + grp];
+            } else {
+                cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, node_base, levels);
             }
-            scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
-            scr[F_PAR * CAP + gl] = -2;
-            // level 1: three cells from the root (treeobs.cpp:205-222)
-            int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
-            if (gl < 3) {
-                c_act = gl - 1;
-                const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
-                if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
-            }
-            int n_cur = 3, node_base = 1, levels = 0;
-            if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
-            while (true) {  // pass A
-                levels++;
-                const bool active = have && node_base < N && n_cur > 0;
-                if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
-                const int m = active ? min(n_cur, N - node_base) : 0;
-                const bool mine = gl < m;
-                const int idx_node = node_base + gl;
-                int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
-                bool explored = false;
-                if (mine) {
-                    if (c_state >= 0) {
-                        const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
-                        explored = true;
-                        ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
-                        ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
-                        scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
-                        scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
-                        scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
-                    }
-                    scr[F_PAR * CAP + idx_node] = c_parent;
-                }
-                const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
-                const int n_next = 3 * __popc(exp_mask);
-                if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
-                    const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
-                    scr[F_HGT * CAP + idx_node] = (fc << 2) | (c_act + 1);
-                }
-                // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
-                const int src_rank = gl / 3, which = gl - 3 * src_rank;
-                const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
-                const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
-                const int s_tot = __shfl(ch_tot, src, 32);
-                if (active) {
-                    const int parent_base = node_base;
-                    node_base += m;
-                    n_cur = n_next;
-                    if (gl < n_next) {
-                        c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
-                        c_parent = parent_base + src;
-                        c_tot = s_tot;
-                        c_act = which - 1;
-                    }
-                }
-            }
-            team_sync();
             TREE_STAMP(X, 6);
             {
                 const int tot_cells = team_prepare<32, CAP>(have, gl, have ? node_base : 1, scr);
@@ -867,7 +895,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint8_t *a_free = (uint8_t *)carve((size_t)A);
     uint8_t *a_dead = (uint8_t *)carve((size_t)A);
     int *misc = (int *)carve(64 * 4);
-    int *team_meta = (int *)carve(192 * 4);
+    int *team_meta = (int *)carve(256 * 4);
     int *wave_scr = (int *)carve((size_t)obs_scr_words(nt >> 6, A, P.tw_c, P.tw_t, P.tpw_t) * 4);  // the teams' node tables
     int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
@@ -1122,8 +1150,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
-        if (do_p1 && p1_beside_walk && wave == nw_walk) phase1();
-        for (int i = lane * nw_walk + wave; wave < nw_walk && i < A; i += 64 * nw_walk) {
+        // Roles of the wavefronts while the paths are walked (a chain of dependent loads on one lane per agent): the LAST
+        // nw_walk wavefronts walk, the one before them does phase 1, and every wavefront (the walkers afterwards) runs pass A
+        // of the first round of cutils trees for its two agents -- none of that needs the prediction index.
+        const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
+        if (do_p1 && p1_beside_walk && wave == w_first - 1) phase1();
+        for (int i = lane * nw_walk + wsel; wsel >= 0 && i < A; i += 64 * nw_walk) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
             uint32_t dd = a_dir[i];
@@ -1166,6 +1198,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (lp < 0) lp = 0;
             a_lp[i] = (uint16_t)lp;
             a_n[i] = (uint16_t)n;
+        }
+        if (CUTILS) {
+            const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
+            int node_base, levels;
+            cutils_pass_a(X, d, P, b, team_id, team_id < A, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32), cellw,
+                          a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T, node_base, levels);
+            if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
         }
         __syncthreads();
         // waypoints per key: only those that can be occupied within the horizon enter the index
@@ -1261,8 +1300,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (CUTILS) {
-        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
-        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
     } else if (P.max_depth <= 2) {
         if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
         else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
@@ -1314,7 +1353,7 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs 
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(192 * 4) +
+    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
            al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
            al((size_t)nh_words * 2) + 64;
