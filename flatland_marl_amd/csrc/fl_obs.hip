@@ -1155,6 +1155,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // of the first round of cutils trees for its two agents -- none of that needs the prediction index.
         const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
         if (do_p1 && p1_beside_walk && wave == w_first - 1) phase1();
+        if (wsel >= 0) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path: its wavefronts issue first
         for (int i = lane * nw_walk + wsel; wsel >= 0 && i < A; i += 64 * nw_walk) {
             uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             int cell = a_vpos[i];
@@ -1199,6 +1200,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             a_lp[i] = (uint16_t)lp;
             a_n[i] = (uint16_t)n;
         }
+        if (wsel >= 0) __builtin_amdgcn_s_setprio(0);
         if (CUTILS) {
             const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
             int node_base, levels;
