@@ -286,6 +286,36 @@ int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, in
     return FL_OK;
 }
 
+int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
+                uint8_t *dones_dev, uint8_t *done_all_dev, int flags, int max_nodes, int pred_depth, float *attr_dev,
+                float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
+                uint8_t *valid_actions_dev, double *props_dev, int tree_max_depth, int tree_pred_depth, double *tree_out_dev) {
+    NEED_COMMIT(h);
+    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 1) { set_err("fl_step_obs: bad step argument"); return FL_ERR_ARG; }
+    if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED || tree_max_depth < 0 ||
+        tree_max_depth > 3 || (tree_max_depth > 0 && (tree_pred_depth < 0 || tree_pred_depth > pred_depth || !tree_out_dev))) {
+        set_err("fl_step_obs: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [0,3], 0 <= tree_pred_depth <= pred_depth",
+                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev) {
+        set_err("fl_step_obs: null output buffer");
+        return FL_ERR_ARG;
+    }
+    // Two launches back to back on the handle's stream.  A single fused launch was measured and is slower: the step wants
+    // one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
+    fl_launch_step(h->d, actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags, h->stream);
+    HIPCHK(hipGetLastError());
+    const int rc = tree_max_depth > 0 ? fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
+                                                           edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth,
+                                                           tree_out_dev, h->stream)
+                                      : fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
+                                                             edge_order_dev, valid_actions_dev, props_dev, h->stream);
+    if (rc != FL_OK) { set_err("fl_step_obs: launch failed"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_check(fl_batch *h) {
     NEED_COMMIT(h);
     std::vector<int> err(h->B);

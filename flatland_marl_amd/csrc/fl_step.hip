@@ -17,381 +17,15 @@
 #include "fl_internal.h"
 #include "../../include/flatland_hip.h"
 
-#define MT_N 624
-#define MT_M 397
-
-struct StepLds {
-    uint32_t *mtl;    // [624] raw MT state
-    uint32_t *words;  // [wcap] tempered stream words, ring indexed by stream offset
-    int *hkey, *hocc, *hwin, *hcnt, *hblk;  // [S] cell hash table
-    int *a_cur, *a_nxt;                     // [Apad] node ids (cell, or HW + i for the private off-map node)
-    int *misc;                              // [16] block-wide scalars
-};
-enum { M_FIRST = 0, M_CHANGED = 1, M_NOTDONE = 2, M_ERR = 3, M_TWISTS = 4 };
-
-// one MT19937 block regeneration in LDS: three passes, each lane reads its inputs, barrier, writes.
-__device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid, int nt) {
-    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
-    // pass bounds: [0,227) uses old[i+397]; [227,454) and [454,624) use new[i-227]; i = 623 wraps to new[0]
-    const int lo[3] = {0, MT_N - MT_M, 2 * (MT_N - MT_M)};
-    const int hi[3] = {MT_N - MT_M, 2 * (MT_N - MT_M), MT_N};
-#pragma unroll
-    for (int ph = 0; ph < 3; ph++) {
-        for (int base = lo[ph]; base < hi[ph]; base += nt) {
-            const int i = base + tid;
-            uint32_t v = 0;
-            const bool on = i < hi[ph];
-            if (on) {
-                const uint32_t y = (mt[i] & UPPER) | (mt[(i + 1 == MT_N) ? 0 : i + 1] & LOWER);
-                const uint32_t src = (i < MT_N - MT_M) ? mt[i + MT_M] : mt[i - (MT_N - MT_M)];
-                v = src ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
-            }
-            __syncthreads();
-            if (on) mt[i] = v;
-            __syncthreads();
-        }
-    }
-}
-
-// Make tempered stream words [gen_hi, want) available in the ring.  Stream offset k lives at absolute
-// position pos0 + k; block number = position / 624 (block 0 = the state as loaded).  Block-uniform.
-__device__ __forceinline__ void rng_ensure(StepLds &L, int pos0, int &gen_hi, int want, int &twists, int wmask, int tid,
-                                           int nt) {
-    while (gen_hi < want) {
-        const int p = pos0 + gen_hi;
-        const int blk = p / MT_N;
-        if (blk > twists) {
-            mt_twist_lds(L.mtl, tid, nt);
-            twists++;
-        }
-        const int blk_end_k = (blk + 1) * MT_N - pos0;  // first stream offset of the next block
-        const int upto = min(want, blk_end_k);
-        for (int k = gen_hi + tid; k < upto; k += nt) L.words[k & wmask] = mt_temper(L.mtl[(pos0 + k) - blk * MT_N]);
-        gen_hi = upto;
-        __syncthreads();
-    }
-}
-
-// transition_utils.check_action (step_utils/transition_utils.py:6-44); tv: -1 = None, 0, 1
-__device__ __forceinline__ uint32_t check_action(uint32_t cell, uint32_t action, uint32_t dir, int &tv) {
-    const uint32_t bits = nibble(cell, dir);
-    const int k = __popc(bits);
-    uint32_t nd = dir;
-    tv = -1;
-    if (action == ACT_LEFT) { nd = dir + 3u; if (k <= 1) tv = 0; }
-    else if (action == ACT_RIGHT) { nd = dir + 1u; if (k <= 1) tv = 0; }
-    nd &= 3u;
-    if (action == ACT_FORWARD && k == 1) { nd = first_dir(bits); tv = 1; }
-    return nd;
-}
-
-// check_valid_action / check_action_on_agent (transition_utils.py:47-82)
-__device__ __forceinline__ bool check_valid_action(const uint16_t *grid, int H, int W, int cellid, uint32_t cell,
-                                                   uint32_t action, uint32_t dir) {
-    int tv;
-    const uint32_t nd = check_action(cell, action, dir, tv);
-    const int r = cellid / W, c = cellid - r * W;
-    const int nr = r + (nd == 0 ? -1 : nd == 2 ? 1 : 0), nc = c + (nd == 1 ? 1 : nd == 3 ? -1 : 0);
-    const bool cell_ok = nr >= 0 && nc >= 0 && nr < H && nc < W && grid[nr * W + nc] != 0;
-    if (tv < 0) tv = (int)tbit(cell, dir, nd);
-    return cell_ok && tv;
-}
-
-__device__ __forceinline__ int hash_slot(int cell, int smask, int sshift) {
-    return (int)(((uint32_t)cell * 2654435761u) >> sshift) & smask;
-}
-__device__ __forceinline__ int hash_insert(int *hkey, int cell, int smask, int sshift) {
-    int s = hash_slot(cell, smask, sshift);
-    while (true) {
-        const int old = atomicCAS(&hkey[s], -1, cell);
-        if (old == -1 || old == cell) return s;
-        s = (s + 1) & smask;
-    }
-}
+#include "fl_step_body.h"
 
 template <bool SYNTH>
 __global__ __launch_bounds__(1024) void k_step(FlDev d, const uint8_t *__restrict__ actions, uint32_t seed,
                                                uint32_t stream_base, int synth_kind, int32_t *__restrict__ rewards,
                                                uint8_t *__restrict__ dones, uint8_t *__restrict__ done_all_out,
                                                int auto_reset, int wcap, int S, int sshift) {
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int A = d.A, H = d.H, W = d.W, HW = H * W;
-    const int i = tid;
-    const bool act = i < A;
-    const int g = b * A + (act ? i : 0);
-
     extern __shared__ uint32_t lds_raw[];
-    StepLds L;
-    L.mtl = lds_raw;
-    L.words = L.mtl + MT_N;
-    L.hkey = (int *)(L.words + wcap);
-    L.hocc = L.hkey + S;
-    L.hwin = L.hocc + S;
-    L.hcnt = L.hwin + S;
-    L.hblk = L.hcnt + S;
-    L.a_cur = L.hblk + S;
-    L.a_nxt = L.a_cur + nt;
-    L.misc = L.a_nxt + nt;
-    const int wmask = wcap - 1, smask = S - 1;
-
-    int t = d.t[b];
-    int was_done = d.done_all[b];
-    const bool filter_required = (auto_reset & 2) != 0;  // flags: bit 0 auto reset, bit 1 eval_env.parse_actions filter
-    auto_reset &= 1;
-    if (was_done && !auto_reset) {  // rail_env.py:508-509
-        if (tid == 0) atomicCAS(&d.err[b], 0, FL_ERR_EPISODE_DONE);
-        return;
-    }
-    const uint16_t *grid = d.grid + (size_t)b * HW;
-    const int T = d.T[b];
-    const int pos0 = d.mt_pos[b];
-    const uint64_t thr = d.malf_thr[b];
-    const int mmin = d.malf_min[b], mmax = d.malf_max[b];
-
-    // ---- per-agent state into registers
-    int pos = -1, old_pos = -1, arrival = -1, init_pos = 0, target = 0, earliest = 0, latest = 0;
-    uint32_t malfw = 0, pk = 0, spk = 0;
-    if (act) {
-        init_pos = d.init_pos[g]; target = d.target[g]; earliest = d.earliest[g]; latest = d.latest[g];
-        spk = d.spk[g];
-        pos = d.pos[g]; old_pos = d.old_pos[g]; arrival = d.arrival[g]; malfw = d.malf[g]; pk = d.pk[g];
-    }
-    const uint32_t init_dir = SPK_INIT_DIR(spk), max_count = SPK_MAX_COUNT(spk);
-    uint32_t dir = PK_DIR(pk), old_dir = PK_OLD_DIR(pk), state = PK_STATE(pk), prev = PK_PREV(pk), saved = PK_SAVED(pk),
-             scount = PK_SCOUNT(pk), sig = PK_SIGMALF(pk), dead = PK_DEADLOCK(pk), done = PK_DONE(pk);
-    uint32_t malf = malfw & 0xFFFFu, nmalf = malfw >> 16;
-    if (was_done) {  // auto-reset (fresh agents): agent_utils.py:90-105 + arrival_time = None
-        pos = -1; old_pos = -1; arrival = -1; dir = init_dir; old_dir = 4; state = ST_WAITING; prev = 7; saved = 0;
-        scount = 0; sig = 0; dead = 0; done = 0; malf = 0; nmalf = 0;
-        t = 0;
-    }
-    t += 1;  // rail_env.py:505
-
-    // ---- LDS init
-    for (int k = tid; k < MT_N; k += nt) L.mtl[k] = d.mt[(size_t)b * MT_N + k];
-    for (int k = tid; k < S; k += nt) { L.hkey[k] = -1; L.hocc[k] = -1; L.hwin[k] = 0x7fffffff; L.hcnt[k] = 0; L.hblk[k] = 0; }
-    if (tid < 16) L.misc[tid] = 0;
-    if (tid == 0) L.misc[M_FIRST] = 0x7fffffff;
-    __syncthreads();
-
-    // ---- malfunction draws (handle order, one shared stream): speculative + serial replay of firing agents
-    int gen_hi = 0, twists = 0, extra = 0, start = 0;
-    uint32_t n_broken = 0;
-    const uint32_t rng_span = (uint32_t)(mmax - mmin);  // randint(min, max+1): rng = hi-1-lo
-    uint32_t rmask = rng_span;
-    rmask |= rmask >> 1; rmask |= rmask >> 2; rmask |= rmask >> 4; rmask |= rmask >> 8; rmask |= rmask >> 16;
-    rng_ensure(L, pos0, gen_hi, 2 * A, twists, wmask, tid, nt);
-    while (true) {
-        bool fire = false;
-        if (act && i >= start) {
-            const uint32_t wa = L.words[(2 * i + extra) & wmask], wb = L.words[(2 * i + extra + 1) & wmask];
-            const uint64_t u53 = ((uint64_t)(wa >> 5) << 26) | (uint64_t)(wb >> 6);  // RandomState.rand() * 2^53
-            fire = u53 < thr;
-            if (fire) atomicMin(&L.misc[M_FIRST], i);
-        }
-        __syncthreads();
-        const int first = L.misc[M_FIRST];
-        __syncthreads();
-        if (first == 0x7fffffff) break;
-        if (tid == 0) L.misc[M_FIRST] = 0x7fffffff;
-        // randint(min, max+1) + 1 for agent `first` (masked rejection on 32-bit words); evaluated by every lane
-        int k = 2 * first + extra + 2;
-        uint32_t v = 0;
-        if (rng_span != 0) {
-            do {
-                rng_ensure(L, pos0, gen_hi, k + 1, twists, wmask, tid, nt);
-                v = L.words[k & wmask] & rmask;
-                k++;
-            } while (v > rng_span);
-        }
-        if (i == first) n_broken = (uint32_t)mmin + v + 1u;
-        extra = k - (2 * first + 2);
-        start = first + 1;
-        rng_ensure(L, pos0, gen_hi, 2 * A + extra, twists, wmask, tid, nt);
-        __syncthreads();
-    }
-    const int consumed = 2 * A + extra;
-    // malfunction_handler.py:35-42
-    if (act && malf == 0) {
-        malf = n_broken;
-        if (n_broken > 0) nmalf += 1;
-    }
-
-    // ---- phase 1 (rail_env.py:519-569)
-    uint32_t a = ACT_NOTHING, np_dir = dir;
-    int np_pos = pos;
-    if (act) {
-        old_pos = pos; old_dir = dir;  // :521-522
-        uint32_t raw = SYNTH ? synth_action(seed, stream_base + (uint32_t)b, (uint32_t)(t - 1), (uint32_t)i, synth_kind)
-                             : (uint32_t)actions[g];
-        // eval_env.parse_actions (solution/eval_env.py:33-39): an agent without action_required (rail_env.py:243-258) is
-        // dropped from the action dict
-        if (filter_required && !(state == ST_READY || (is_on_map(state) && scount == 0))) raw = 255u;
-        if (raw > 4u) raw = ACT_NOTHING;  // absent (255) or illegal -> DO_NOTHING (:527, action_preprocessing.py:7-11)
-        a = raw;
-        if (a == ACT_NOTHING) a = (state == ST_MOVING) ? (uint32_t)ACT_FORWARD : (saved ? saved : (uint32_t)ACT_NOTHING);
-        if (state == ST_WAITING) a = ACT_NOTHING;
-        const int pc = pos < 0 ? init_pos : pos;
-        const uint32_t pd = pos < 0 ? init_dir : dir;
-        const uint32_t cell = grid[pc];
-        if ((a == ACT_LEFT || a == ACT_RIGHT) && !check_valid_action(grid, H, W, pc, cell, a, pd)) a = ACT_FORWARD;
-        if (a >= ACT_LEFT && a <= ACT_RIGHT && !check_valid_action(grid, H, W, pc, cell, a, pd)) a = ACT_STOP;
-        if (a >= ACT_LEFT && a <= ACT_RIGHT && !saved && state != ST_DONE) saved = a;  // action_saver.py:16-24
-        const bool upd = (scount == max_count) && !(malf > 0) && a != ACT_STOP;        // :535-537
-        if (pos < 0 && state != ST_DONE && a == ACT_STOP) saved = 0;                   // :540-542
-        if (state == ST_DONE) { np_pos = pos; np_dir = dir; }
-        else if (pos < 0 && saved) { np_pos = init_pos; np_dir = init_dir; }
-        else if (saved && upd) {
-            int tv;
-            np_dir = check_action(cell, saved, dir, tv);  // env_utils.py:26-43 (validity not re-checked)
-            np_pos = step_cell(pos, np_dir, W);
-            a = saved;
-        } else { np_pos = pos; np_dir = dir; }
-    }
-
-    // ---- MotionCheck on cells (agent_chains.py), see header comment of resolve step below
-    // nodes: on-map cell id, or HW + i for the private virtual node of an off-map agent (:28-32)
-    const int cur_node = act ? (pos < 0 ? HW + i : pos) : -1;
-    const int nxt_node = act ? (np_pos < 0 ? HW + i : np_pos) : -1;
-    L.a_cur[tid] = cur_node;
-    L.a_nxt[tid] = nxt_node;
-    int slot_c = -1, slot_n = -1;
-    if (act) {
-        if (pos >= 0) {
-            slot_c = hash_insert(L.hkey, pos, smask, sshift);
-            atomicMax(&L.hocc[slot_c], i);  // node attribute "agent" = last agent added on that cell (:34)
-            atomicAdd(&L.hcnt[slot_c], 1);
-        }
-        if (np_pos >= 0) slot_n = (np_pos == pos) ? slot_c : hash_insert(L.hkey, np_pos, smask, sshift);
-    }
-    __syncthreads();
-    const int key = (act && pos >= 0) ? L.hocc[slot_c] : i;
-    const bool wants_move = act && nxt_node != cur_node;
-    if (wants_move) atomicMin(&L.hwin[slot_n], key);  // lowest handle wins a contended cell (:190-195)
-    __syncthreads();
-    bool blocked = false;
-    if (act) {
-        if (!wants_move) blocked = true;  // self loop = stopped (:59-63)
-        else {
-            const int occ = L.hocc[slot_n];
-            if (occ >= 0) {  // 2-cycle swap (:107-117)
-                if (L.hcnt[slot_n] == 1) blocked = (L.a_nxt[occ] == cur_node);
-                else
-                    for (int j = 0; j < A; j++)
-                        if (L.a_cur[j] == nxt_node && L.a_nxt[j] == cur_node) blocked = true;
-            }
-            if (L.hwin[slot_n] != key) blocked = true;  // lost the contention (:176-202)
-        }
-        if (blocked && slot_c >= 0) L.hblk[slot_c] = 1;
-    }
-    __syncthreads();
-    // predecessors of a blocked cell are blocked, transitively (:125-149, :65-105); agents sharing a cell share its flag
-    while (true) {
-        if (act && !blocked) {
-            if ((slot_n >= 0 && L.hblk[slot_n]) || (slot_c >= 0 && L.hblk[slot_c])) {
-                blocked = true;
-                if (slot_c >= 0) L.hblk[slot_c] = 1;
-                L.misc[M_CHANGED] = 1;
-            }
-        }
-        __syncthreads();
-        const int ch = L.misc[M_CHANGED];
-        __syncthreads();
-        if (!ch) break;
-        if (tid == 0) L.misc[M_CHANGED] = 0;
-        __syncthreads();
-    }
-    const bool can_move = !blocked;
-
-    // ---- phase 2 (rail_env.py:574-627)
-    if (act) {
-        const bool in_malf = malf > 0;
-        bool mv = in_malf ? false : can_move;
-        mv = mv || (state == ST_STOPPED && scount != max_count);
-        const bool malf_done = malf == 0, dep = t >= earliest, stop = a == ACT_STOP;
-        const bool vmove = (a >= ACT_LEFT && a <= ACT_RIGHT) && mv;
-        const bool at_target = pos >= 0 && pos == target;
-        const bool conflict = (!mv) && scount == max_count;
-        sig = in_malf;
-        uint32_t ns;
-        switch (state) {  // state_machine.py:12-80
-        case ST_WAITING: ns = in_malf ? ST_MALF_OFF : (dep ? ST_READY : ST_WAITING); break;
-        case ST_READY: ns = in_malf ? ST_MALF_OFF : (vmove ? ST_MOVING : ST_READY); break;
-        case ST_MALF_OFF: ns = malf_done ? (dep ? (vmove ? ST_MOVING : (stop ? ST_STOPPED : ST_READY)) : ST_WAITING) : ST_MALF_OFF; break;
-        case ST_MOVING: ns = in_malf ? ST_MALF : (at_target ? ST_DONE : ((stop || conflict) ? ST_STOPPED : ST_MOVING)); break;
-        case ST_STOPPED: ns = in_malf ? ST_MALF : (vmove ? ST_MOVING : ST_STOPPED); break;
-        case ST_MALF: ns = malf_done ? (vmove ? ST_MOVING : ST_STOPPED) : ST_MALF; break;
-        default: ns = ST_DONE; break;
-        }
-        prev = state;
-        state = ns;
-        mv = mv && state != ST_DONE;  // :596
-        if (is_on_map(state)) {       // :599-607
-            if (is_off_map(prev)) { pos = init_pos; dir = init_dir; }
-            else if (mv && scount == max_count) {
-                pos = np_pos; dir = np_dir;
-                if (pos == target) { prev = state; state = ST_DONE; }  // update_if_reached state_machine.py:139-144
-            }
-        }
-        if ((is_on_map(state) && pos < 0) || (is_off_map(state) && pos >= 0)) L.misc[M_ERR] = FL_ERR_STATE_SYNC;  // env_utils.py:45-52
-        if (state == ST_DONE && arrival < 0) { arrival = t; done = 1; pos = -1; }  // :493-499
-        if (state != ST_DONE) L.misc[M_NOTDONE] = 1;                               // :615
-        if (state == ST_MOVING && old_pos >= 0) scount = (scount + 1) % (max_count + 1);  // speed_counter.py:10-14
-        if (malf > 0) malf -= 1;                                                           // malfunction_handler.py:48-50
-        if (scount == 0 && pos >= 0) saved = 0;                                            // :626-627
-    }
-    __syncthreads();
-
-    // ---- end of episode (rail_env.py:476-491)
-    const bool ended = (!L.misc[M_NOTDONE]) || (t >= T);
-    int reward = 0;
-    if (act && ended) {
-        if (state == ST_DONE) reward = min(latest - arrival, 0);
-        else {
-            // len(shortest path) = distance-map value at (position, direction) + 1 waypoints, 0 if unreachable
-            // (greedy strict descent of rail_env_shortest_paths.py:203-274 on a consistent BFS map)
-            const int pc = is_off_map(state) ? init_pos : pos;
-            const uint16_t dv = d.dm[(((size_t)b * d.Umax + d.tslot[g]) * HW + pc) * 4 + dir];
-            const int len = (dv == FL_INF16) ? 0 : (int)dv + 1;
-            const int travel = (int)ceil((double)len / d.speed[g]);  // agent_utils.py:129-136
-            reward = is_off_map(state) ? -travel : (latest - t) - travel;
-        }
-        done = 1;
-        if (reward != 0) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward); atomicAdd(&L.misc[5], reward); }
-        if (state == ST_DONE) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull); atomicAdd(&L.misc[6], 1); }
-    }
-
-    __syncthreads();
-    // ---- write back
-    if (act) {
-        d.pos[g] = pos; d.old_pos[g] = old_pos; d.arrival[g] = arrival;
-        d.malf[g] = malf | (nmalf << 16);
-        d.pk[g] = pk_make(dir, old_dir, state, prev, saved, scount, sig, dead, done);
-        rewards[g] = reward;
-        dones[g] = (uint8_t)done;
-    }
-    // RNG state: numpy keeps pos in (0, 624]; twist only what was consumed
-    {
-        const int P = pos0 + consumed;
-        const int need_twists = P <= MT_N ? 0 : (P - 1) / MT_N;
-        // rng_ensure never generates beyond `consumed`, so twists == need_twists unless pos0 == 624 and nothing
-        // was drawn (A == 0)
-        if (twists > 0)
-            for (int k = tid; k < MT_N; k += nt) d.mt[(size_t)b * MT_N + k] = L.mtl[k];
-        if (tid == 0) {
-            d.mt_pos[b] = P - need_twists * MT_N;
-            d.t[b] = t;
-            d.done_all[b] = ended ? 1 : 0;
-            done_all_out[b] = ended ? 1 : 0;
-            d.metrics[(size_t)b * 4 + 2] += A;              // only this workgroup touches env b's counters
-            if (ended) {
-                atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
-                d.last_episode[(size_t)b * 2 + 0] = L.misc[5];  // evaluator scoring inputs (service.py:875-879,900-913)
-                d.last_episode[(size_t)b * 2 + 1] = L.misc[6];
-            }
-            if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
-        }
-    }
+    step_body<SYNTH>(d, actions, seed, stream_base, synth_kind, rewards, dones, done_all_out, auto_reset, wcap, S, sshift, lds_raw);
 }
 
 __global__ void k_reset(FlDev d, const uint8_t *mask, int fresh) {
@@ -479,17 +113,13 @@ void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStre
     hipLaunchKernelGGL(k_reset, dim3((n + 255) / 256), dim3(256), 0, s, d, mask_dev, fresh);
 }
 
-static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
-
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s) {
     int nt = ((d.A + 63) / 64) * 64;
     if (nt < 256) nt = 256;
-    const int wcap = next_pow2(2 * d.A + 64);
-    const int S = next_pow2(4 * d.A < 64 ? 64 : 4 * d.A);
-    int lg = 0; while ((1 << lg) < S) lg++;
-    const int sshift = 32 - lg;
-    const size_t lds = (size_t)(MT_N + wcap + 5 * S + 2 * nt + 16) * 4;
+    const StepGeom q = step_geom(d.A);
+    const int wcap = q.wcap, S = q.S, sshift = q.sshift;
+    const size_t lds = step_lds_words(d.A, nt) * 4;
     if (actions)
         hipLaunchKernelGGL(k_step<false>, dim3(d.B), dim3(nt), lds, s, d, actions, seed, stream_base, synth_kind, rewards,
                            dones, done_all, auto_reset, wcap, S, sshift);

@@ -24,7 +24,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
-           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_check",
+           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
            "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
@@ -75,6 +75,7 @@ def lib():
         L.fl_metrics.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        L.fl_step_obs.argtypes = [vp, vp, u32, u32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 7 + [i32, i32, vp]
         L.fl_obs_cutils_tree.argtypes = [vp, i32, i32] + [vp] * 7 + [i32, i32, vp]
         L.fl_info.argtypes = [vp, vp, vp, vp, vp]
         L.fl_policy_pack.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -211,6 +212,36 @@ class BatchedRailEnv:
         _chk(lib().fl_info(self.h, i["action_required"].data_ptr(), i["malfunction"].data_ptr(), i["state"].data_ptr(),
                            i["scores"].data_ptr()))
         return i
+
+    def step_obs(self, actions=None, seed=0, stream_base=0, kind=0, auto_reset=False, filter_required=False, tree_depth=0,
+                 tree_pred=30):
+        """RailEnv.step() as the reference defines it: the tick AND the observations of the new state, one launch.
+        actions None: the on-device synthetic stream (seed, stream_base, kind).  Returns (rewards, dones, done_all,
+        cutils observation dict, upstream tree tensor or None)."""
+        t = self.torch
+        ap = None
+        if actions is not None:
+            if not (isinstance(actions, t.Tensor) and actions.is_cuda):
+                actions = t.as_tensor(np.ascontiguousarray(actions, dtype=np.uint8)).to(self.device)
+            actions = actions.contiguous()
+            assert actions.dtype == t.uint8 and actions.shape == (self.B, self.A)
+            ap = actions.data_ptr()
+        o = self._obs_buffers()
+        tree = None
+        if tree_depth > 0:
+            key = (tree_depth,)
+            if key not in self._tree:
+                n = (4 ** (tree_depth + 1) - 1) // 3
+                self._tree[key] = t.zeros((self.B, self.A, n, 12), dtype=t.float64, device=self.device)
+            tree = self._tree[key]
+        _chk(lib().fl_step_obs(self.h, ap, int(seed), int(stream_base), int(kind), self.rewards.data_ptr(),
+                               self.dones.data_ptr(), self.done_all.data_ptr(),
+                               int(bool(auto_reset)) | (2 if filter_required else 0), self.max_nodes, self.pred_depth,
+                               o["agent_attr"].data_ptr(), o["forest"].data_ptr(), o["adjacency"].data_ptr(),
+                               o["node_order"].data_ptr(), o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(),
+                               o["props"].data_ptr(), int(tree_depth), int(tree_pred),
+                               tree.data_ptr() if tree is not None else None))
+        return self.rewards, self.dones, self.done_all, o, tree
 
     def step_synth(self, seed, stream_base=0, kind=0, auto_reset=True):
         _chk(lib().fl_step_synth(self.h, int(seed), int(stream_base), int(kind), self.rewards.data_ptr(),

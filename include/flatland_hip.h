@@ -92,6 +92,16 @@ int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8
  * kind 0 = uniform 0..4, 1 = forward-biased; env b uses stream id stream_base + b and its own step counter. */
 int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
                   uint8_t *dones_dev, uint8_t *done_all_dev, int auto_reset);
+/* RailEnv.step() returns the observations of the new state (rail_env.py:634 -> _get_observations, :660-666): fl_step /
+ * fl_step_synth (actions_dev == NULL: the synthetic stream seed / stream_base / kind) followed by fl_obs_cutils and, when
+ * tree_max_depth > 0, fl_obs_tree, as one call (two launches back to back on the handle's stream; a single fused launch
+ * measured slower).  flags as fl_step's auto_reset word.  An env whose episode is over (and no auto-reset) gets
+ * FL_ERR_EPISODE_DONE at fl_check(); its observation is then that of the unchanged state. */
+int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t stream_base, int kind,
+                int32_t *rewards_dev, uint8_t *dones_dev, uint8_t *done_all_dev, int flags, int max_nodes,
+                int pred_depth, float *attr_dev, float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev,
+                int32_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev, int tree_max_depth,
+                int tree_pred_depth, double *tree_out_dev);
 /* fl_obs_cutils + fl_obs_tree in ONE launch (same outputs, bit for bit): the second builder reuses the first one's
  * LDS-resident maps and predicted paths (the upstream predictor's path is a prefix of the cutils one).
  * Requires 0 <= tree_pred_depth <= pred_depth. */

@@ -206,3 +206,65 @@ def test_fused_observation_launch_equals_separate_launches(name, B, depth, pred)
         else:
             env.obs_both(depth, pred)
     env.check()
+
+
+@pytest.mark.parametrize("name,B,depth,kind", [("cfg2_spfollow", 5, 2, 0), ("cfg1_malf50", 3, 0, 1), ("cfg0_tall_uniform", 2, 3, 0),
+                                               ("cfg3_spfollow_malf100", 2, 2, 1), ("cfg5_fwd_head", 1, 2, 1)])
+def test_fused_step_and_observation_launch_equals_separate_launches(name, B, depth, kind):
+    """fl_step_obs (RailEnv.step() returning the observations, one launch) vs fl_step_synth + fl_obs_*: state, rewards,
+    dones, RNG and every observation tensor identical on every step, through auto-resets."""
+    fx = util.load(name)
+    st = util.static_of(fx)
+    e1, e2 = _env([st] * B), _env([st] * B)
+    n_steps = min(int(st["T"]) + 25, 260)
+    for t in range(n_steps):
+        r1, d1, a1 = (x.clone() for x in e1.step_synth(5, 3, kind, auto_reset=True))
+        o1 = {k: v.clone() for k, v in e1.obs_cutils().items()}
+        t1 = e1.obs_tree(depth, 30).clone() if depth > 0 else None
+        r2, d2, a2, o2, t2 = e2.step_obs(None, 5, 3, kind, auto_reset=True, tree_depth=depth, tree_pred=30)
+        _same(r2.cpu().numpy(), r1.cpu().numpy(), f"{name} t={t} rewards")
+        _same(d2.cpu().numpy(), d1.cpu().numpy(), f"{name} t={t} dones")
+        _same(a2.cpu().numpy(), a1.cpu().numpy(), f"{name} t={t} done_all")
+        if t % 7 == 0 or t > n_steps - 30:
+            _same(e2.state()[0], e1.state()[0], f"{name} t={t} state")
+            for k in o1:
+                _same(o2[k].cpu().numpy(), o1[k].cpu().numpy(), f"{name} t={t} {k}")
+            if depth > 0:
+                _same(t2.cpu().numpy(), t1.cpu().numpy(), f"{name} t={t} tree")
+    k1, p1 = e1.rng_state()
+    k2, p2 = e2.rng_state()
+    _same(k2, k1, "mt key"); _same(p2, p1, "mt pos")
+    e1.check(); e2.check()
+
+
+def test_fused_step_with_explicit_actions_and_filter():
+    import torch
+    fx = util.load("cfg2_filtered")
+    st = util.static_of(fx)
+    raw = fx["actions"]                       # RAW action stream of the fixture (the filter drops part of it)
+    e1, e2 = _env([st, st]), _env([st, st])
+    for t in range(min(len(raw), 150)):
+        a = torch.from_numpy(np.stack([raw[t], raw[t]]).astype(np.uint8)).cuda()
+        r1, d1, _ = (x.clone() for x in e1.step(a, filter_required=True))
+        o1 = {k: v.clone() for k, v in e1.obs_cutils().items()}
+        r2, d2, _, o2, _ = e2.step_obs(a, filter_required=True)
+        _same(r2.cpu().numpy(), r1.cpu().numpy(), f"t={t} rewards")
+        _same(d2.cpu().numpy(), d1.cpu().numpy(), f"t={t} dones")
+        for k in o1:
+            _same(o2[k].cpu().numpy(), o1[k].cpu().numpy(), f"t={t} {k}")
+        if bool(e1.done_all.cpu().numpy().all()):
+            break
+    e1.check(); e2.check()
+
+
+def test_fused_step_after_episode_end_raises_like_the_reference():
+    from flatland_marl_amd.hip_backend import EpisodeDoneError
+    fx = util.load("cfg1_spfollow")
+    st = util.static_of(fx)
+    env = _env([st])
+    for a in util.actions_of(fx):
+        env.step_obs(np.asarray(a, dtype=np.uint8)[None])
+    env.check()
+    env.step_obs(np.zeros((1, env.A), dtype=np.uint8))
+    with pytest.raises(EpisodeDoneError):
+        env.check()
