@@ -217,6 +217,33 @@ __global__ __launch_bounds__(256) void k_nexthop(FlDev d) {
     d.nh[idx] = (uint16_t)out;
 }
 
+// Eight greedy hops at once: hop8[b][u][state] = the state reached from `state` after eight next-hops towards target u, or
+// FL_HOP_NONE when the greedy path ends earlier.  The observation kernels walk a predicted path with eight lanes, lane j
+// covering the waypoints j, j + 8, j + 16, ... (a chain of L2 gathers an eighth as long as the single-step chain).
+__global__ __launch_bounds__(256) void k_hop8(FlDev d) {
+    const int HW = d.H * d.W, W = d.W;
+    const long long n = (long long)d.B * d.Umax * HW * 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int st0 = (int)(idx % (HW * 4));
+    const long long bu = idx / (HW * 4);
+    const uint16_t *nh = d.nh + (size_t)bu * HW;
+    int cell = st0 >> 2;
+    uint32_t dd = st0 & 3;
+    bool ok = (int)(bu % d.Umax) < d.U[bu / d.Umax];
+    for (int k = 0; k < 8 && ok; k++) {
+        const uint32_t hop = ((uint32_t)nh[cell] >> (3u * dd)) & 7u;
+        if (hop == 4u) ok = false;
+        else { cell = step_cell(cell, hop, W); dd = hop; }
+    }
+    d.hop8[idx] = ok ? (((uint32_t)cell << 2) | dd) : FL_HOP_NONE;
+}
+
+void fl_launch_hop8(const FlDev &d, hipStream_t s) {
+    const long long n = (long long)d.B * d.Umax * d.H * d.W * 4;
+    hipLaunchKernelGGL(k_hop8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+}
+
 void fl_launch_nexthop(const FlDev &d, hipStream_t s) {
     const long long n = (long long)d.B * d.Umax * d.H * d.W;
     hipLaunchKernelGGL(k_nexthop, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);

@@ -197,6 +197,7 @@ int fl_commit(fl_batch *h) {
     DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
     DALLOC(d.seg, (size_t)B * HW * 4);
     DALLOC(d.nh, (size_t)B * Umax * HW);
+    DALLOC(d.hop8, (size_t)B * Umax * HW * 4);
     DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
     DALLOC(d.spk, BA); DALLOC(d.speed, BA);
     DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
@@ -214,6 +215,8 @@ int fl_commit(fl_batch *h) {
     fl_launch_segments(d, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_nexthop(d, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_hop8(d, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_reset(d, nullptr, 1, h->stream);
     HIPCHK(hipGetLastError());
@@ -417,6 +420,7 @@ int fl_distance_map_rebuild(fl_batch *h) {
     fl_launch_segments(h->d, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_nexthop(h->d, h->stream);
+    fl_launch_hop8(h->d, h->stream);
     HIPCHK(hipGetLastError());
     return FL_OK;
 }

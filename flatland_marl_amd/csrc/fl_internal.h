@@ -43,6 +43,8 @@ __host__ __device__ inline uint32_t pk_make(uint32_t dir, uint32_t old_dir, uint
 #define SPK_INIT_DIR(s) ((s)&3u)
 #define SPK_MAX_COUNT(s) (((s) >> 2) & 15u)
 
+#define FL_HOP_NONE 0xFFFFFFFFu
+
 struct FlDev {
     int B, A, H, W, Umax;
     // per env
@@ -62,6 +64,7 @@ struct FlDev {
     int *ut;         // [B][Umax] unique target cells
     uint2 *seg;      // [B][H*W*4] static branch-walk table per (cell, orientation), see fl_dmap.hip k_segments
     uint16_t *nh;    // [B][Umax][H*W] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
+    uint32_t *hop8;  // [B][Umax][H*W*4] state after eight greedy hops, FL_HOP_NONE if the path ends earlier (k_hop8)
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
     uint32_t *spk;
@@ -119,6 +122,7 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
 void fl_launch_segments(const FlDev &d, hipStream_t s);
 void fl_launch_nexthop(const FlDev &d, hipStream_t s);
+void fl_launch_hop8(const FlDev &d, hipStream_t s);  // after fl_launch_nexthop
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
                            long long *no_out, long long *eo_out, hipStream_t s);

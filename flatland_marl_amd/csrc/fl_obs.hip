@@ -1132,10 +1132,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
     };
 
-    // one walker lane per agent on as few wavefronts as possible, one per SIMD first (consecutive wavefronts of a
-    // workgroup land on different SIMDs): a lone wavefront issues at the full rate of its SIMD, sixteen one-lane
-    // walkers would share four
-    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min(nt >> 6, max(4, (A + 63) / 64)) : 0;
+    // eight walker lanes per agent, on at least four wavefronts (consecutive wavefronts of a workgroup land on different
+    // SIMDs): a lone wavefront issues at the full rate of its SIMD
+    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min(nt >> 6, max(4, (A + 7) / 8)) : 0;
     const bool do_p1 = CUTILS && STAGE != 2;
     const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
@@ -1156,49 +1155,56 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
         if (do_p1 && p1_beside_walk && wave == w_first - 1) phase1();
         if (wsel >= 0) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path: its wavefronts issue first
-        for (int i = lane * nw_walk + wsel; wsel >= 0 && i < A; i += 64 * nw_walk) {
-            uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
-            int cell = a_vpos[i];
-            uint32_t dd = a_dir[i];
-            const int target = a_target[i];
-            int n = 0;
-            // last waypoint that can be occupied within the horizon; only those enter the per-key index
-            const int tpc = a_tpc[i];
-            const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
-            auto walk = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
-                if (cell == target) {  // holds at its position (DONE agents): predictions.cpp:208-214
-                    path[n++] = ((uint32_t)cell << 2) | dd;
-                    return;
+        // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265): the choice
+        // at every (target, cell, orientation) is static (k_nexthop), so the predicted path is the chain of next-hops from
+        // the agent's state until nothing is strictly closer (on the target, or at once when it is unreachable), cut after
+        // n_max waypoints: cutils walks max_depth iterations and appends the final waypoint (predictions.cpp:131-133),
+        // upstream stops after max_depth waypoints (rail_env_shortest_paths.py:245-267) and keeps the current position when
+        // there is no path (predictions.py:126,150-156).  EIGHT lanes walk one path: lane j takes j single hops and then
+        // eight hops at a time through the static hop8 table, recording the waypoints j, j + 8, j + 16, ...
+        const int n_max = CUTILS ? pred_depth + 1 : max(pred_depth, 1);
+        for (int base = 0; wsel >= 0 && base < A; base += 8 * nw_walk) {
+            const int slot = lane >> 3, j = lane & 7;
+            const int i = base + wsel * 8 + slot;
+            const bool have = i < A;
+            const int ia = have ? i : 0;
+            uint32_t *path = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            const int u = a_tslot[ia];
+            const uint32_t *h8 = d.hop8 + ((size_t)b * d.Umax + u) * HW * 4;
+            uint32_t st = ((uint32_t)a_vpos[ia] << 2) | a_dir[ia];
+            bool alive = have && j < n_max;
+            auto lead_in = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
+                for (int h = 0; h < 7; h++) {
+                    if (alive && h < j) {
+                        const uint32_t hop = ((uint32_t)nh_u[st >> 2] >> (3u * (st & 3u))) & 7u;
+                        if (hop == 4u) alive = false;
+                        else st = ((uint32_t)step_cell((int)(st >> 2), hop, W) << 2) | hop;
+                    }
                 }
-                // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265):
-                // the choice at every (cell, orientation) is static, see k_nexthop.  cutils walks max_depth iterations and
-                // stops where nothing is strictly closer (i.e. on the target); upstream stops at the target.  This is a
-                // chain of dependent loads on one lane: the loop only chases and records, everything else happens afterwards
-                // with one lane per waypoint.
-                int depth = 0;
-                bool none = false;
-                while (depth < pred_depth && (CUTILS || cell != target)) {
-                    const uint32_t hop = ((uint32_t)nh_u[cell] >> (3u * dd)) & 7u;
-                    path[n++] = ((uint32_t)cell << 2) | dd;
-                    depth++;
-                    if (hop == 4u) { none = true; break; }
-                    cell = step_cell(cell, hop, W);
-                    dd = hop;
-                }
-                // the final waypoint (predictions.cpp:131-133; rail_env_shortest_paths.py:266-267 when not cut by max_depth)
-                if (!none && (CUTILS || depth < pred_depth)) path[n++] = ((uint32_t)cell << 2) | dd;
-                // upstream: a None path (nothing strictly closer) means the agent stands still (predictions.py:150-156);
-                // that only happens on the first step, where exactly one waypoint was recorded
             };
             // two call sites so that each keeps a static address space (LDS copy vs HBM table)
-            if (nh_in_lds) walk(nh_lds + (size_t)a_tslot[i] * HW);
-            else walk(gnh + (size_t)a_tslot[i] * HW);
-            if (n == 0) path[n++] = ((uint32_t)a_vpos[i] << 2) | a_dir[i];  // zero-step predictor: prediction[0] is the current position (predictions.py:126)
-            int lp = n - 1;
-            if (lp > horizon) lp = horizon;
-            if (lp < 0) lp = 0;
-            a_lp[i] = (uint16_t)lp;
-            a_n[i] = (uint16_t)n;
+            if (nh_in_lds) lead_in(nh_lds + (size_t)u * HW);
+            else lead_in(gnh + (size_t)u * HW);
+            int idx = j, last = -1;
+            while (__any(alive)) {
+                if (alive) {
+                    path[idx] = st;
+                    last = idx;
+                    const uint32_t s8 = idx + 8 < n_max ? h8[st] : FL_HOP_NONE;
+                    if (s8 == FL_HOP_NONE) alive = false;
+                    else { st = s8; idx += 8; }
+                }
+            }
+            int m = last;
+            m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
+            if (have && j == 0) {
+                const int n = m + 1;  // lane 0 always records the current position
+                // last waypoint that can be occupied within the horizon; only those enter the per-key index
+                const int tpc = a_tpc[i];
+                const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
+                a_lp[i] = (uint16_t)max(0, min(n - 1, horizon));
+                a_n[i] = (uint16_t)n;
+            }
         }
         if (wsel >= 0) __builtin_amdgcn_s_setprio(0);
         if (CUTILS) {
