@@ -923,12 +923,18 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const bool nh_in_lds = P.nh_lds_words >= nh_n && (STAGE == 0 ? my_pred_depth >= 0 : true);
     if (STAGE != 2) {
     for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
-    if (nh_in_lds) for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
-
+    if (nh_in_lds) {
+        if ((((uintptr_t)gnh) & 3u) == 0 && (nh_n & 1) == 0) {  // two entries per load
+            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(gnh);
+            uint32_t *l2 = reinterpret_cast<uint32_t *>(nh_lds);
+            for (int c = tid; c < (nh_n >> 1); c += nt) l2[c] = g2[c];
+        } else {
+            for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
+        }
+    }
     for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
-    __syncthreads();
     for (int i = tid; i < A; i += nt) {
         const int g = b * A + i;
         const uint32_t pk = d.pk[g], spk = d.spk[g];
