@@ -27,6 +27,7 @@
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
 #define CF_CHUNK 8                   // items of a key's list scanned per conflict work-list entry
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
+#define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
@@ -574,6 +575,7 @@ struct ObsArgs {
     int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
     int wl_bytes;      // LDS bytes of the pass B work lists
     int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
+    int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
 };
 
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
@@ -902,7 +904,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
     uint32_t *wl_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // pass B work lists
     unsigned long long *tmask = (unsigned long long *)carve(CSR_LDS && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
-    uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);  // next-hop tables of the env's targets when they fit
+    uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);
+    // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
+    int *csr2 = (int *)carve(P.dual_index ? (size_t)(K + 1) * 4 : 16);
+    unsigned long long *tmaskb = (unsigned long long *)carve(P.dual_index && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
+    uint32_t *items2 = (uint32_t *)carve(P.dual_index ? (size_t)OBS_ITEMS2_CAP * 4 : 16);
+    uint16_t *a_lp2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);
+    uint16_t *a_tpc2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);  // next-hop tables of the env's targets when they fit
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
@@ -951,6 +959,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         a_tslot[i] = d.tslot[g];
         a_target[i] = target;
         a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
+        if (CUTILS && STAGE == 1 && P.dual_index) a_tpc2[i] = (uint16_t)(int)(1.0 / speed);  // the upstream predictor's (predictions.py:139)
         (void)spk;
     }
     __syncthreads();
@@ -1150,8 +1159,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     OBS_STAMP(2);
     // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
     if (X.Tn > 0) {
-        for (int k = tid; k <= K; k += nt) csr[k] = 0;
-        if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
+        // fused launch: stage 1 builds the upstream predictor's index too (same paths, one pass over the waypoints); stage 2
+        // then starts at its trees.  misc[4] tells stage 2 that the second index is complete.
+        const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
+        const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
+        const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : 2;
+        if (!reuse) {
+            for (int k = tid; k <= K; k += nt) csr[k] = 0;
+            if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
+        }
+        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
@@ -1210,6 +1227,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
                 a_lp[i] = (uint16_t)max(0, min(n - 1, horizon));
                 a_n[i] = (uint16_t)n;
+                if (dual) {  // the upstream path is a prefix of this one (see stage 2 below)
+                    const int tpc2 = a_tpc2[i];
+                    const int n_py = (n - 1 < P.tree_pred) ? n : P.tree_pred;
+                    a_lp2[i] = (uint16_t)max(0, min(n_py - 1, (Tn2 - 1) / tpc2));
+                }
             }
         }
         if (wsel >= 0) __builtin_amdgcn_s_setprio(0);
@@ -1225,9 +1247,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         for (int i = wave; i < A; i += (nt >> 6)) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i];
-            for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
+            const int lp2 = dual ? (int)a_lp2[i] : -1;
+            for (int k = lane; k <= lp; k += 64) {
+                const int key = key_of(X, (int)(path[k] >> 2));
+                atomicAdd(&csr[key], 1);
+                if (k <= lp2) atomicAdd(&csr2[key], 1);
+            }
         }
-        } else {
+        } else if (!reuse) {
             // second stage: the upstream path is the prefix of the cutils path kept by stage 1 -- it stops at the target
             // (which ends the cutils path too) and after pred_depth waypoints (rail_env_shortest_paths.py:245-267)
             for (int i = tid; i < A; i += nt) {
@@ -1245,12 +1272,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         __syncthreads();
         OBS_STAMP(3);
-        // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan
-        {
+        // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan.  With the second
+        // index both counts share the scan, 16 bits each (the launcher guarantees totals below 65536).
+        if (!reuse) {
             const int chunk = (K + 1 + nt - 1) / nt;
             const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
             int sum = 0;
-            for (int k = lo; k < hi; k++) sum += csr[k];
+            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
@@ -1269,17 +1297,34 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             __syncthreads();
             int run = partial[tid];
-            for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
-            if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
+            if (dual) {
+                for (int k = lo; k < hi; k++) {
+                    const int v = csr[k] | (csr2[k] << 16);
+                    csr[k] = run & 0xFFFF; csr2[k] = (int)((unsigned)run >> 16);
+                    run += v;
+                }
+                if (hi == K + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
+            } else {
+                for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
+                if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
+            }
         }
         __syncthreads();
+        if (reuse) {  // stage 1 built this index
+            csr = csr2; X.csr_end = csr2; X.items_lds = items2;
+            X.tmask = P.use_tmask ? tmaskb : nullptr;
+            if (!X.tmask) { X.wl_occ_cap = P.wl_bytes / 8; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
+        }
         const bool fit = CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP;
-        if (fit) { csr_items = items_lds; X.items_lds = items_lds; }
+        const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
+        if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
+        if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
-        for (int i = wave; i < A; i += (nt >> 6)) {
+        for (int i = wave; !reuse && i < A; i += (nt >> 6)) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
+            const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
             for (int k = lane; k <= lp; k += 64) {
                 const uint32_t w = path[k];
                 const uint32_t dnext = k < lp ? (path[k + 1] & 3u) : (w & 3u), dprev = k > 0 ? (path[k - 1] & 3u) : (w & 3u);
@@ -1301,6 +1346,18 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const int slot = atomicAdd(&csr[key], 1);
                 csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                   ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                if (k <= lp2) {  // the same waypoint in the upstream predictor's index: w(t) = min(t / tpc, lp)
+                    const int tlo2 = k * tpc2, tlast2 = Tn2 - 1;
+                    const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
+                    const uint32_t dnext2 = k < lp2 ? dnext : (w & 3u);
+                    if (P.use_tmask) {
+                        const int b1 = min(tlo2 >> tshift2, 63), b2 = min((to_end2 ? tlast2 : tlo2 + tpc2 - 1) >> tshift2, 63);
+                        atomicOr(&tmaskb[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
+                    }
+                    const int slot2 = atomicAdd(&csr2[key], 1);
+                    items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
+                                    ((uint32_t)(tpc2 - 1) << 6) | (dprev << 4) | (dnext2 << 2) | (w & 3u);
+                }
             }
         }
         __syncthreads();
@@ -1362,18 +1419,19 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask, bool dual) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
            al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
-           al((size_t)nh_words * 2) + 64;
+           al((size_t)nh_words * 2) + al(dual ? (K + 1) * 4 : 16) + al(dual && use_tmask ? (K + 1) * 8 : 16) +
+           al(dual ? (size_t)OBS_ITEMS2_CAP * 4 : 16) + 2 * al(dual ? A * 2 : 16) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, bool &csr_lds, int &nt, size_t &lds) {
+static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, int &dual_index, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
     // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
@@ -1386,8 +1444,14 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
         for (int k = 0; k < 3; k++) {
             nt = nts[k];
             for (wl_bytes = 24 * 1024; wl_bytes >= 8 * 1024; wl_bytes /= 3) {  // a third of the work-list space still does
-                for (use_tmask = csr_lds ? 1 : 0; use_tmask >= 0; use_tmask--) {  // the masks are the first thing to go
-                    lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0);
+                // first to go: the second index of the fused launch, then the time masks
+                const bool dual_ok = csr_lds && P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
+                                     (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
+                for (int opt = 0; opt < 4; opt++) {
+                    use_tmask = opt < 2 ? 1 : 0;
+                    dual_index = opt % 2 == 0 ? 1 : 0;
+                    if ((use_tmask && !csr_lds) || (dual_index && !dual_ok)) continue;
+                    lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0, dual_index != 0);
                     if (lds <= 160 * 1024) return true;
                 }
             }
@@ -1412,7 +1476,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = F_WORDS * 32;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
@@ -1432,7 +1496,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
     P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
 }
 
@@ -1447,6 +1511,6 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
     P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
