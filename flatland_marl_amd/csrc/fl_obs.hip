@@ -9,12 +9,13 @@
 //   flatland_cutils/src/feature_parser.cpp:3-98 AgentAttrParser::get_features
 //   flatland-rl/flatland/envs/observations.py:60-494 + predictions.py:97-180   upstream TreeObsForRailEnv
 //
-// Layout of one launch (gfx950): the env's rail bitmap (u16 H*W) and the per-cell occupancy maps are staged
-// in LDS once; phase 1 runs one lane per agent (snapshot, deadlock fixpoint, 83-float attribute row);
-// phase 2 walks every agent's predicted path (<= 500 dependent distance-map gathers) and builds a
-// per-cell CSR index of (agent, waypoint) pairs in HBM scratch; phase 3 builds the trees with one
-// wavefront per agent: every BFS level is explored by one lane per queue entry, children are handed to
-// the next level's lanes with wave shuffles (no queue in memory), node rows are written straight to HBM.
+// Layout of one launch (gfx950): one workgroup (up to 16 wavefronts) per env.  The env's rail bitmap and an occupied-cell
+// table are staged in LDS once.  Then, concurrently: eight lanes per agent walk its predicted path (static next-hop /
+// eight-hop tables), one wavefront does the per-agent part (deadlock fixpoint, valid actions, 83-float attribute row) and
+// the other wavefronts derive the topology of the trees from the static segment table (pass A).  A per-key index of
+// prediction items (+ per-key time-bucket masks) is built in LDS.  Pass B splits the visited cells of all trees evenly over
+// all lanes, classifies them, and processes the few cells that need work from LDS work lists on packed wavefronts; rows
+// are written straight to HBM.  DESIGN.md section 4 describes the phases; tools/obs_phase_clocks.py measures them.
 #include "fl_obs.h"
 
 #include <string.h>
@@ -22,8 +23,6 @@
 #include "../../include/flatland_hip.h"
 
 #define OBS_NT 1024
-#define OBS_WAVES (OBS_NT / 64)
-#define OBS_GROUPS (OBS_WAVES * 2)   // cutils trees: two agents per wavefront, 32 lanes each (max_nodes <= 33)
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
 #define CF_CHUNK 8                   // items of a key's list scanned per conflict work-list entry
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
@@ -1366,7 +1365,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     OBS_STAMP(4);
     // ---- phase 3: trees.  Pass A derives the topology of a tree from the static segment table (O(1) per node, one
     // BFS level per step); pass B evaluates the agent-dependent features with the visited cells of all nodes split
-    // evenly over the lanes of the team (team_pass_b); then one lane per node writes its row.
+    // evenly over the lanes of the workgroup (wg_pass_b); then one lane per node writes its row.
     const float max_dist = (float)T;
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
