@@ -18,6 +18,7 @@
 // are written straight to HBM.  DESIGN.md section 4 describes the phases; tools/obs_phase_clocks.py measures them.
 #include "fl_obs.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/flatland_hip.h"
@@ -1433,6 +1434,9 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs 
 static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, int &dual_index, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
+    // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes)
+    static const int force_nt = getenv("FL_OBS_NT") ? atoi(getenv("FL_OBS_NT")) : 0;
+    static const size_t lds_limit = getenv("FL_OBS_LDS_LIMIT") ? (size_t)atol(getenv("FL_OBS_LDS_LIMIT")) : (size_t)160 * 1024;
     // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
     // of an env, else they are read from HBM anyway), then the prediction index
     const int nh_fit = (size_t)d.Umax * d.H * d.W * 2 <= 24 * 1024 ? d.Umax * d.H * d.W : 0;
@@ -1442,6 +1446,7 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
         if ((c < 2 && !csr_lds) || (c % 2 == 0 && nh_fit == 0)) continue;
         for (int k = 0; k < 3; k++) {
             nt = nts[k];
+            if (force_nt && nt != force_nt) continue;
             for (wl_bytes = 24 * 1024; wl_bytes >= 8 * 1024; wl_bytes /= 3) {  // a third of the work-list space still does
                 // first to go: the second index of the fused launch, then the time masks
                 const bool dual_ok = csr_lds && P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
@@ -1451,7 +1456,7 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
                     dual_index = opt % 2 == 0 ? 1 : 0;
                     if ((use_tmask && !csr_lds) || (dual_index && !dual_ok)) continue;
                     lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0, dual_index != 0);
-                    if (lds <= 160 * 1024) return true;
+                    if (lds <= lds_limit) return true;
                 }
             }
         }
