@@ -25,7 +25,9 @@
 
 #define OBS_NT 1024
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
-#define CF_CHUNK 8                   // items of a key's list scanned per conflict work-list entry
+#ifndef CF_CHUNK
+#define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
+#endif
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
 #define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
