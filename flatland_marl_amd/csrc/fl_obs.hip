@@ -28,6 +28,12 @@
 #ifndef CF_CHUNK
 #define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
 #endif
+#ifndef OBS_WL_OCC_DIV
+#define OBS_WL_OCC_DIV 6            // occupant work list = 1 / OBS_WL_OCC_DIV of the work-list entries, conflicts get the rest
+#endif
+#ifndef OBS_TSHIFT
+#define OBS_TSHIFT 1                 // time-bucket width of the per-key masks for long horizons: 1 << OBS_TSHIFT steps
+#endif
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
 #define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
@@ -1007,10 +1013,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (CSR_LDS && P.use_tmask && X.Tn > 0) ? tmask : nullptr;
-    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / 24 : P.wl_bytes / 8;  // a third of the entries
+    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / (8 * OBS_WL_OCC_DIV) : P.wl_bytes / 8;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = P.wl_bytes / 8 - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
-    X.tshift = X.Tn <= 64 ? 0 : 2;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
+    X.tshift = X.Tn <= 64 ? 0 : OBS_TSHIFT;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
     X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
     OBS_STAMP(1);
