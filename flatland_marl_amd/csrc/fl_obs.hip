@@ -584,6 +584,7 @@ struct ObsArgs {
     int wl_bytes;      // LDS bytes of the pass B work lists
     int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
+    unsigned lds_bytes; // dynamic LDS of the launch (the kernel checks its own carving against it)
 };
 
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
@@ -918,7 +919,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     unsigned long long *tmaskb = (unsigned long long *)carve(P.dual_index && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
     uint32_t *items2 = (uint32_t *)carve(P.dual_index ? (size_t)OBS_ITEMS2_CAP * 4 : 16);
     uint16_t *a_lp2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);
-    uint16_t *a_tpc2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);  // next-hop tables of the env's targets when they fit
+    uint16_t *a_tpc2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);
+    if (off > P.lds_bytes) {  // host-side sizing (obs_lds_bytes) and this carving disagree: refuse to run
+        if (tid == 0) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);
+        return;
+    }  // next-hop tables of the env's targets when they fit
 
     const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
@@ -1473,7 +1478,9 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
 }
 
 template <typename KernelT>
-static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, size_t lds, int nt, hipStream_t s) {
+static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P0, size_t lds, int nt, hipStream_t s) {
+    ObsArgs P = P0;
+    P.lds_bytes = (unsigned)lds;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(d.B), dim3(nt), lds, s, d, o, P);
     return FL_OK;
