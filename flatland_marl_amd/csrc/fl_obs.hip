@@ -18,6 +18,7 @@
 // are written straight to HBM.  DESIGN.md section 4 describes the phases; tools/obs_phase_clocks.py measures them.
 #include "fl_obs.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -584,6 +585,8 @@ struct ObsArgs {
     int wl_bytes;      // LDS bytes of the pass B work lists
     int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
+    int partial_own;   // own scratch for the key scan (else it borrows the work-list area)
+    int items_lds;     // reserve LDS for the prediction items (maps whose items never fit keep them in HBM and spend the LDS elsewhere)
     unsigned lds_bytes; // dynamic LDS of the launch (the kernel checks its own carving against it)
 };
 
@@ -908,10 +911,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *misc = (int *)carve(64 * 4);
     int *team_meta = (int *)carve(256 * 4);
     int *wave_scr = (int *)carve((size_t)obs_scr_words(nt >> 6, A, P.tw_c, P.tw_t, P.tpw_t) * 4);  // the teams' node tables
-    int *partial = (int *)carve((size_t)nt * 4);                       // scan scratch
     int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
-    uint32_t *items_lds = (uint32_t *)carve(CSR_LDS ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
-    uint32_t *wl_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // pass B work lists
+    uint32_t *items_lds = (uint32_t *)carve(CSR_LDS && P.items_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
+    uint32_t *wl_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // pass B work lists; scratch of the key scan before that
+    int *partial = P.partial_own ? (int *)carve((size_t)nt * 4) : reinterpret_cast<int *>(wl_lds);
     unsigned long long *tmask = (unsigned long long *)carve(CSR_LDS && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
     uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
@@ -1328,7 +1331,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             X.tmask = P.use_tmask ? tmaskb : nullptr;
             if (!X.tmask) { X.wl_occ_cap = P.wl_bytes / 8; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
-        const bool fit = CSR_LDS && misc[2] <= OBS_ITEMS_LDS_CAP;
+        const bool fit = CSR_LDS && P.items_lds && misc[2] <= OBS_ITEMS_LDS_CAP;
         const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
@@ -1432,19 +1435,19 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask, bool dual) {
+static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask, bool dual, bool items, bool partial_own) {
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
-           al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al((size_t)nt * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
-           al(csr_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
+           al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
+           al(csr_lds && items ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + (partial_own ? al((size_t)nt * 4) : 0) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
            al((size_t)nh_words * 2) + al(dual ? (K + 1) * 4 : 16) + al(dual && use_tmask ? (K + 1) * 8 : 16) +
            al(dual ? (size_t)OBS_ITEMS2_CAP * 4 : 16) + 2 * al(dual ? A * 2 : 16) + 64;
 }
 
 // pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, int &dual_index, bool &csr_lds, int &nt, size_t &lds) {
+static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, int &dual_index, int &items_lds, int &partial_own, bool &csr_lds, int &nt, size_t &lds) {
     const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
     const int nts[3] = {OBS_NT, 512, 256};
     // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes)
@@ -1461,15 +1464,18 @@ static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int
             nt = nts[k];
             if (force_nt && nt != force_nt) continue;
             for (wl_bytes = 24 * 1024; wl_bytes >= 8 * 1024; wl_bytes /= 3) {  // a third of the work-list space still does
-                // first to go: the second index of the fused launch, then the time masks
+                // first to go: the second index of the fused launch, then the LDS copy of the items (the time masks are
+                // worth more: they feed the work lists), then the masks
                 const bool dual_ok = csr_lds && P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
                                      (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
-                for (int opt = 0; opt < 4; opt++) {
-                    use_tmask = opt < 2 ? 1 : 0;
-                    dual_index = opt % 2 == 0 ? 1 : 0;
-                    if ((use_tmask && !csr_lds) || (dual_index && !dual_ok)) continue;
-                    lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0, dual_index != 0);
-                    if (lds <= lds_limit) return true;
+                static const int opts[5][3] = {{1, 1, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {0, 0, 0}};  // masks, second index, items
+                for (int opt = 0; opt < 5; opt++) {
+                    use_tmask = opts[opt][0]; dual_index = opts[opt][1]; items_lds = opts[opt][2];
+                    if (((use_tmask || items_lds) && !csr_lds) || (dual_index && !dual_ok)) continue;
+                    for (partial_own = 1; partial_own >= 0; partial_own--) {  // 4 KB of scan scratch: borrowed when tight
+                        lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0, dual_index != 0, items_lds != 0, partial_own != 0);
+                        if (lds <= lds_limit) return true;
+                    }
                 }
             }
         }
@@ -1481,6 +1487,13 @@ template <typename KernelT>
 static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P0, size_t lds, int nt, hipStream_t s) {
     ObsArgs P = P0;
     P.lds_bytes = (unsigned)lds;
+    static const bool verbose = getenv("FL_OBS_VERBOSE") != nullptr;  // diagnostic: the configuration obs_pick_config chose
+    static int printed = 0;
+    if (verbose && printed < 4) {
+        printed++;
+        fprintf(stderr, "[fl_obs] %d threads, %zu B LDS: next-hop in LDS %d, work lists %d B, time masks %d, second index %d, items in LDS %d\n",
+                nt, lds, P.nh_lds_words > 0, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds);
+    }
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(d.B), dim3(nt), lds, s, d, o, P);
     return FL_OK;
@@ -1495,7 +1508,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = F_WORDS * 32;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
 }
 
@@ -1515,7 +1528,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
     P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
 }
 
@@ -1530,6 +1543,6 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
     P.tpw_t = max_depth <= 2 ? 2 : 1;
     bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, csr_lds, nt, lds)) return FL_ERR_ARG;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
