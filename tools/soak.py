@@ -30,15 +30,31 @@ keys = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency")
 episodes = 0
 for it in range(steps):
     kind = (it // 400) % 2
-    rew, done, done_all = env.step_synth(seed, 0, kind, auto_reset=True)
-    o, tree = env.obs_both(2, 30)
+    explicit = (it // 250) % 3 == 2          # every third block: explicit action tensors incl. absent / illegal values
+    if explicit:
+        rs = np.random.RandomState(it)
+        acts = rs.choice(np.array([0, 1, 2, 3, 4, 5, 9, 255], dtype=np.uint8), size=(B, A),
+                         p=[0.1, 0.15, 0.4, 0.15, 0.1, 0.03, 0.02, 0.05]).astype(np.uint8)
+        filt = (it // 250) % 2 == 0
+        rew, done, done_all, o, tree = env.step_obs(acts, auto_reset=True, filter_required=filt, tree_depth=2, tree_pred=30)
+    else:
+        rew, done, done_all = env.step_synth(seed, 0, kind, auto_reset=True)
+        o, tree = env.obs_both(2, 30)
     rew, done = rew.cpu().numpy(), done.cpu().numpy()
     on = {k: v.cpu().numpy() for k, v in o.items()}
     tr = tree.cpu().numpy()
     state = env.state()[0]
     for b in range(shadow):
         fn = synth.forward_biased_actions if kind == 1 else synth.uniform_actions
-        r_o, d_o, da = oracles[b].step(fn(seed, b, tc[b], A))
+        if explicit:
+            a_b = acts[b].copy()
+            if filt:      # eval_env.parse_actions: drop the actions of agents without action_required
+                st = oracles[b].state()   # columns: row, col, dir, state, malf, nmalf, speed counter, ... (rail_env.py:243-258)
+                required = (st[:, 3] == 1) | ((st[:, 3] >= 3) & (st[:, 3] <= 5) & (st[:, 6] == 0))
+                a_b[~required] = 255
+            r_o, d_o, da = oracles[b].step(a_b)
+        else:
+            r_o, d_o, da = oracles[b].step(fn(seed, b, tc[b], A))
         tc[b] += 1
         assert np.array_equal(rew[b], r_o) and np.array_equal(done[b], d_o), (it, b, "reward/done")
         assert np.array_equal(state[b], oracles[b].state()), (it, b, "state")
