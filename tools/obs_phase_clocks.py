@@ -1,6 +1,6 @@
 """Diagnostic: per-phase clocks of the fused observation kernel, from a -DFL_OBS_TIMING build of the library.
 
-  OUT=$PWD/gpurun_tmp/libfl_timing.so EXTRA_HIPCC_FLAGS=-DFL_OBS_TIMING FORCE=1 flatland_marl_amd/csrc/build.sh
+  mkdir -p gpurun_tmp; OUT=$PWD/gpurun_tmp/libfl_timing.so EXTRA_HIPCC_FLAGS=-DFL_OBS_TIMING FORCE=1 flatland_marl_amd/csrc/build.sh
   python tools/obs_phase_clocks.py gpurun_tmp/libfl_timing.so [workload]        (on the GPU box)
 
 Prints the mean over envs / steps of the time between stamps (us; wall_clock64 ticks at 100 MHz).
