@@ -55,6 +55,11 @@ struct ObsCtx {
     int A, H, W, HW;
     bool keycell;                 // prediction keys (col * W + row, tool.h:391-398) are injective (H <= W): index by cell id
     const uint32_t *cellw;        // LDS per cell: rail bitmap (low 16) | occupied-cell table index (high 16, 0xFFFF = none)
+    // large maps (keys not in LDS): the rail bitmap alone, u16 per cell, and the occupied cells in a small hash set whose
+    // slot index plays the role of the table index above
+    const uint16_t *cell16;       // LDS per cell rail bitmap, nullptr = cellw layout
+    const int *hkey;              // LDS [hmask + 1] cell id or -1
+    int hmask;
     const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
     const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
     const uint32_t *cell_target;  // LDS bitmap: some agent's target (upstream location_has_target)
@@ -80,6 +85,25 @@ struct ObsCtx {
     long long *dbg;               // diagnostic builds
     int dbg_base;
 };
+
+__host__ __device__ inline int obs_hash_cap(int A) { int c = 64; while (c < 2 * A) c <<= 1; return c; }
+__device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int cell) {
+    return X.cell16 ? (uint32_t)X.cell16[cell] : (X.cellw[cell] & 0xFFFFu);
+}
+// occupied-cell table index of the cell, 0xFFFF = nobody on it and nobody waiting to depart from it
+__device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int cell) {
+    if (!X.cell16) return X.cellw[cell] >> 16;
+    int h = (int)(((uint32_t)cell * 2654435761u) >> 16) & X.hmask;
+    while (true) {
+        const int k = X.hkey[h];
+        if (k == cell) return (uint32_t)h;
+        if (k < 0) return 0xFFFFu;
+        h = (h + 1) & X.hmask;
+    }
+}
+__device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int cell) {
+    return X.cell16 ? (cw_bits(X, cell) | (cw_slot(X, cell) << 16)) : X.cellw[cell];
+}
 
 __device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
     if (X.keycell) return cell;
@@ -126,7 +150,7 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, i
 // advance k cells along a chain of single-transition cells (no features)
 __device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t &d, int k) {
     for (int v = 0; v < k; v++) {
-        d = first_dir(nibble(X.cellw[cell] & 0xFFFFu, d));
+        d = first_dir(nibble(cw_bits(X, cell), d));
         cell = step_cell(cell, d, X.W);
     }
 }
@@ -173,7 +197,7 @@ __device__ __forceinline__ void occ_event(const ObsCtx &X, int *sc, int node, ui
 // predicted there then (self included) satisfies the conflict condition.  Flags of sub-ranges of a list simply OR.
 template <bool CUTILS, bool ITL>
 __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, int cell, uint32_t d, int pt, int lo, int hi) {
-    const uint32_t bits = nibble(X.cellw[cell] & 0xFFFFu, d);
+    const uint32_t bits = nibble(cw_bits(X, cell), d);
     const uint32_t tlast = (uint32_t)(X.Tn - 1);
     const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
     uint32_t flags = 0;
@@ -367,7 +391,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 tot = vs[F_TOT * CAP + node];
                 left = vs[F_VIS * CAP + node];
             }
-            const uint32_t cw = X.cellw[cell];
+            const uint32_t cw = cw_load(X, cell);
             int *sc = scr0 + team * team_words;
             const uint2 entry = make_uint2(((uint32_t)cell << 2) | dd | ((uint32_t)team << 24), (uint32_t)tot | ((uint32_t)node << 24));
             // occupant?
@@ -425,7 +449,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     for (int e = tid; e < n_occ; e += nt) {
         const uint2 w = X.wl_occ[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), X.cellw[cell] >> 16, w.x & 3u, (int)(w.y & 0xFFFFFFu));
+        occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
     // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes
     // further entries for the rest of its list.  First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) |
@@ -519,7 +543,7 @@ __device__ __forceinline__ int child_state(const ObsCtx &X, const NodeDesc &nd, 
     if (!(nd.flags & (ND_SWITCH | ND_DEAD_END))) return -1;
     const int ecell = nd.end >> 2;
     const uint32_t edir = nd.end & 3;
-    const uint32_t pbits = nibble(X.cellw[ecell] & 0xFFFFu, edir);
+    const uint32_t pbits = nibble(cw_bits(X, ecell), edir);
     const uint32_t bd = (edir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
     if (nd.flags & ND_DEAD_END) return ((pbits >> (3 - rev)) & 1) ? ((step_cell(ecell, rev, X.W) << 2) | (int)rev) : -1;
     return ((pbits >> (3 - bd)) & 1) ? ((step_cell(ecell, bd, X.W) << 2) | (int)bd) : -1;
@@ -614,7 +638,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         const int g = b * A + ia;
         const int vpos = a_vpos[ia];
         const uint32_t dir = a_dir[ia];
-        const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+        const uint32_t rbits = nibble(cw_bits(X, vpos), dir);
         uint32_t orientation = dir;
         if (__popc(rbits) == 1) orientation = first_dir(rbits);
         double *out = P.tree_out + (size_t)g * NN * 12;
@@ -704,7 +728,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
     const int g = b * A + ia;
     const int vpos = a_vpos[ia];
     const uint32_t dir = a_dir[ia];
-    const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+    const uint32_t rbits = nibble(cw_bits(X, vpos), dir);
     uint32_t orientation = dir;
     if (__popc(rbits) == 1) orientation = first_dir(rbits);
     float *F = P.forest + (size_t)g * N * 12;
@@ -802,7 +826,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
             const int g = b * A + ia;
             const int vpos = a_vpos[ia];
             const uint32_t dir = a_dir[ia];
-            const uint32_t rbits = nibble(cellw[vpos] & 0xFFFFu, dir);
+            const uint32_t rbits = nibble(cw_bits(X, vpos), dir);
             uint32_t orientation = dir;
             if (__popc(rbits) == 1) orientation = first_dir(rbits);
             float *F = P.forest + (size_t)g * N * 12;
@@ -891,9 +915,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     extern __shared__ __align__(16) unsigned char lds[];
     size_t off = 0;
     auto carve = [&](size_t bytes) { void *p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    uint32_t *cellw = (uint32_t *)carve((size_t)HW * 4);  // rail bitmap | occupied-cell table index << 16
-    int *slot_agent = (int *)carve((size_t)A * 4);
-    int *slot_ready = (int *)carve((size_t)A * 4);
+    constexpr bool CW16 = !CSR_LDS;  // large maps: u16 rail bitmap + hash set of the occupied cells (see ObsCtx)
+    const int HC = obs_hash_cap(A), n_slots_occ = CW16 ? HC : A;
+    uint32_t *cellw = (uint32_t *)carve(CW16 ? (size_t)HW * 2 : (size_t)HW * 4);  // rail bitmap | occupied-cell table index << 16
+    uint16_t *cell16 = reinterpret_cast<uint16_t *>(cellw);
+    int *hkey = (int *)carve(CW16 ? (size_t)HC * 4 : 16);
+    int *slot_agent = (int *)carve((size_t)n_slots_occ * 4);
+    int *slot_ready = (int *)carve((size_t)n_slots_occ * 4);
     uint32_t *cell_target = (uint32_t *)carve((size_t)((HW + 31) / 32) * 4);
     double *a_speed = (double *)carve((size_t)A * 8);
     int *a_vpos = (int *)carve((size_t)A * 4);
@@ -946,7 +974,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nh_n = d.U[b] * HW;
     const bool nh_in_lds = P.nh_lds_words >= nh_n && (STAGE == 0 ? my_pred_depth >= 0 : true);
     if (STAGE != 2) {
-    for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
+    if (CW16) {
+        for (int c = tid; c < HW; c += nt) cell16[c] = ggrid[c];
+        for (int c = tid; c < HC; c += nt) hkey[c] = -1;
+    } else {
+        for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
+    }
     if (nh_in_lds) {
         if ((((uintptr_t)gnh) & 3u) == 0 && (nh_n & 1) == 0) {  // two entries per load
             const uint32_t *g2 = reinterpret_cast<const uint32_t *>(gnh);
@@ -956,7 +989,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
         }
     }
-    for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
+    for (int i = tid; i < n_slots_occ; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
     for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
     if (tid < 64) misc[tid] = 0;
     for (int i = tid; i < A; i += nt) {
@@ -987,14 +1020,24 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (on || off) {
             const int c = on ? a_pos[i] : d.init_pos[b * A + i];
             int slot = -1;
-            unsigned int cur = *(volatile unsigned int *)&cellw[c];
-            while (true) {  // claim (or find) the cell's table entry
-                const unsigned int have = cur >> 16;
-                if (have != 0xFFFFu) { slot = (int)have; break; }
-                if (slot < 0) slot = atomicAdd(&misc[1], 1);
-                const unsigned int old = atomicCAS(&cellw[c], cur, (cur & 0xFFFFu) | ((unsigned int)slot << 16));
-                if (old == cur) break;
-                cur = old;
+            if (CW16) {  // the hash slot of the cell is its table entry
+                int h = (int)(((uint32_t)c * 2654435761u) >> 16) & (HC - 1);
+                while (true) {
+                    const int old = atomicCAS(&hkey[h], -1, c);
+                    if (old == -1 || old == c) break;
+                    h = (h + 1) & (HC - 1);
+                }
+                slot = h;
+            } else {
+                unsigned int cur = *(volatile unsigned int *)&cellw[c];
+                while (true) {  // claim (or find) the cell's table entry
+                    const unsigned int have = cur >> 16;
+                    if (have != 0xFFFFu) { slot = (int)have; break; }
+                    if (slot < 0) slot = atomicAdd(&misc[1], 1);
+                    const unsigned int old = atomicCAS(&cellw[c], cur, (cur & 0xFFFFu) | ((unsigned int)slot << 16));
+                    if (old == cur) break;
+                    cur = old;
+                }
             }
             if (on) atomicMax(&slot_agent[slot], i);
             else atomicAdd(&slot_ready[slot], 1);
@@ -1009,7 +1052,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 
     ObsCtx X;
     X.A = A; X.H = H; X.W = W; X.HW = HW;
-    X.keycell = keycell; X.cellw = cellw; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
+    X.keycell = keycell; X.cellw = cellw; X.cell16 = CW16 ? cell16 : nullptr; X.hkey = hkey; X.hmask = HC - 1; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
     X.seg = d.seg + (size_t)b * HW * 4;
     X.dbg = P.dbg ? P.dbg + (size_t)b * 32 : nullptr;
     X.dbg_base = STAGE == 2 ? 16 : 0;
@@ -1037,14 +1080,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         for (int i = lane; i < A; i += 64) {
             bool fr = false;
             if (is_on_map(a_state[i]) && !a_dead[i]) {
-                const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
+                const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
                 if (bits == 0) fr = true;
                 const int r = a_pos[i] / W, c = a_pos[i] - r * W;
                 for (uint32_t m = 0; m < 4 && !fr; m++) {
                     if (!((bits >> (3 - m)) & 1)) continue;
                     const int nr = r + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = c + (m == 1 ? 1 : m == 3 ? -1 : 0);
                     if (nr < 0 || nc < 0 || nr >= H || nc >= W) { fr = true; continue; }
-                    const uint32_t sl = cellw[nr * W + nc] >> 16;
+                    const uint32_t sl = cw_slot(X, nr * W + nc);
                     if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
                 }
             }
@@ -1055,11 +1098,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             bool changed = false;
             for (int i = lane; i < A; i += 64) {
                 if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
-                    const uint32_t bits = nibble(cellw[a_pos[i]] & 0xFFFFu, a_dir[i]);
+                    const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
                     bool fr = false;
                     for (uint32_t m = 0; m < 4 && !fr; m++) {
                         if (!((bits >> (3 - m)) & 1)) continue;
-                        const uint32_t sl = cellw[step_cell(a_pos[i], m, W)] >> 16;
+                        const uint32_t sl = cw_slot(X, step_cell(a_pos[i], m, W));
                         const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
                         if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
                     }
@@ -1094,7 +1137,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             // valid-action mask (loader.cpp:273-312)
             uint32_t va = 0;
-            const uint32_t cell = pos >= 0 ? (cellw[pos] & 0xFFFFu) : 0;
+            const uint32_t cell = pos >= 0 ? cw_bits(X, pos) : 0;
             if (state == ST_MOVING || state == ST_STOPPED) {
                 if (scount == 0) {
                     const uint32_t bits = nibble(cell, dir);
@@ -1105,7 +1148,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         if ((bits >> (3 - nd)) & 1) {
                             va |= 1u << a;
                             cnt++;
-                            if (__popc(cellw[step_cell(pos, nd, W)] & 0xFFFFu) > 2) has_branch = true;
+                            if (__popc(cw_bits(X, step_cell(pos, nd, W))) > 2) has_branch = true;
                         }
                     }
                     if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
@@ -1439,7 +1482,8 @@ static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs 
     const size_t HW = (size_t)d.H * d.W, A = d.A;
     const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al(HW * 4) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 6 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
+    const size_t HC = (size_t)obs_hash_cap(d.A);
+    return (csr_lds ? al(HW * 4) + 16 + 2 * al(A * 4) : al(HW * 2) + 3 * al(HC * 4)) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 4 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
            al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
            al(csr_lds && items ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + (partial_own ? al((size_t)nt * 4) : 0) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
            al((size_t)nh_words * 2) + al(dual ? (K + 1) * 4 : 16) + al(dual && use_tmask ? (K + 1) * 8 : 16) +
