@@ -498,6 +498,13 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][32] */) {
     return FL_OK;
 }
 
+// diagnostic (not part of the public header): threads, LDS bytes, keys in LDS, next-hop in LDS, work-list bytes, time masks,
+// second index, items in LDS of the fused observation launch on this batch
+extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out8) {
+    NEED_COMMIT(h);
+    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out8);
+}
+
 double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {
     if (!h) return 0.0;
     // DESIGN.md "algorithmic bytes": compulsory HBM traffic per agent-step with this SoA.

@@ -1590,3 +1590,17 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
     return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
 }
+
+// diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth)
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[8]) {
+    ObsArgs P = {};
+    P.pred_depth = pred_depth; P.max_depth = max_depth; P.tree_pred = tree_pred;
+    P.tw_c = F_WORDS * 32;
+    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
+    P.tpw_t = max_depth <= 2 ? 2 : 1;
+    bool csr_lds; int nt; size_t lds;
+    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
+    out[0] = nt; out[1] = (int)lds; out[2] = csr_lds; out[3] = P.nh_lds_words > 0; out[4] = P.wl_bytes; out[5] = P.use_tmask;
+    out[6] = P.dual_index; out[7] = P.items_lds;
+    return FL_OK;
+}

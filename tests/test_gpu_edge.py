@@ -268,3 +268,26 @@ def test_fused_step_after_episode_end_raises_like_the_reference():
     env.step_obs(np.zeros((1, env.A), dtype=np.uint8))
     with pytest.raises(EpisodeDoneError):
         env.check()
+
+
+@pytest.mark.parametrize("workload,expect", [
+    # threads, keys in LDS, time masks, second index of the fused launch -- the LDS budget is tight: a few hundred bytes more
+    # per workgroup silently cost a configuration (and 20 % throughput) once
+    ("cfg2", dict(nt=1024, csr=1, tmask=1, dual=1)),
+    ("cfg3", dict(nt=1024, csr=1, tmask=1, dual=0)),
+    ("cfg4", dict(nt=1024, csr=1, tmask=1, dual=0)),
+    ("cfg5", dict(nt=1024, csr=0, tmask=0, dual=0)),
+])
+def test_observation_launch_configuration_of_the_bench_workloads(workload, expect):
+    import ctypes
+    from flatland_marl_amd import workload as wl
+    from flatland_marl_amd import hip_backend as hb
+    envs, _ = wl.make_envs(workload, B=1)
+    env = _env(envs)
+    L = hb.lib()
+    L.fl_debug_obs_config.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = (ctypes.c_int * 8)()
+    assert L.fl_debug_obs_config(env.h, 500, 2, 30, out) == 0
+    got = dict(nt=out[0], csr=out[2], tmask=out[5], dual=out[6])
+    assert got == expect, (workload, list(out))
+    assert out[1] <= 160 * 1024
