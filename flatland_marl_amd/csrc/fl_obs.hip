@@ -619,7 +619,7 @@ struct ObsArgs {
 // every row that is not a real node is -inf.
 template <int TEAM, int CAP, bool ITL>
 __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                              int nwaves, int *wave_scr0, int *team_meta, const uint32_t *cellw,
+                                              int nwaves, int *wave_scr0, int *team_meta,
                                               const int *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
                                               const double *a_speed, const int *a_tslot) {
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
@@ -719,7 +719,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 // lanes per agent, two teams per wavefront.  Only wave-level synchronisation, so a wavefront can run it whenever the
 // rail bitmap and the agent snapshot are in LDS (the workgroup overlaps it with the path walk of phase 2).
 __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
-                                              int gl, int *scr, const uint32_t *cellw, const int *a_vpos, const int *a_pos,
+                                              int gl, int *scr, const int *a_vpos, const int *a_pos,
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
                                               const int *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
     constexpr int CAP = 32;
@@ -807,7 +807,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
 template <bool ITL>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                             int nwaves, int *wave_scr, int *team_meta, const uint32_t *cellw,
+                                             int nwaves, int *wave_scr, int *team_meta,
                                              const int *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const int *a_tslot,
                                              float max_dist, bool hoisted) {
@@ -836,7 +836,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                 node_base = team_meta[64 + wave * 2 + grp];
                 levels = team_meta[192 + wave * 2 + grp];
             } else {
-                cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, node_base, levels);
+                cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, node_base, levels);
             }
             TREE_STAMP(X, 6);
             {
@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (CUTILS) {
             const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
             int node_base, levels;
-            cutils_pass_a(X, d, P, b, team_id, team_id < A, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32), cellw,
+            cutils_pass_a(X, d, P, b, team_id, team_id < A, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32),
                           a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T, node_base, levels);
             if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
         }
@@ -1430,14 +1430,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (CUTILS) {
-        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
-        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
     } else if (P.max_depth <= 2) {
-        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     } else {
-        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, cellw, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     }
     OBS_STAMP(5);
 }
