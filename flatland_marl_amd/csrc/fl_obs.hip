@@ -19,6 +19,7 @@
 #include "fl_obs.h"
 
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,6 +29,9 @@
 #define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
 #ifndef CF_CHUNK
 #define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
+#endif
+#ifndef OBS_GLB_BATCH
+#define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
 #endif
 #ifndef OBS_WL_OCC_DIV
 #define OBS_WL_OCC_DIV 6            // occupant work list = 1 / OBS_WL_OCC_DIV of the work-list entries, conflicts get the rest
@@ -215,21 +219,24 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, 
         const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
         flags |= (a != handle ? in : 0u) | (cnd ? in << 3 : 0u);
     };
-    // the key's list is short and unsorted: scan it with four independent loads in flight, most items fall out at the
+    // the key's list is short and unsorted: scan it with NB independent loads in flight, most items fall out at the
     // interval test (sorting the lists costs more than it saves)
-    auto scan = [&](const uint32_t *items) __attribute__((always_inline)) {
-        for (int e0 = lo; e0 < hi; e0 += 4) {
-            uint32_t itv[4];
+    auto scan = [&](const uint32_t *items, auto nb) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nb)::value;
+        for (int e0 = lo; e0 < hi; e0 += NB) {
+            uint32_t itv[NB];
 #pragma unroll
-            for (int q = 0; q < 4; q++) itv[q] = items[min(e0 + q, hi - 1)];
+            for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, hi - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < NB; q++)
                 if (e0 + q < hi) test_item(itv[q]);
         }
     };
-    // two call sites so that each keeps a static address space (LDS vs HBM scratch)
-    if (ITL) scan(X.items_lds);
-    else scan(X.items_glb);
+    // separate call sites so that each keeps a static address space; whole lists in HBM scratch (large maps without time
+    // masks) are fetched in bigger batches: their round trips are what the scan costs
+    if (ITL) scan(X.items_lds, std::integral_constant<int, 4>());
+    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, 4>());  // chunked work-list entries: short ranges
+    else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
     return flags;
 }
 // the other-agent test takes the first time (pt, pt - 1, pt + 1) at which somebody else is predicted on the cell
