@@ -209,7 +209,31 @@ int fl_commit(fl_batch *h) {
     UPLOAD(d.grid, h->h_grid); UPLOAD(d.ut, ut);
     UPLOAD(d.init_pos, h->h_init_pos); UPLOAD(d.target, h->h_target); UPLOAD(d.earliest, h->h_earliest);
     UPLOAD(d.latest, h->h_latest); UPLOAD(d.tslot, h->h_tslot); UPLOAD(d.spk, h->h_spk); UPLOAD(d.speed, h->h_speed);
-    HIPCHK(hipStreamSynchronize(h->stream));  // `ut` is a local
+    // rail-cell compaction table
+    std::vector<int> rcount(B, 0);
+    int Rmax = 1;
+    for (int b = 0; b < B; b++) {
+        int r = 0;
+        for (size_t c = 0; c < HW; c++) r += h->h_grid[(size_t)b * HW + c] != 0;
+        rcount[b] = r;
+        Rmax = r > Rmax ? r : Rmax;
+    }
+    d.Rmax = Rmax;
+    DALLOC(d.R, B);
+    UPLOAD(d.R, rcount);
+    d.ridx = nullptr;
+    std::vector<uint16_t> ridx;
+    if (Rmax <= 65534) {
+        DALLOC(d.ridx, B * HW);
+        ridx.assign((size_t)B * HW, 0xFFFF);
+        for (int b = 0; b < B; b++) {
+            int r = 0;
+            for (size_t c = 0; c < HW; c++)
+                if (h->h_grid[(size_t)b * HW + c] != 0) ridx[(size_t)b * HW + c] = (uint16_t)r++;
+        }
+        UPLOAD(d.ridx, ridx);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));  // `ut` and the compaction table are locals
     fl_launch_distance_maps(d, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_segments(d, h->stream);

@@ -64,6 +64,10 @@ struct FlDev {
     int *ut;         // [B][Umax] unique target cells
     uint2 *seg;      // [B][H*W*4] static branch-walk table per (cell, orientation), see fl_dmap.hip k_segments
     uint16_t *nh;    // [B][Umax][H*W] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
+    // rail-cell compaction (built on the host at commit): index of a cell among the env's rail cells in row-major order
+    int Rmax;        // most rail cells of any env
+    int *R;          // [B] rail cells of the env
+    uint16_t *ridx;  // [B][H*W], 0xFFFF = no rail; nullptr if Rmax > 65534
     uint32_t *hop8;  // [B][Umax][H*W*4] state after eight greedy hops, FL_HOP_NONE if the path ends earlier (k_hop8)
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;

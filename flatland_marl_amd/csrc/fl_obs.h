@@ -13,7 +13,8 @@ struct FlObsScratch {
     int keys;          // prediction keys per env: (W - 1) * W + H (key = col * W + row, tool.h:391-398)
     int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index (used when they do not fit LDS)
     long long *dbg;    // [B][32] phase clocks of diagnostic builds (-DFL_OBS_TIMING)
-    uint32_t *cell_items;  // [B][A * pred_cap] prediction items (IT_* packing, fl_obs.hip) when they do not fit LDS
+    uint32_t *cell_items;  // [B][items_cap] prediction items (IT_* packing, fl_obs.hip) when they do not fit LDS
+    size_t items_cap;
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);

@@ -30,6 +30,8 @@
 #ifndef CF_CHUNK
 #define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
 #endif
+#define OBS_NBK 8                    // time buckets per rail cell of the HBM-resident prediction index (large maps)
+#define OBS_BK_SHIFT 6                // ... of 64 steps each (the last one takes the rest)
 #ifndef OBS_GLB_BATCH
 #define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
 #endif
@@ -74,6 +76,7 @@ struct ObsCtx {
     const uint16_t *a_tpc;        // times per cell of the predictor
     const int *a_tslot;
     const int *a_target;
+    const uint16_t *bk_ridx;      // HBM [HW]: large maps key the index by (rail index, time bucket) instead of the cell; nullptr = by cell
     const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
@@ -244,6 +247,18 @@ __device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f 
 
 template <bool CUTILS, int CAP, bool ITL>
 __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
+    if (!ITL && X.bk_ridx) {  // (rail index, time bucket) lists: only the buckets the queried times fall in
+        const int kb = (int)X.bk_ridx[cell] * OBS_NBK;
+        const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_NBK - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_NBK - 1);
+        uint32_t f = 0;
+        for (int bb = b1; bb <= b2; bb++) {
+            const int kk = kb + bb;
+            const int hi = X.csr_end[kk], lo = kk > 0 ? X.csr_end[kk - 1] : 0;
+            if (hi > lo) f |= conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi);
+        }
+        if (conflict_hit(f)) atomicMin(&sc[F_PC * CAP + node], tot);
+        return;
+    }
     const int key = key_of(X, cell);
     const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
     if (hi <= lo) return;
@@ -417,7 +432,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                         const unsigned long long qm = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
                         cand = (X.tmask[key] & qm) != 0ull;
                     } else {
-                        cand = X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);
+                        cand = X.bk_ridx ? true : X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);  // bucketed: conflict_event looks
                     }
                 }
             }
@@ -1066,7 +1081,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
-    uint32_t *csr_items = S.cell_items + (size_t)b * A * S.pred_cap;
+    uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
+    // large maps (keys in HBM, cell keys injective): the index is keyed by (rail index, bucket of 64 time steps), which
+    // keeps the lists a conflict query scans short
+    const bool bk = !CSR_LDS && keycell && d.ridx != nullptr;
+    const uint16_t *g_ridx = bk ? d.ridx + (size_t)b * HW : nullptr;
+    const int KX = bk ? d.R[b] * OBS_NBK : K;  // csr keys of this env
+    X.bk_ridx = g_ridx;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
@@ -1231,7 +1252,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : 2;
         if (!reuse) {
-            for (int k = tid; k <= K; k += nt) csr[k] = 0;
+            for (int k = tid; k <= KX; k += nt) csr[k] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
@@ -1314,6 +1335,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i];
             const int lp2 = dual ? (int)a_lp2[i] : -1;
+            if (bk) {  // one count per time bucket the waypoint's interval touches
+                const int tpc = a_tpc[i], tlast = X.Tn - 1;
+                for (int k = lane; k <= lp; k += 64) {
+                    const int tlo = CUTILS ? (k == 0 ? 0 : (k - 1) * tpc + 1) : k * tpc, span = (CUTILS && k == 0) ? 1 : tpc;
+                    const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
+                    const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
+                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr[kb + bb], 1);
+                }
+                continue;
+            }
             for (int k = lane; k <= lp; k += 64) {
                 const int key = key_of(X, (int)(path[k] >> 2));
                 atomicAdd(&csr[key], 1);
@@ -1333,6 +1364,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             for (int i = wave; i < A; i += (nt >> 6)) {
                 const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
                 const int lp = a_lp[i];
+                if (bk) {
+                    const int tpc = a_tpc[i], tlast = X.Tn - 1;
+                    for (int k = lane; k <= lp; k += 64) {
+                        const int tlo = k * tpc;
+                        const int thi = (k == lp || tlo + tpc - 1 >= tlast) ? tlast : tlo + tpc - 1;
+                        const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
+                        for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr[kb + bb], 1);
+                    }
+                    continue;
+                }
                 for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
             }
         }
@@ -1341,8 +1382,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan.  With the second
         // index both counts share the scan, 16 bits each (the launcher guarantees totals below 65536).
         if (!reuse) {
-            const int chunk = (K + 1 + nt - 1) / nt;
-            const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
+            const int chunk = (KX + 1 + nt - 1) / nt;
+            const int lo = min(tid * chunk, KX + 1), hi = min(lo + chunk, KX + 1);
             int sum = 0;
             for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
             partial[tid] = sum;
@@ -1369,10 +1410,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     csr[k] = run & 0xFFFF; csr2[k] = (int)((unsigned)run >> 16);
                     run += v;
                 }
-                if (hi == K + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
+                if (hi == KX + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
             } else {
                 for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
-                if (hi == K + 1 && lo < hi) misc[2] = run;                                        // total number of items
+                if (hi == KX + 1 && lo < hi) misc[2] = run;                                       // total number of items
             }
         }
         __syncthreads();
@@ -1404,6 +1445,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     span = tpc;
                 }
                 const bool to_end = k == lp || tlo + span - 1 >= tlast;
+                if (bk) {  // into the list of every time bucket the interval touches
+                    const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                                          ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                    const int thi = to_end ? tlast : tlo + span - 1, kb = (int)g_ridx[w >> 2] * OBS_NBK;
+                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++)
+                        csr_items[atomicAdd(&csr[kb + bb], 1)] = item;
+                    continue;
+                }
                 const int key = key_of(X, (int)(w >> 2));
                 if (X.tmask) {  // time buckets this item covers
                     const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
@@ -1465,11 +1514,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
     o.keys = d.H <= d.W ? d.H * d.W : (d.W - 1) * d.W + d.H;
+    o.items_cap = (size_t)d.A * o.pred_cap;
+    if (d.ridx && d.H <= d.W) {  // the (rail index, time bucket) keying of large maps: an item sits in every bucket it touches
+        if (d.Rmax * OBS_NBK > o.keys) o.keys = d.Rmax * OBS_NBK;
+        o.items_cap = (size_t)d.A * (2 * o.pred_cap + 2 * OBS_NBK);  // <= 2 buckets per item, <= 2 until-the-end items per agent
+    }
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;
     if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.path = (uint32_t *)p; allocs.push_back(p);
-    if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * o.items_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_head = (int *)p; allocs.push_back(p);
