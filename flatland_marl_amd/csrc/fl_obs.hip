@@ -30,8 +30,10 @@
 #ifndef CF_CHUNK
 #define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
 #endif
-#define OBS_NBK 8                    // time buckets per rail cell of the HBM-resident prediction index (large maps)
-#define OBS_BK_SHIFT 6                // ... of 64 steps each (the last one takes the rest)
+#ifndef OBS_NBK
+#define OBS_NBK 4                    // time buckets per rail cell of the HBM-resident prediction index (large maps)
+#define OBS_BK_SHIFT 7               // ... of 128 steps each (the last one takes the rest); 4 x 128 measured best at 150x150
+#endif
 #ifndef OBS_GLB_BATCH
 #define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
 #endif
@@ -1082,7 +1084,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
-    // large maps (keys in HBM, cell keys injective): the index is keyed by (rail index, bucket of 64 time steps), which
+    // large maps (keys in HBM, cell keys injective): the index is keyed by (rail index, bucket of 1 << OBS_BK_SHIFT time steps), which
     // keeps the lists a conflict query scans short
     const bool bk = !CSR_LDS && keycell && d.ridx != nullptr;
     const uint16_t *g_ridx = bk ? d.ridx + (size_t)b * HW : nullptr;
