@@ -239,9 +239,31 @@ __global__ __launch_bounds__(256) void k_hop8(FlDev d) {
     d.hop8[idx] = ok ? (((uint32_t)cell << 2) | dd) : FL_HOP_NONE;
 }
 
+// hop8 restricted to rail states and expressed in rail-state space (see FlDev::chop8)
+__global__ __launch_bounds__(256) void k_chop8(FlDev d) {
+    const int HW = d.H * d.W;
+    const long long per = (long long)d.Rmax * 4;
+    const long long n = (long long)d.B * d.Umax * per;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const long long bu = idx / per;
+    const int b = (int)(bu / d.Umax), rs = (int)(idx % per);
+    uint16_t out = 0xFFFF;
+    if ((rs >> 2) < d.R[b]) {
+        const uint32_t cell = d.rcell[(size_t)b * d.Rmax + (rs >> 2)];
+        const uint32_t s8 = d.hop8[bu * ((long long)HW * 4) + ((long long)cell << 2 | (rs & 3))];
+        if (s8 != FL_HOP_NONE) out = (uint16_t)(((uint32_t)d.ridx[(size_t)b * HW + (s8 >> 2)] << 2) | (s8 & 3u));
+    }
+    d.chop8[idx] = out;
+}
+
 void fl_launch_hop8(const FlDev &d, hipStream_t s) {
     const long long n = (long long)d.B * d.Umax * d.H * d.W * 4;
     hipLaunchKernelGGL(k_hop8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+    if (d.chop8) {
+        const long long nc = (long long)d.B * d.Umax * d.Rmax * 4;
+        hipLaunchKernelGGL(k_chop8, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, d);
+    }
 }
 
 void fl_launch_nexthop(const FlDev &d, hipStream_t s) {

@@ -221,17 +221,26 @@ int fl_commit(fl_batch *h) {
     d.Rmax = Rmax;
     DALLOC(d.R, B);
     UPLOAD(d.R, rcount);
-    d.ridx = nullptr;
+    d.ridx = nullptr; d.rcell = nullptr; d.chop8 = nullptr;
     std::vector<uint16_t> ridx;
+    std::vector<uint32_t> rcell;
     if (Rmax <= 65534) {
         DALLOC(d.ridx, B * HW);
+        DALLOC(d.rcell, (size_t)B * Rmax);
         ridx.assign((size_t)B * HW, 0xFFFF);
+        rcell.assign((size_t)B * Rmax, 0);
         for (int b = 0; b < B; b++) {
             int r = 0;
             for (size_t c = 0; c < HW; c++)
-                if (h->h_grid[(size_t)b * HW + c] != 0) ridx[(size_t)b * HW + c] = (uint16_t)r++;
+                if (h->h_grid[(size_t)b * HW + c] != 0) {
+                    rcell[(size_t)b * Rmax + r] = (uint32_t)c;
+                    ridx[(size_t)b * HW + c] = (uint16_t)r++;
+                }
         }
         UPLOAD(d.ridx, ridx);
+        UPLOAD(d.rcell, rcell);
+        // the rail-state copy of the eight-hop table pays off where the full table falls out of the caches
+        if (Rmax * 4 <= 65534 && fl_obs_large_map(h->H, h->W)) DALLOC(d.chop8, (size_t)B * Umax * Rmax * 4);
     }
     HIPCHK(hipStreamSynchronize(h->stream));  // `ut` and the compaction table are locals
     fl_launch_distance_maps(d, h->stream);

@@ -68,6 +68,9 @@ struct FlDev {
     int Rmax;        // most rail cells of any env
     int *R;          // [B] rail cells of the env
     uint16_t *ridx;  // [B][H*W], 0xFFFF = no rail; nullptr if Rmax > 65534
+    uint32_t *rcell; // [B][Rmax] cell of rail index r (with ridx)
+    uint16_t *chop8; // [B][Umax][Rmax*4] hop8 in rail-state space (rail index * 4 + orientation, 0xFFFF = none): 16x smaller at
+                     // 150x150, so the path walk of large maps gathers from the last-level cache; nullptr when not built
     uint32_t *hop8;  // [B][Umax][H*W*4] state after eight greedy hops, FL_HOP_NONE if the path ends earlier (k_hop8)
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
@@ -126,7 +129,7 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
 void fl_launch_segments(const FlDev &d, hipStream_t s);
 void fl_launch_nexthop(const FlDev &d, hipStream_t s);
-void fl_launch_hop8(const FlDev &d, hipStream_t s);  // after fl_launch_nexthop
+void fl_launch_hop8(const FlDev &d, hipStream_t s);  // also the rail-state copy (chop8) when allocated  // after fl_launch_nexthop
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
                            long long *no_out, long long *eo_out, hipStream_t s);

@@ -1298,6 +1298,22 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (nh_in_lds) lead_in(nh_lds + (size_t)u * HW);
             else lead_in(gnh + (size_t)u * HW);
             int idx = j, last = -1;
+            if (!CSR_LDS && d.chop8) {
+                // large maps: jump in rail-state space through the 16x smaller table (the waypoints are translated back
+                // to cells off the dependent chain)
+                const uint16_t *c8 = d.chop8 + ((size_t)b * d.Umax + u) * d.Rmax * 4;
+                const uint32_t *rc = d.rcell + (size_t)b * d.Rmax;
+                uint32_t rs = alive ? (((uint32_t)d.ridx[(size_t)b * HW + (st >> 2)] << 2) | (st & 3u)) : 0u;
+                while (__any(alive)) {
+                    if (alive) {
+                        path[idx] = (rc[rs >> 2] << 2) | (rs & 3u);
+                        last = idx;
+                        const uint32_t sn = idx + 8 < n_max ? (uint32_t)c8[rs] : 0xFFFFu;
+                        if (sn == 0xFFFFu) alive = false;
+                        else { rs = sn; idx += 8; }
+                    }
+                }
+            }
             while (__any(alive)) {
                 if (alive) {
                     path[idx] = st;
@@ -1513,6 +1529,11 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+bool fl_obs_large_map(int H, int W) {
+    const size_t K = H <= W ? (size_t)H * W : (size_t)(W - 1) * W + H;
+    return K > OBS_CSR_LDS_MAX_KEYS;
+}
+
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
     o.keys = d.H <= d.W ? d.H * d.W : (d.W - 1) * d.W + d.H;
