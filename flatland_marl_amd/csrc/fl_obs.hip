@@ -1090,6 +1090,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const uint16_t *g_ridx = bk ? d.ridx + (size_t)b * HW : nullptr;
     const int KX = bk ? d.R[b] * OBS_NBK : K;  // csr keys of this env
     X.bk_ridx = g_ridx;
+    // ... and its offsets are counted with LDS atomics in the place of the rail bitmap, which nothing reads while the
+    // index is built (the bitmap is staged again afterwards, the offsets go to HBM for the trees)
+    const bool csr_alias = bk && (size_t)(KX + 1) * 4 <= (size_t)HW * 2;
+    int *csr_w = csr_alias ? reinterpret_cast<int *>(cell16) : csr;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
@@ -1253,8 +1257,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
         const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : 2;
-        if (!reuse) {
-            for (int k = tid; k <= KX; k += nt) csr[k] = 0;
+        if (!reuse && !(csr_alias && STAGE != 2)) {  // (aliased: stage 0 / 1 still read the bitmap during the walk, see below)
+            for (int k = tid; k <= KX; k += nt) csr_w[k] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
@@ -1348,6 +1352,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
         }
         __syncthreads();
+        if (csr_alias) {
+            for (int k = tid; k <= KX; k += nt) csr_w[k] = 0;
+            __syncthreads();
+        }
         // waypoints per key: only those that can be occupied within the horizon enter the index
         for (int i = wave; i < A; i += (nt >> 6)) {
             const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
@@ -1359,7 +1367,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const int tlo = CUTILS ? (k == 0 ? 0 : (k - 1) * tpc + 1) : k * tpc, span = (CUTILS && k == 0) ? 1 : tpc;
                     const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
                     const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
-                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr[kb + bb], 1);
+                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr_w[kb + bb], 1);
                 }
                 continue;
             }
@@ -1388,7 +1396,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         const int tlo = k * tpc;
                         const int thi = (k == lp || tlo + tpc - 1 >= tlast) ? tlast : tlo + tpc - 1;
                         const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
-                        for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr[kb + bb], 1);
+                        for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr_w[kb + bb], 1);
                     }
                     continue;
                 }
@@ -1403,7 +1411,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int chunk = (KX + 1 + nt - 1) / nt;
             const int lo = min(tid * chunk, KX + 1), hi = min(lo + chunk, KX + 1);
             int sum = 0;
-            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
+            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr_w[k];
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
@@ -1430,7 +1438,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 }
                 if (hi == KX + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
             } else {
-                for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
+                for (int k = lo; k < hi; k++) { const int v = csr_w[k]; csr_w[k] = run; run += v; }  // csr[k] = start of key k
                 if (hi == KX + 1 && lo < hi) misc[2] = run;                                       // total number of items
             }
         }
@@ -1468,7 +1476,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                                           ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
                     const int thi = to_end ? tlast : tlo + span - 1, kb = (int)g_ridx[w >> 2] * OBS_NBK;
                     for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++)
-                        csr_items[atomicAdd(&csr[kb + bb], 1)] = item;
+                        csr_items[atomicAdd(&csr_w[kb + bb], 1)] = item;
                     continue;
                 }
                 const int key = key_of(X, (int)(w >> 2));
@@ -1494,6 +1502,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         __syncthreads();
+        if (csr_alias && !reuse) {
+            for (int k = tid; k <= KX; k += nt) csr[k] = csr_w[k];
+            __syncthreads();
+            for (int c = tid; c < HW; c += nt) cell16[c] = ggrid[c];
+            __syncthreads();
+        }
     }
 
     OBS_STAMP(4);
