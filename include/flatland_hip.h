@@ -15,6 +15,12 @@
  *                                         (flatland_cutils/src/main.cpp:17-22, treeobs.cpp:30-108, 612-640)
  *   fl_obs_tree                           flatland.envs.observations.TreeObsForRailEnv.get_many()
  *                                         (flatland/envs/observations.py:60-115)
+ *   fl_step_obs                           RailEnv.step() incl. the observations it returns (rail_env.py:634 -> :660-666)
+ *   fl_obs_cutils_tree                    both observation builders above in one launch
+ *   fl_info                               RailEnv.get_info_dict / action_required (rail_env.py:243-258, 452-468),
+ *                                         evaluator scores (flatland/evaluators/service.py:875-879, 900-913)
+ *   fl_policy_pack                        plfActor.get_feature + Network.modify_adjacency
+ *                                         (solution/plfActor.py:48-74, solution/nn/net_tree.py:105-116)
  *   fl_get_state / fl_get_rng             EnvAgent attribute reads (agent_utils.py:57-88), np_random.get_state()
  *
  * Conventions: plain pointers and sizes only.  Pointers named *_dev are DEVICE pointers (hipMalloc /
