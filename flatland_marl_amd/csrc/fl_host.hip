@@ -48,6 +48,7 @@ struct fl_batch {
     std::vector<double> h_speed;
     std::vector<uint64_t> h_thr;
     std::vector<uint8_t> h_loaded;
+    uint8_t *mask_dev;  // [B] staging of fl_reset's host mask (allocated once at commit)
     FlObsScratch obs;
 };
 
@@ -79,6 +80,12 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
     fl_batch *h = new fl_batch();
     h->B = B; h->A = A; h->H = H; h->W = W; h->device = device;
     h->committed = false;
+    h->mask_dev = nullptr;
+    if (fl_step_lds_bytes(A) > 160 * 1024) {
+        delete h;
+        set_err("fl_create: %d agents need %zu B of LDS per workgroup in the step kernel (limit 160 KiB)", A, fl_step_lds_bytes(A));
+        return FL_ERR_ARG;
+    }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         set_err("hipStreamCreate failed");
@@ -126,6 +133,7 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
                 int max_episode_steps, uint64_t malf_threshold, int malf_min, int malf_max, const uint32_t *mt_key,
                 int mt_pos) {
     if (!h || b < 0 || b >= h->B) { set_err("fl_load_env: env index out of range"); return FL_ERR_ARG; }
+    if (h->committed) { set_err("fl_load_env: handle already committed"); return FL_ERR_ARG; }
     const int A = h->A, H = h->H, W = h->W;
     const size_t HW = (size_t)H * W;
     if (mt_pos < 0 || mt_pos > 624) { set_err("fl_load_env: mt_pos out of range"); return FL_ERR_ARG; }
@@ -242,6 +250,8 @@ int fl_commit(fl_batch *h) {
         // the rail-state copy of the eight-hop table pays off where the full table falls out of the caches
         if (Rmax * 4 <= 65534 && fl_obs_large_map(h->H, h->W)) DALLOC(d.chop8, (size_t)B * Umax * Rmax * 4);
     }
+    DALLOC(h->mask_dev, B);
+    if (fl_step_prepare() != FL_OK) { set_err("fl_commit: hipFuncSetAttribute failed"); return FL_ERR_HIP; }
     HIPCHK(hipStreamSynchronize(h->stream));  // `ut` and the compaction table are locals
     fl_launch_distance_maps(d, h->stream);
     HIPCHK(hipGetLastError());
@@ -289,18 +299,17 @@ int fl_get_rng(fl_batch *h, uint32_t *mt_key, int32_t *mt_pos) {
 
 int fl_reset(fl_batch *h, const uint8_t *mask, int fresh) {
     NEED_COMMIT(h);
-    uint8_t *mask_dev = nullptr;
-    if (mask) {
-        HIPCHK(hipMalloc((void **)&mask_dev, h->B));
-        HIPCHK(hipMemcpyAsync(mask_dev, mask, h->B, hipMemcpyHostToDevice, h->stream));
-    }
+    // the mask goes through a device buffer owned by the handle (no allocation, no host synchronisation here: a copy from
+    // pageable memory returns once the source has been staged)
+    if (mask) HIPCHK(hipMemcpyAsync(h->mask_dev, mask, h->B, hipMemcpyHostToDevice, h->stream));
+    return fl_reset_dev(h, mask ? h->mask_dev : nullptr, fresh);
+}
+
+int fl_reset_dev(fl_batch *h, const uint8_t *mask_dev, int fresh) {
+    NEED_COMMIT(h);
     fl_launch_reset(h->d, mask_dev, fresh, h->stream);
     fl_obs_reset(h->obs, h->d, mask_dev, h->stream);
     HIPCHK(hipGetLastError());
-    if (mask_dev) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipFree(mask_dev));
-    }
     return FL_OK;
 }
 
@@ -430,6 +439,111 @@ int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed) {
             o[11] = PK_OLD_DIR(p) == 4 ? -1 : (int)PK_OLD_DIR(p);
         }
     }
+    return FL_OK;
+}
+
+int fl_get_state_aux(fl_batch *h, int32_t *aux) {
+    NEED_COMMIT(h);
+    if (!aux) { set_err("fl_get_state_aux: null buffer"); return FL_ERR_ARG; }
+    const size_t BA = (size_t)h->B * h->A;
+    std::vector<uint32_t> pk(BA);
+    HIPCHK(hipMemcpyAsync(pk.data(), h->d.pk, BA * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t g = 0; g < BA; g++) {
+        int32_t *o = aux + g * FL_AUX_COLS;
+        o[0] = PK_PREV(pk[g]) == 7 ? -1 : (int)PK_PREV(pk[g]);
+        o[1] = (int)PK_SIGMALF(pk[g]);
+        o[2] = (int)PK_DEADLOCK(pk[g]);
+        o[3] = (int)PK_DONE(pk[g]);
+    }
+    return FL_OK;
+}
+
+int fl_set_state(fl_batch *h, const int32_t *state, const int32_t *aux, const int32_t *elapsed, const uint8_t *done_all) {
+    NEED_COMMIT(h);
+    if (!state) { set_err("fl_set_state: null state"); return FL_ERR_ARG; }
+    const size_t BA = (size_t)h->B * h->A;
+    const int H = h->H, W = h->W;
+    std::vector<int> pos(BA), old_pos(BA), arrival(BA);
+    std::vector<uint32_t> malf(BA), pk(BA);
+    for (size_t g = 0; g < BA; g++) {
+        const int32_t *o = state + g * FL_STATE_COLS;
+        const int r = o[0], c = o[1], dir = o[2], st = o[3], mf = o[4], nmf = o[5], sc = o[6], sv = o[7], orow = o[9], ocol = o[10], od = o[11];
+        const bool on = r >= 0;
+        if ((on && (r >= H || c < 0 || c >= W)) || dir < 0 || dir > 3 || st < ST_WAITING || st > ST_DONE || mf < 0 || mf > 0xFFFF ||
+            nmf < 0 || nmf > 0xFFFF || sc < 0 || sc > 15 || sv < 0 || sv > 3 || od < -1 || od > 3 ||
+            (orow >= 0 && (orow >= H || ocol < 0 || ocol >= W))) {
+            set_err("fl_set_state: env %zu agent %zu: value out of range", g / h->A, g % h->A);
+            return FL_ERR_ARG;
+        }
+        // env_utils.state_position_sync_check (step_utils/env_utils.py:45-52)
+        if ((st >= ST_MOVING && st <= ST_MALF && !on) || (st <= ST_MALF_OFF && on)) {
+            set_err("fl_set_state: env %zu agent %zu: state %d does not match position", g / h->A, g % h->A, st);
+            return FL_ERR_STATE_SYNC;
+        }
+        pos[g] = on ? r * W + c : -1;
+        old_pos[g] = orow >= 0 ? orow * W + ocol : -1;
+        arrival[g] = o[8];
+        malf[g] = (uint32_t)mf | ((uint32_t)nmf << 16);
+        int prev = 7, sig = mf > 0, dead = 0, done = st == ST_DONE;
+        if (aux) {
+            const int32_t *x = aux + g * FL_AUX_COLS;
+            if (x[0] < -1 || x[0] > ST_DONE || (x[1] | x[2] | x[3]) < 0 || x[1] > 1 || x[2] > 1 || x[3] > 1) {
+                set_err("fl_set_state: env %zu agent %zu: aux value out of range", g / h->A, g % h->A);
+                return FL_ERR_ARG;
+            }
+            prev = x[0] < 0 ? 7 : x[0]; sig = x[1]; dead = x[2]; done = x[3];
+        }
+        pk[g] = pk_make((uint32_t)dir, od < 0 ? 4u : (uint32_t)od, (uint32_t)st, (uint32_t)prev, (uint32_t)sv, (uint32_t)sc,
+                        (uint32_t)sig, (uint32_t)dead, (uint32_t)done);
+    }
+    if (elapsed)
+        for (int b = 0; b < h->B; b++)
+            if (elapsed[b] < 0) { set_err("fl_set_state: negative elapsed steps"); return FL_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(h->d.pos, pos.data(), BA * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d.old_pos, old_pos.data(), BA * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d.arrival, arrival.data(), BA * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d.malf, malf.data(), BA * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d.pk, pk.data(), BA * 4, hipMemcpyHostToDevice, h->stream));
+    if (elapsed) HIPCHK(hipMemcpyAsync(h->d.t, elapsed, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    if (done_all) HIPCHK(hipMemcpyAsync(h->d.done_all, done_all, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the staging vectors are locals
+    return FL_OK;
+}
+
+int fl_motion_check(int device, int n_cases, const int32_t *offsets, const int32_t *cur, const int32_t *nxt, uint8_t *can_move) {
+    if (n_cases <= 0 || !offsets || !cur || !nxt || !can_move) { set_err("fl_motion_check: bad argument"); return FL_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("fl_motion_check: no HIP device visible"); return FL_ERR_HIP; }
+    int max_agents = 0;
+    for (int c = 0; c < n_cases; c++) {
+        const int n = offsets[c + 1] - offsets[c];
+        if (n < 0 || n > 1024) { set_err("fl_motion_check: case %d has %d agents (0..1024 supported)", c, n); return FL_ERR_ARG; }
+        max_agents = n > max_agents ? n : max_agents;
+    }
+    const int total = offsets[n_cases] - offsets[0];
+    for (int k = offsets[0]; k < offsets[n_cases]; k++)
+        if (cur[k] < -1 || nxt[k] < -1 || cur[k] >= (1 << 28) || nxt[k] >= (1 << 28)) { set_err("fl_motion_check: cell id out of range"); return FL_ERR_ARG; }
+    if (offsets[0] != 0) { set_err("fl_motion_check: offsets must start at 0"); return FL_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    int *d_off = nullptr, *d_cur = nullptr, *d_nxt = nullptr;
+    uint8_t *d_out = nullptr;
+    const size_t nb = (size_t)(total > 0 ? total : 1);
+    hipError_t e = hipMalloc((void **)&d_off, (size_t)(n_cases + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, nb * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_nxt, nb * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, nb);
+    if (e == hipSuccess) e = hipMemcpy(d_off, offsets, (size_t)(n_cases + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && total > 0) e = hipMemcpy(d_cur, cur, nb * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && total > 0) e = hipMemcpy(d_nxt, nxt, nb * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        fl_launch_motion_check(n_cases, max_agents, d_off, d_cur, d_nxt, d_out, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && total > 0) e = hipMemcpy(can_move, d_out, nb, hipMemcpyDeviceToHost);
+    (void)hipFree(d_off); (void)hipFree(d_cur); (void)hipFree(d_nxt); (void)hipFree(d_out);
+    if (e != hipSuccess) { set_err("fl_motion_check: %s", hipGetErrorString(e)); return FL_ERR_HIP; }
     return FL_OK;
 }
 

@@ -135,5 +135,9 @@ void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_
                            long long *no_out, long long *eo_out, hipStream_t s);
 void fl_launch_info(const FlDev &d, uint8_t *action_required, int32_t *malfunction, uint8_t *state, double *scores, hipStream_t s);
 void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStream_t s);
+void fl_launch_motion_check(int n_cases, int max_agents, const int *offsets, const int *cur, const int *nxt, uint8_t *can_move,
+                            hipStream_t s);
+size_t fl_step_lds_bytes(int A);
+int fl_step_prepare();
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s);

@@ -113,6 +113,50 @@ void fl_launch_reset(const FlDev &d, const uint8_t *mask_dev, int fresh, hipStre
     hipLaunchKernelGGL(k_reset, dim3((n + 255) / 256), dim3(256), 0, s, d, mask_dev, fresh);
 }
 
+// MotionCheck alone on caller-supplied (current cell, wanted cell) lists: one workgroup per case, the same device function
+// the step uses (fl_step_body.h motion_check_cells).
+__global__ __launch_bounds__(1024) void k_motion_check(const int *__restrict__ offsets, const int *__restrict__ cur,
+                                                       const int *__restrict__ nxt, uint8_t *__restrict__ can_move, int S,
+                                                       int sshift) {
+    extern __shared__ uint32_t lds_raw[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lo = offsets[blockIdx.x], A = offsets[blockIdx.x + 1] - lo;
+    StepLds L;
+    L.mtl = nullptr; L.words = nullptr;
+    L.hkey = (int *)lds_raw; L.hocc = L.hkey + S; L.hwin = L.hocc + S; L.hcnt = L.hwin + S; L.hblk = L.hcnt + S;
+    L.a_cur = L.hblk + S; L.a_nxt = L.a_cur + nt; L.misc = L.a_nxt + nt;
+    for (int k = tid; k < S; k += nt) { L.hkey[k] = -1; L.hocc[k] = -1; L.hwin[k] = 0x7fffffff; L.hcnt[k] = 0; L.hblk[k] = 0; }
+    if (tid < 16) L.misc[tid] = 0;
+    __syncthreads();
+    const bool act = tid < A;
+    const int pos = act ? cur[lo + tid] : -1, np_pos = act ? nxt[lo + tid] : -1;
+    const bool blocked = motion_check_cells(L, act, tid, A, pos, np_pos, 1 << 28, S - 1, sshift, tid);
+    if (act) can_move[lo + tid] = blocked ? 0 : 1;
+}
+
+void fl_launch_motion_check(int n_cases, int max_agents, const int *offsets, const int *cur, const int *nxt, uint8_t *can_move,
+                            hipStream_t s) {
+    int nt = ((max_agents + 63) / 64) * 64;
+    if (nt < 64) nt = 64;
+    const StepGeom q = step_geom(max_agents);
+    const size_t lds = ((size_t)5 * q.S + 2 * nt + 16) * 4;
+    (void)hipFuncSetAttribute((const void *)k_motion_check, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_motion_check, dim3(n_cases), dim3(nt), lds, s, offsets, cur, nxt, can_move, q.S, q.sshift);
+}
+
+// more than 64 KiB of dynamic LDS (A > 512) needs the attribute; set once per handle at commit, on the handle's device
+int fl_step_prepare() {
+    if (hipFuncSetAttribute((const void *)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
+    if (hipFuncSetAttribute((const void *)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
+    return FL_OK;
+}
+
+size_t fl_step_lds_bytes(int A) {
+    int nt = ((A + 63) / 64) * 64;
+    if (nt < 256) nt = 256;
+    return step_lds_words(A, nt) * 4;
+}
+
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s) {
     int nt = ((d.A + 63) / 64) * 64;

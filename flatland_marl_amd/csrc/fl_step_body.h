@@ -96,6 +96,65 @@ __device__ __forceinline__ int hash_insert(int *hkey, int cell, int smask, int s
     }
 }
 
+// MotionCheck (envs/agent_chains.py:19-236) restated on cells.  Nodes: an on-map cell id, or vbase + i for the private
+// virtual node of an off-map agent (:28-32).  Needs the cell hash table of L initialised (hkey -1, hocc -1, hwin INT_MAX,
+// hcnt 0, hblk 0) and misc[M_CHANGED] == 0; all nt lanes of the workgroup call it (lane i = agent i, act = i < A).
+// pos / np_pos: current and wanted cell, -1 = off map.  Returns "blocked" (check_motion == false).
+__device__ __forceinline__ bool motion_check_cells(StepLds &L, bool act, int i, int A, int pos, int np_pos, int vbase,
+                                                   int smask, int sshift, int tid) {
+    const int cur_node = act ? (pos < 0 ? vbase + i : pos) : -1;
+    const int nxt_node = act ? (np_pos < 0 ? vbase + i : np_pos) : -1;
+    L.a_cur[tid] = cur_node;
+    L.a_nxt[tid] = nxt_node;
+    int slot_c = -1, slot_n = -1;
+    if (act) {
+        if (pos >= 0) {
+            slot_c = hash_insert(L.hkey, pos, smask, sshift);
+            atomicMax(&L.hocc[slot_c], i);  // node attribute "agent" = last agent added on that cell (:34)
+            atomicAdd(&L.hcnt[slot_c], 1);
+        }
+        if (np_pos >= 0) slot_n = (np_pos == pos) ? slot_c : hash_insert(L.hkey, np_pos, smask, sshift);
+    }
+    __syncthreads();
+    const int key = (act && pos >= 0) ? L.hocc[slot_c] : i;
+    const bool wants_move = act && nxt_node != cur_node;
+    if (wants_move) atomicMin(&L.hwin[slot_n], key);  // lowest handle wins a contended cell (:190-195)
+    __syncthreads();
+    bool blocked = false;
+    if (act) {
+        if (!wants_move) blocked = true;  // self loop = stopped (:59-63)
+        else {
+            const int occ = L.hocc[slot_n];
+            if (occ >= 0) {  // 2-cycle swap (:107-117)
+                if (L.hcnt[slot_n] == 1) blocked = (L.a_nxt[occ] == cur_node);
+                else
+                    for (int j = 0; j < A; j++)
+                        if (L.a_cur[j] == nxt_node && L.a_nxt[j] == cur_node) blocked = true;
+            }
+            if (L.hwin[slot_n] != key) blocked = true;  // lost the contention (:176-202)
+        }
+        if (blocked && slot_c >= 0) L.hblk[slot_c] = 1;
+    }
+    __syncthreads();
+    // predecessors of a blocked cell are blocked, transitively (:125-149, :65-105); agents sharing a cell share its flag
+    while (true) {
+        if (act && !blocked) {
+            if ((slot_n >= 0 && L.hblk[slot_n]) || (slot_c >= 0 && L.hblk[slot_c])) {
+                blocked = true;
+                if (slot_c >= 0) L.hblk[slot_c] = 1;
+                L.misc[M_CHANGED] = 1;
+            }
+        }
+        __syncthreads();
+        const int ch = L.misc[M_CHANGED];
+        __syncthreads();
+        if (!ch) break;
+        if (tid == 0) L.misc[M_CHANGED] = 0;
+        __syncthreads();
+    }
+    return blocked;
+}
+
 // One RailEnv.step() of the workgroup's env (blockIdx.x): nt = blockDim.x >= A lanes, lds_raw = step_lds_words(A, nt)
 // words of LDS.  false: the episode was over and auto-reset is off (error code set, nothing done).
 template <bool SYNTH>
@@ -126,8 +185,15 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
     int was_done = d.done_all[b];
     const bool filter_required = (auto_reset & 2) != 0;  // flags: bit 0 auto reset, bit 1 eval_env.parse_actions filter
     auto_reset &= 1;
-    if (was_done && !auto_reset) {  // rail_env.py:508-509
-        if (tid == 0) atomicCAS(&d.err[b], 0, FL_ERR_EPISODE_DONE);
+    if (was_done && !auto_reset) {
+        // rail_env.py:505-509: _elapsed_steps is incremented, then the exception is raised.  The env's slice of the output
+        // tensors is defined too (no stale terminal rewards inside a batch): zero rewards, every done flag set.
+        if (act) { rewards[g] = 0; dones[g] = 1; }
+        if (tid == 0) {
+            d.t[b] = t + 1;
+            done_all_out[b] = 1;
+            atomicCAS(&d.err[b], 0, FL_ERR_EPISODE_DONE);
+        }
         return false;
     }
     const uint16_t *grid = d.grid + (size_t)b * HW;
@@ -237,58 +303,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         } else { np_pos = pos; np_dir = dir; }
     }
 
-    // ---- MotionCheck on cells (agent_chains.py), see header comment of resolve step below
-    // nodes: on-map cell id, or HW + i for the private virtual node of an off-map agent (:28-32)
-    const int cur_node = act ? (pos < 0 ? HW + i : pos) : -1;
-    const int nxt_node = act ? (np_pos < 0 ? HW + i : np_pos) : -1;
-    L.a_cur[tid] = cur_node;
-    L.a_nxt[tid] = nxt_node;
-    int slot_c = -1, slot_n = -1;
-    if (act) {
-        if (pos >= 0) {
-            slot_c = hash_insert(L.hkey, pos, smask, sshift);
-            atomicMax(&L.hocc[slot_c], i);  // node attribute "agent" = last agent added on that cell (:34)
-            atomicAdd(&L.hcnt[slot_c], 1);
-        }
-        if (np_pos >= 0) slot_n = (np_pos == pos) ? slot_c : hash_insert(L.hkey, np_pos, smask, sshift);
-    }
-    __syncthreads();
-    const int key = (act && pos >= 0) ? L.hocc[slot_c] : i;
-    const bool wants_move = act && nxt_node != cur_node;
-    if (wants_move) atomicMin(&L.hwin[slot_n], key);  // lowest handle wins a contended cell (:190-195)
-    __syncthreads();
-    bool blocked = false;
-    if (act) {
-        if (!wants_move) blocked = true;  // self loop = stopped (:59-63)
-        else {
-            const int occ = L.hocc[slot_n];
-            if (occ >= 0) {  // 2-cycle swap (:107-117)
-                if (L.hcnt[slot_n] == 1) blocked = (L.a_nxt[occ] == cur_node);
-                else
-                    for (int j = 0; j < A; j++)
-                        if (L.a_cur[j] == nxt_node && L.a_nxt[j] == cur_node) blocked = true;
-            }
-            if (L.hwin[slot_n] != key) blocked = true;  // lost the contention (:176-202)
-        }
-        if (blocked && slot_c >= 0) L.hblk[slot_c] = 1;
-    }
-    __syncthreads();
-    // predecessors of a blocked cell are blocked, transitively (:125-149, :65-105); agents sharing a cell share its flag
-    while (true) {
-        if (act && !blocked) {
-            if ((slot_n >= 0 && L.hblk[slot_n]) || (slot_c >= 0 && L.hblk[slot_c])) {
-                blocked = true;
-                if (slot_c >= 0) L.hblk[slot_c] = 1;
-                L.misc[M_CHANGED] = 1;
-            }
-        }
-        __syncthreads();
-        const int ch = L.misc[M_CHANGED];
-        __syncthreads();
-        if (!ch) break;
-        if (tid == 0) L.misc[M_CHANGED] = 0;
-        __syncthreads();
-    }
+    // ---- MotionCheck on cells (agent_chains.py:19-236)
+    const bool blocked = motion_check_cells(L, act, i, A, pos, np_pos, HW, smask, sshift, tid);
     const bool can_move = !blocked;
 
     // ---- phase 2 (rail_env.py:574-627)

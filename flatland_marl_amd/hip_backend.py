@@ -19,13 +19,14 @@ ERR_NAMES = {1: "FL_ERR_ARG", 2: "FL_ERR_HIP", 3: "FL_ERR_EPISODE_DONE", 4: "FL_
              5: "FL_ERR_ZERO_TRANSITION", 6: "FL_ERR_CAPACITY"}
 ACTION_ABSENT = 255
 STATE_COLS = 12
+AUX_COLS = 4
 STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved", "arrival",
                "old_row", "old_col", "old_dir")
 
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
-           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
+           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
+           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -56,6 +57,9 @@ def lib():
             raise FileNotFoundError(
                 "%s is missing: build it with flatland_marl_amd/csrc/build.sh (hipcc --offload-arch=gfx950); "
                 "there is no CPU fallback" % LIB_PATH)
+        # torch ships its own HIP runtime (same soname as /opt/rocm's): it has to be the one this process loads first,
+        # otherwise torch.cuda finds no device once the library below has pulled in the system runtime
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
         L.fl_last_error.restype = C.c_char_p
@@ -69,6 +73,10 @@ def lib():
         L.fl_set_rng.argtypes = [vp, vp, vp]
         L.fl_get_rng.argtypes = [vp, vp, vp]
         L.fl_reset.argtypes = [vp, vp, i32]
+        L.fl_reset_dev.argtypes = [vp, vp, i32]
+        L.fl_get_state_aux.argtypes = [vp, vp]
+        L.fl_set_state.argtypes = [vp, vp, vp, vp, vp]
+        L.fl_motion_check.argtypes = [i32, i32, vp, vp, vp, vp]
         L.fl_step.argtypes = [vp, vp, vp, vp, vp, i32]
         L.fl_step_synth.argtypes = [vp, u32, u32, i32, vp, vp, vp, i32]
         L.fl_check.argtypes = [vp]
@@ -108,6 +116,17 @@ def malf_threshold(rate):
         return 0
     p = float(1 - np.exp(-rate))
     return int(math.ceil(p * 2.0 ** 53))
+
+
+def motion_check(offsets, cur, nxt, device=0):
+    """MotionCheck (agent_chains.py:19-236) on independent agent lists through the step kernel's conflict resolution
+    (fl_motion_check): cur / nxt are cell ids or -1 (off the map); returns can_move as a bool array."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    cur = np.ascontiguousarray(cur, dtype=np.int32)
+    nxt = np.ascontiguousarray(nxt, dtype=np.int32)
+    out = np.zeros(max(len(cur), 1), dtype=np.uint8)
+    _chk(lib().fl_motion_check(int(device), len(offsets) - 1, _p(offsets), _p(cur), _p(nxt), _p(out)))
+    return out[:len(cur)].astype(bool)
 
 
 def policy_pack(adjacency, node_order, edge_order, adj_out, no_out, eo_out):
@@ -329,6 +348,30 @@ class BatchedRailEnv:
         el = np.zeros(self.B, dtype=np.int32)
         _chk(lib().fl_get_state(self.h, _p(st), _p(el)))
         return st, el
+
+    def state_aux(self):
+        """int32[B, A, 4]: previous_state (-1 = None), in_malfunction signal of the last step, deadlocked, done."""
+        aux = np.zeros((self.B, self.A, AUX_COLS), dtype=np.int32)
+        _chk(lib().fl_get_state_aux(self.h, _p(aux)))
+        return aux
+
+    def set_state(self, state, aux=None, elapsed=None, done_all=None):
+        """inject the dynamic agent state (fl_set_state): state int32[B, A, 12] as state() returns it."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        assert state.shape == (self.B, self.A, STATE_COLS)
+        keep = [state]
+        if aux is not None:
+            aux = np.ascontiguousarray(aux, dtype=np.int32)
+            assert aux.shape == (self.B, self.A, AUX_COLS)
+        if elapsed is not None:
+            elapsed = np.ascontiguousarray(elapsed, dtype=np.int32)
+            assert elapsed.shape == (self.B,)
+        if done_all is not None:
+            done_all = np.ascontiguousarray(done_all, dtype=np.uint8)
+            assert done_all.shape == (self.B,)
+        keep += [aux, elapsed, done_all]
+        _chk(lib().fl_set_state(self.h, _p(state), None if aux is None else _p(aux), None if elapsed is None else _p(elapsed),
+                                None if done_all is None else _p(done_all)))
 
     def rng_state(self):
         key = np.zeros((self.B, 624), dtype=np.uint32)

@@ -4,8 +4,10 @@ reference installed: the Round-2 test files (solution/debug-environments/generat
 into the batched env.
 
 The pickle refers to flatland classes (the Agent namedtuple of agent_utils.py:18-34, SpeedCounter, TrainStateMachine,
-...).  A restricted Unpickler maps every `flatland.*` global to an inert stand-in and refuses anything else that is not
-numpy / builtins, so loading a file never executes reference or third-party code.
+...).  A restricted Unpickler maps every `flatland.*` global to an inert stand-in and refuses everything else except a fixed
+allowlist: the four numpy constructors of array / scalar pickles (ndarray, dtype, _reconstruct, scalar) plus the dtype
+classes, a few inert builtins, copyreg._reconstructor and OrderedDict -- so loading a file never executes reference or
+third-party code (no other numpy callable is reachable).
 
 The MT19937 state of the env is NOT part of the format (the reference re-seeds at load); the caller supplies it.
 """
@@ -55,6 +57,11 @@ _SAFE_BUILTINS = {"tuple", "list", "dict", "set", "frozenset", "int", "float", "
                   "bytearray", "slice", "range", "object"}
 
 
+_NUMPY_ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"),
+                  ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+                  ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar")}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module.startswith("flatland."):
@@ -65,9 +72,14 @@ class _Unpickler(pickle.Unpickler):
             if name in ("MalfunctionProcessData", "MalfunctionParameters", "Malfunction"):
                 return _Tuple
             return type(name, (_Bag,), {})
-        if module in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric",
-                      "numpy._core.numeric", "numpy.dtypes"):
+        # numpy: ONLY the constructors an array / scalar pickle needs -- an explicit (module, name) allowlist, never a
+        # whole-module getattr (numpy.savetxt, numpy.load, ... are callables a REDUCE could reach)
+        if (module, name) in _NUMPY_ALLOWED:
             return getattr(__import__(module, fromlist=[name]), name)
+        if module == "numpy.dtypes" and name.endswith("DType") and name[:-5].isalnum():
+            cls = getattr(__import__(module, fromlist=[name]), name, None)
+            if isinstance(cls, type) and issubclass(cls, np.dtype):
+                return cls
         if module == "builtins" and name in _SAFE_BUILTINS:
             return getattr(__import__("builtins"), name)
         if (module, name) in (("copyreg", "_reconstructor"), ("collections", "OrderedDict")):

@@ -22,6 +22,9 @@
  *   fl_policy_pack                        plfActor.get_feature + Network.modify_adjacency
  *                                         (solution/plfActor.py:48-74, solution/nn/net_tree.py:105-116)
  *   fl_get_state / fl_get_rng             EnvAgent attribute reads (agent_utils.py:57-88), np_random.get_state()
+ *   fl_set_state / fl_get_state_aux       AgentsLoader's per-call read of a caller-owned env (flatland_cutils/src/loader.cpp:8-120,
+ *                                         221-327), RailEnvPersister.set_full_state (flatland/envs/persistence.py:182-222)
+ *   fl_motion_check                       MotionCheck.addAgent / find_conflicts / check_motion (flatland/envs/agent_chains.py:19-236)
  *
  * Conventions: plain pointers and sizes only.  Pointers named *_dev are DEVICE pointers (hipMalloc /
  * torch CUDA tensors), everything else is host memory.  All buffers are caller-owned; the library keeps
@@ -53,6 +56,7 @@ enum {
 #define FL_STEP_FILTER_REQUIRED 2
 #define FL_ACTION_ABSENT 255 /* agent missing from the action dict (rail_env.py:527 -> DO_NOTHING) */
 #define FL_STATE_COLS 12     /* row,col,dir,state,malf,nmalf,speed_counter,saved_action,arrival,old_row,old_col,old_dir */
+#define FL_AUX_COLS 4        /* prev_state (-1 = None), st_signals.in_malfunction of the last step, deadlocked, done */
 #define FL_CUTILS_ATTR 83
 #define FL_NODE_FEATURES 12
 
@@ -85,6 +89,8 @@ int fl_get_rng(fl_batch *h, uint32_t *mt_key, int32_t *mt_pos);
 /* Reset agents (not the RNG, not the maps).  mask: host u8[B] or NULL (= all).  fresh != 0 also clears
  * arrival_time (a freshly loaded env); fresh == 0 follows EnvAgent.reset() literally (agent_utils.py:90-105). */
 int fl_reset(fl_batch *h, const uint8_t *mask, int fresh);
+/* Same with the mask on the device (u8[B] or NULL), e.g. the done_all tensor of the last step: no host round trip. */
+int fl_reset_dev(fl_batch *h, const uint8_t *mask_dev, int fresh);
 
 /* One lock-step tick of all B envs.  actions_dev u8[B][A] (FL_ACTION_ABSENT allowed);
  * rewards_dev int32[B][A], dones_dev u8[B][A], done_all_dev u8[B].
@@ -150,6 +156,22 @@ int fl_policy_pack(int B, int A, int E, const int32_t *adjacency_dev, const int3
 
 /* Host read-backs (synchronising). state int32[B][A][FL_STATE_COLS]; elapsed int32[B]. */
 int fl_get_state(fl_batch *h, int32_t *state, int32_t *elapsed);
+/* The rest of the dynamic agent state, int32[B][A][FL_AUX_COLS]: state_machine.previous_state (-1 = None),
+ * state_machine.st_signals.in_malfunction as of the last step (read by flatland_cutils, loader.cpp:16-18), the sticky
+ * DeadlockChecker flag (deadlock_checker.cpp:3-114), dones[handle]. */
+int fl_get_state_aux(fl_batch *h, int32_t *aux);
+/* Inject the dynamic state of every agent: what AgentsLoader reads from a caller-owned env each call
+ * (flatland_cutils/src/loader.cpp:8-120, 221-327) and what RailEnvPersister.set_full_state restores
+ * (flatland/envs/persistence.py:182-222).  state int32[B][A][FL_STATE_COLS] as fl_get_state returns it; aux
+ * int32[B][A][FL_AUX_COLS] or NULL (= previous_state None, in_malfunction = malf > 0, not deadlocked, done = state DONE);
+ * elapsed int32[B] (_elapsed_steps) and done_all u8[B] (dones["__all__"]) or NULL (= unchanged).  Host arrays.
+ * A state / position mismatch is refused with FL_ERR_STATE_SYNC (step_utils/env_utils.py:45-52). */
+int fl_set_state(fl_batch *h, const int32_t *state, const int32_t *aux, const int32_t *elapsed, const uint8_t *done_all);
+/* MotionCheck alone (flatland/envs/agent_chains.py:19-236: addAgent for every agent in handle order, find_conflicts,
+ * check_motion) on n_cases independent agent lists: case c = agents offsets[c] .. offsets[c+1]-1 (offsets[0] = 0, at most
+ * 1024 agents per case); cur / nxt = current and wanted cell id (>= 0) or -1 for "off the map" (the reference's private
+ * virtual node (-1, i)); can_move u8 per agent.  Host arrays; runs the conflict resolution of the step kernel. */
+int fl_motion_check(int device, int n_cases, const int32_t *offsets, const int32_t *cur, const int32_t *nxt, uint8_t *can_move);
 /* distance map of env b: returns number of unique targets in *n_targets; dm u16[n][H][W][4] (0xFFFF = inf),
  * target_slot int32[A].  dm may be NULL to query n only. */
 int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot);

@@ -308,6 +308,85 @@ def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=
           f"arrived={arrived} malf_events={int(per_step['nmalf'][-1].sum())} -> {os.path.getsize(path)/1024:.0f} KB")
 
 
+def run_dense(name, test_id, level, seed, max_steps, snap_onmap, state_every=8, pytree=None, extra_snaps=()):
+    """Dense-traffic episode (large maps): a shortest-path-following stream replayed for max_steps steps.  The per-step
+    agent state is kept every `state_every` steps (and at every snapshot); flatland_cutils tensors and the upstream trees
+    are recorded the first time the number of on-map agents reaches each threshold of `snap_onmap`, at the steps listed in
+    `extra_snaps`, and at the last step.  The static env equals the `*_fwd_head` fixture of the same CSV row, so the
+    distance map is not stored again."""
+    row = csv_row(test_id, level)
+    env, mp = make_env(row)
+    obs, _ = env.reset()
+    A = env.get_num_agents()
+    out = static_arrays(env, mp)
+    d = dm_unique(env)
+    out["target_slot"], out["dm_targets"] = d["target_slot"], d["dm_targets"]
+    out["stream"] = np.array("spfollow")
+    out["stream_seed"] = np.int64(seed)
+    py_builders = {}
+    for (depth, pdepth) in (pytree or []):
+        b = PyTreeObs(max_depth=depth, predictor=ShortestPathPredictorForRailEnv(pdepth))
+        b.set_env(env)
+        b.reset()
+        py_builders[(depth, pdepth)] = b
+    rng = np.random.default_rng(seed)
+    thresholds = sorted(snap_onmap)
+    actions, state_steps, states, rewards, dones = [], [], [], [], []
+    obs_steps, obs_rec, py_rec, onmap_hist, aux_rec = [], {}, {k: [] for k in py_builders}, [], []
+    T = env._max_episode_steps
+    nsteps = min(T, max_steps)
+    t = 0
+    while t < nsteps and not env.dones["__all__"]:
+        ad = sp_follow_actions(env, rng)
+        actions.append(np.array([ad[i] for i in range(A)], dtype=np.uint8))
+        obs, rew, dn, info = env.step(ad)
+        t += 1
+        n_on = sum(1 for a in env.agents if a.position is not None)
+        onmap_hist.append(n_on)
+        snap = False
+        while thresholds and n_on >= thresholds[0]:
+            thresholds.pop(0)
+            snap = True
+        snap = snap or t in extra_snaps or t == nsteps or env.dones["__all__"]
+        if snap:
+            obs_steps.append(t)
+            for k, v in cutils_arrays(obs, env).items():
+                obs_rec.setdefault(k, []).append(v)
+            for k, b in py_builders.items():
+                py_rec[k].append(pytree_arrays(b, env, k[0]))
+            # the rest of the dynamic state a replacement needs to resume from here (fl_set_state's aux columns)
+            dead = obs_rec["p_deadlocked"][-1]
+            aux_rec.append(np.array([[-1 if a.state_machine.previous_state is None else int(a.state_machine.previous_state),
+                                      int(bool(a.state_machine.st_signals.in_malfunction)), int(dead[i]), int(dn[i])]
+                                     for i, a in enumerate(env.agents)], dtype=np.int32))
+            print(f"  {name}: snapshot at t={t}, {n_on} of {A} agents on the map", flush=True)
+        if snap or t % state_every == 0:
+            state_steps.append(t)
+            s = agent_snapshot(env)
+            states.append(np.stack([s[k] for k in ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved", "arrival",
+                                                   "old_row", "old_col", "old_dir")], axis=1).astype(np.int32))
+            rewards.append(np.array([rew[i] for i in range(A)], dtype=np.int32))
+            dones.append(np.array([dn[i] for i in range(A)], dtype=np.uint8))
+        if t % 50 == 0:
+            print(f"  {name}: t={t} on map {n_on}", flush=True)
+    out["actions"] = np.stack(actions)
+    out["state_steps"] = np.array(state_steps, dtype=np.int32)     # 1-based: state AFTER that many steps
+    out["states"] = np.stack(states)                                # [n, A, 12] in hip_backend.STATE_NAMES order
+    out["rewards"] = np.stack(rewards)
+    out["dones"] = np.stack(dones)
+    out["on_map"] = np.array(onmap_hist, dtype=np.int32)
+    out["obs_steps"] = np.array(obs_steps, dtype=np.int32)
+    out["o_aux"] = np.stack(aux_rec)
+    for k, v in obs_rec.items():
+        out["o_" + k] = np.stack(v)
+    for (depth, pdepth), v in py_rec.items():
+        out[f"py_d{depth}_p{pdepth}"] = np.stack(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {row['x_dim']}x{row['y_dim']} A={A} T={T} steps={t} snapshots at {obs_steps} "
+          f"(on map {[onmap_hist[s - 1] for s in obs_steps]}) -> {os.path.getsize(path)/1024:.0f} KB")
+
+
 def static_only(name, test_id, level):
     row = csv_row(test_id, level)
     env, mp = make_env(row)
@@ -353,6 +432,11 @@ JOBS = {
     # cfg5 = Test_13 (150x150, 400 agents): first 40 steps
     "cfg5_fwd_head": lambda: run_episode("cfg5_fwd_head", "Test_13", "Level_0", "fwd", seed=41, max_steps=40,
                                          obs_every=40),
+    # dense traffic on the large maps (>= 40 of 80 / >= 100 of 400 agents on the map), cutils + depth-3 upstream trees
+    "dense_cfg4_spfollow": lambda: run_dense("dense_cfg4_spfollow", "Test_8", "Level_0", seed=32, max_steps=800,
+                                             snap_onmap=(25, 40, 50), pytree=[(3, 30)]),
+    "dense_cfg5_spfollow": lambda: run_dense("dense_cfg5_spfollow", "Test_13", "Level_0", seed=42, max_steps=900,
+                                             snap_onmap=(60, 100, 150), pytree=[(3, 30)]),
 }
 for lv in range(1, 8):
     JOBS[f"base_cfg2_L{lv}"] = (lambda lv=lv: static_only(f"base_cfg2_L{lv}", "Test_2", f"Level_{lv}"))

@@ -28,6 +28,35 @@ def test_unpickler_refuses_foreign_globals():
         persistence.load_env_dict(evil)
 
 
+class _Reduce:
+    def __init__(self, fn, args):
+        self.fn, self.args = fn, args
+
+    def __reduce__(self):
+        return self.fn, self.args
+
+
+@pytest.mark.parametrize("fn,args", [(np.savetxt, ("/tmp/fl_persistence_should_not_exist.txt", [1, 2])),
+                                     (np.load, ("/tmp/fl_persistence_should_not_exist.npy", None, True)),
+                                     (np.fromfile, ("/etc/hostname",)), (np.frombuffer, (b"abcd", "u1")),
+                                     (eval, ("1+1",)), (getattr, ("abc", "upper"))])
+def test_unpickler_refuses_numpy_callables_and_other_reduce_targets(fn, args, tmp_path):
+    """a crafted env file must not reach numpy.savetxt / numpy.load (file write, unrestricted unpickle) or any
+    other callable through REDUCE; only the array / scalar constructors are allowed."""
+    evil = pickle.dumps({"grid": _Reduce(fn, args)})
+    with pytest.raises(pickle.UnpicklingError, match="refusing to load"):
+        persistence.load_env_dict(evil)
+    assert not os.path.exists("/tmp/fl_persistence_should_not_exist.txt")
+
+
+def test_unpickler_still_loads_arrays_scalars_and_dtypes():
+    blob = pickle.dumps({"a": np.arange(6, dtype=np.uint16).reshape(2, 3), "s": np.float64(1.5), "i": np.int32(7),
+                         "d": np.dtype("float32"), "b": np.array([True, False])})
+    d = persistence.load_env_dict(blob)
+    np.testing.assert_array_equal(d["a"], np.arange(6).reshape(2, 3))
+    assert d["s"] == 1.5 and d["i"] == 7 and d["d"] == np.float32 and d["b"].tolist() == [True, False]
+
+
 def test_ingested_env_steps_like_the_golden_episode():
     """the oracle stepped from the ingested description reproduces the golden trajectory."""
     from oracle import orc
