@@ -126,3 +126,71 @@ def test_injected_dense_reference_states_reproduce_the_snapshots(name):
         _check_cutils(of, fx, k, 0, f"{name} T={T} injected")
         _same(tf.cpu().numpy()[0], fx["py_d3_p30"][k], f"{name} T={T} injected py_d3_p30")
     env.check()
+
+
+def _replica_rng(b):
+    st = np.random.RandomState([b]).get_state()
+    return np.array(st[1], dtype=np.uint32), int(st[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head,steps,every", [("cfg5_fwd_head", 420, 5), ("cfg4_fwd_head", 460, 4)])
+def test_batched_dense_run_matches_oracle_with_depth3_fused_obs_and_autoreset(head, steps, every):
+    """B = 3 replicas of a large map with the departures brought forward (>= 80 % of the agents on the map after ~200
+    steps), forward-biased synthetic actions, one replica with a shortened episode (auto-reset crossed at least twice) and
+    one with frequent malfunctions; every `every` steps the fused launch obs_both(3, 30) and the state are compared with
+    the scalar oracle, which steps and builds its observations on the same schedule (sticky deadlock flags)."""
+    from oracle import orc
+    from flatland_marl_amd import synth
+    fx = util.load(head)
+    envs = []
+    for b in range(3):
+        key, pos = _replica_rng(300 + b)
+        st = util.static_of(fx, key, pos)
+        st["earliest"] = (np.asarray(st["earliest"]) // (8 if b < 2 else 4)).astype(np.int32)
+        if b == 1:
+            st["T"] = np.int32(150)
+        if b == 2:
+            st["malf_rate"] = 1 / 400.0
+        envs.append(st)
+    env = _env(envs)
+    oracles = [orc.OracleEnv(st) for st in envs]
+    A = env.A
+    tcount, resets, peak = [0, 0, 0], 0, 0
+    for it in range(steps):
+        rew, done, done_all = env.step_synth(23, 7, 1, auto_reset=True)
+        chk = it % every == 0
+        if chk:
+            o, tr = env.obs_both(3, 30)
+            o = {k: v.cpu().numpy() for k, v in o.items()}
+            tr = tr.cpu().numpy()
+            st_g = env.state()[0]
+            rew, done, done_all = rew.cpu().numpy(), done.cpu().numpy(), done_all.cpu().numpy()
+        for b, oe in enumerate(oracles):
+            r_o, d_o, da = oe.step(synth.forward_biased_actions(23, 7 + b, tcount[b], A))
+            tcount[b] += 1
+            if chk:
+                st_o = oe.state()
+                peak = max(peak, int((st_o[:, 0] >= 0).sum()))
+                _same(st_g[b], st_o, f"{head} replica {b} iter {it} state")
+                _same(rew[b], r_o, f"{head} replica {b} iter {it} rewards")
+                _same(done[b], d_o, f"{head} replica {b} iter {it} dones")
+                assert bool(done_all[b]) == da
+                exp = oe.obs_cutils(31, 500)
+                for ok, gk, _ in CUTILS:
+                    _same(o[gk][b], exp[ok], f"{head} replica {b} iter {it} {gk}")
+                _same(o["props"][b], exp["props"], f"{head} replica {b} iter {it} props")
+                _same(tr[b], oe.obs_pytree(3, 30), f"{head} replica {b} iter {it} depth-3 tree")
+            if da:
+                key, pos = oe.get_rng()
+                oracles[b] = orc.OracleEnv(envs[b])
+                oracles[b].set_rng(key, pos)
+                tcount[b] = 0
+                resets += 1
+    env.check()
+    assert resets >= 2 and peak >= 0.8 * A, (resets, peak)
+    key, pos = env.rng_state()
+    for b, oe in enumerate(oracles):
+        k_o, p_o = oe.get_rng()
+        assert pos[b] == p_o
+        np.testing.assert_array_equal(key[b], k_o)
