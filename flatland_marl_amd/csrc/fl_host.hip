@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/flatland_hip.h"
@@ -40,15 +41,18 @@ struct fl_batch {
     FlDev d;
     hipStream_t own_stream, stream;
     bool committed;
+    int reserve_U, reserve_R;  // fl_reserve: capacity for envs loaded after the first commit
     std::vector<void *> allocs;
-    // host staging (filled by fl_load_env, uploaded by fl_commit)
-    std::vector<uint16_t> h_grid;
-    std::vector<int> h_init_pos, h_target, h_earliest, h_latest, h_tslot, h_ut, h_U, h_T, h_mt_pos, h_malf_min, h_malf_max;
+    // host copy of every env's static description (filled by fl_load_env; kept after commit: live map replacement,
+    // fl_distance_map's expansion to the dense layout)
+    std::vector<uint16_t> h_grid, h_ridx, h_rgrid, h_nbr, h_rkey, h_init_r, h_target_r, h_ut_r;
+    std::vector<uint32_t> h_rcell;
+    std::vector<int> h_init_pos, h_target, h_earliest, h_latest, h_tslot, h_ut, h_U, h_R, h_K, h_T, h_mt_pos, h_malf_min, h_malf_max;
     std::vector<uint32_t> h_spk, h_mt;
     std::vector<double> h_speed;
     std::vector<uint64_t> h_thr;
-    std::vector<uint8_t> h_loaded;
-    uint8_t *mask_dev;  // [B] staging of fl_reset's host mask (allocated once at commit)
+    std::vector<uint8_t> h_loaded, h_dirty;  // dirty: loaded since the last commit
+    uint8_t *mask_dev;   // [B] staging of host-side env masks (fl_reset, fl_commit after a live replacement)
     FlObsScratch obs;
 };
 
@@ -93,15 +97,17 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
     }
     h->stream = h->own_stream;
     memset(&h->d, 0, sizeof h->d);
-    h->d.B = B; h->d.A = A; h->d.H = H; h->d.W = W; h->d.Umax = 0;
+    h->d.B = B; h->d.A = A; h->d.H = H; h->d.W = W; h->d.Ucap = 0; h->d.Rcap = 0;
     const size_t BA = (size_t)B * A, HW = (size_t)H * W;
-    h->h_grid.assign(B * HW, 0);
+    h->reserve_U = 0; h->reserve_R = 0;
+    h->h_grid.assign(B * HW, 0); h->h_ridx.assign(B * HW, FL_R_NONE);
     h->h_init_pos.assign(BA, 0); h->h_target.assign(BA, 0); h->h_earliest.assign(BA, 0); h->h_latest.assign(BA, 0);
+    h->h_init_r.assign(BA, 0); h->h_target_r.assign(BA, 0);
     h->h_tslot.assign(BA, 0); h->h_spk.assign(BA, 0); h->h_speed.assign(BA, 1.0);
-    h->h_ut.assign(BA, 0); h->h_U.assign(B, 0); h->h_T.assign(B, 0); h->h_mt_pos.assign(B, 624);
+    h->h_ut.assign(BA, 0); h->h_U.assign(B, 0); h->h_R.assign(B, 0); h->h_K.assign(B, 0); h->h_T.assign(B, 0); h->h_mt_pos.assign(B, 624);
     h->h_malf_min.assign(B, 0); h->h_malf_max.assign(B, 0); h->h_thr.assign(B, 0);
     h->h_mt.assign((size_t)B * 624, 0);
-    h->h_loaded.assign(B, 0);
+    h->h_loaded.assign(B, 0); h->h_dirty.assign(B, 0);
     memset(&h->obs, 0, sizeof h->obs);
     *out = h;
     return FL_OK;
@@ -128,45 +134,142 @@ int fl_sync(fl_batch *h) {
     return FL_OK;
 }
 
+int fl_reserve(fl_batch *h, int max_targets, int max_rail_cells) {
+    if (!h || max_targets < 0 || max_rail_cells < 0) { set_err("fl_reserve: bad argument"); return FL_ERR_ARG; }
+    if (h->committed) { set_err("fl_reserve: the capacities are fixed at the first fl_commit"); return FL_ERR_ARG; }
+    if ((long long)max_rail_cells * 4 > 65532) { set_err("fl_reserve: at most 16383 rail cells per env (u16 rail states)"); return FL_ERR_ARG; }
+    h->reserve_U = max_targets > h->A ? h->A : max_targets;
+    h->reserve_R = max_rail_cells;
+    return FL_OK;
+}
+
+template <typename T>
+static int upload_range(fl_batch *h, T *dst, const std::vector<T> &src, size_t first, size_t count) {
+    HIPCHK(hipMemcpyAsync(dst + first, src.data() + first, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return FL_OK;
+}
+#define UPLOAD_RANGE(dst, src, first, count)                    \
+    do {                                                        \
+        int rc_ = upload_range(h, dst, src, (size_t)(first), (size_t)(count)); \
+        if (rc_ != FL_OK) return rc_;                           \
+    } while (0)
+
+// rail-cell index space of env b (fl_internal.h): ridx / rcell / rgrid / nbr / rkey, the agents' and targets' rail indices
+static void build_rail_tables(fl_batch *h, int b) {
+    const int A = h->A, H = h->H, W = h->W, Rcap = h->d.Rcap, Ucap = h->d.Ucap;
+    const size_t HW = (size_t)H * W;
+    const uint16_t *grid = &h->h_grid[b * HW];
+    uint16_t *ridx = &h->h_ridx[b * HW];
+    uint32_t *rcell = &h->h_rcell[(size_t)b * Rcap];
+    uint16_t *rgrid = &h->h_rgrid[(size_t)b * Rcap], *nbr = &h->h_nbr[(size_t)b * Rcap * 4];
+    int R = 0;
+    for (size_t c = 0; c < HW; c++) {
+        if (grid[c]) { ridx[c] = (uint16_t)R; rcell[R] = (uint32_t)c; rgrid[R] = grid[c]; R++; }
+        else ridx[c] = FL_R_NONE;
+    }
+    for (int r = R; r < Rcap; r++) { rcell[r] = 0; rgrid[r] = 0; }
+    for (int r = 0; r < Rcap; r++) {
+        const int row = r < R ? (int)(rcell[r] / W) : 0, col = r < R ? (int)(rcell[r] % W) : 0;
+        for (int m = 0; m < 4; m++) {
+            const int nr = row + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = col + (m == 1 ? 1 : m == 3 ? -1 : 0);
+            nbr[r * 4 + m] = (r < R && nr >= 0 && nr < H && nc >= 0 && nc < W) ? ridx[(size_t)nr * W + nc] : FL_R_NONE;
+        }
+    }
+    int K = R;
+    if (H > W) {  // flatland_cutils keys its prediction maps by col * W + row (tool.h:391-398), which collides on tall maps:
+                  // rail cells with equal keys share one compact key
+        std::vector<uint32_t> keys(R);
+        for (int r = 0; r < R; r++) keys[r] = (rcell[r] % W) * (uint32_t)W + rcell[r] / W;
+        std::vector<uint32_t> uniq(keys);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        K = (int)uniq.size();
+        uint16_t *rkey = &h->h_rkey[(size_t)b * Rcap];
+        for (int r = 0; r < R; r++) rkey[r] = (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), keys[r]) - uniq.begin());
+        for (int r = R; r < Rcap; r++) rkey[r] = 0;
+    }
+    h->h_K[b] = K;
+    for (int i = 0; i < A; i++) {
+        const size_t g = (size_t)b * A + i;
+        h->h_init_r[g] = ridx[h->h_init_pos[g]];
+        h->h_target_r[g] = ridx[h->h_target[g]];
+    }
+    for (int u = 0; u < Ucap; u++) h->h_ut_r[(size_t)b * Ucap + u] = u < h->h_U[b] ? ridx[h->h_ut[(size_t)b * A + u]] : 0;
+}
+
+// upload everything fl_load_env staged for env b (device arrays exist)
+static int upload_env(fl_batch *h, int b) {
+    const int A = h->A, Rcap = h->d.Rcap, Ucap = h->d.Ucap;
+    const size_t HW = (size_t)h->H * h->W;
+    FlDev &d = h->d;
+    UPLOAD_RANGE(d.T, h->h_T, b, 1); UPLOAD_RANGE(d.mt_pos, h->h_mt_pos, b, 1); UPLOAD_RANGE(d.mt, h->h_mt, (size_t)b * 624, 624);
+    UPLOAD_RANGE(d.malf_thr, h->h_thr, b, 1); UPLOAD_RANGE(d.malf_min, h->h_malf_min, b, 1); UPLOAD_RANGE(d.malf_max, h->h_malf_max, b, 1);
+    UPLOAD_RANGE(d.U, h->h_U, b, 1); UPLOAD_RANGE(d.R, h->h_R, b, 1); UPLOAD_RANGE(d.K, h->h_K, b, 1);
+    UPLOAD_RANGE(d.grid, h->h_grid, b * HW, HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, HW);
+    UPLOAD_RANGE(d.rgrid, h->h_rgrid, (size_t)b * Rcap, Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, (size_t)b * Rcap * 4, (size_t)Rcap * 4);
+    if (d.rkey) UPLOAD_RANGE(d.rkey, h->h_rkey, (size_t)b * Rcap, Rcap);
+    UPLOAD_RANGE(d.ut_r, h->h_ut_r, (size_t)b * Ucap, Ucap);
+    const size_t g0 = (size_t)b * A;
+    UPLOAD_RANGE(d.init_pos, h->h_init_pos, g0, A); UPLOAD_RANGE(d.target, h->h_target, g0, A);
+    UPLOAD_RANGE(d.init_r, h->h_init_r, g0, A); UPLOAD_RANGE(d.target_r, h->h_target_r, g0, A);
+    UPLOAD_RANGE(d.earliest, h->h_earliest, g0, A); UPLOAD_RANGE(d.latest, h->h_latest, g0, A);
+    UPLOAD_RANGE(d.tslot, h->h_tslot, g0, A); UPLOAD_RANGE(d.spk, h->h_spk, g0, A); UPLOAD_RANGE(d.speed, h->h_speed, g0, A);
+    return FL_OK;
+}
+
 int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_pos, const int32_t *init_dir,
                 const int32_t *target, const double *speed, const int32_t *earliest, const int32_t *latest,
                 int max_episode_steps, uint64_t malf_threshold, int malf_min, int malf_max, const uint32_t *mt_key,
                 int mt_pos) {
     if (!h || b < 0 || b >= h->B) { set_err("fl_load_env: env index out of range"); return FL_ERR_ARG; }
-    if (h->committed) { set_err("fl_load_env: handle already committed"); return FL_ERR_ARG; }
+    if (!grid || !init_pos || !init_dir || !target || !speed || !earliest || !latest || !mt_key) { set_err("fl_load_env: null argument"); return FL_ERR_ARG; }
     const int A = h->A, H = h->H, W = h->W;
     const size_t HW = (size_t)H * W;
     if (mt_pos < 0 || mt_pos > 624) { set_err("fl_load_env: mt_pos out of range"); return FL_ERR_ARG; }
     if (malf_max < malf_min || malf_min < 0 || malf_max > 60000) { set_err("fl_load_env: bad malfunction duration range"); return FL_ERR_ARG; }
     size_t rail_cells = 0;
     for (size_t c = 0; c < HW; c++) rail_cells += grid[c] != 0;
-    if (rail_cells * 4 >= 65534) { set_err("fl_load_env: %zu rail cells exceed the u16 distance-map range", rail_cells); return FL_ERR_ARG; }
-    memcpy(&h->h_grid[b * HW], grid, HW * 2);
-    int U = 0;
+    if (rail_cells * 4 > 65532) { set_err("fl_load_env: %zu rail cells exceed the u16 rail-state / distance range", rail_cells); return FL_ERR_ARG; }
+    // validate everything before touching the staged copy of env b (a refused call leaves it as it was)
+    std::vector<int> ut;
+    std::vector<int> tslot(A);
     for (int i = 0; i < A; i++) {
-        const size_t g = (size_t)b * A + i;
         const int ir = init_pos[2 * i], ic = init_pos[2 * i + 1], tr = target[2 * i], tc = target[2 * i + 1];
         if (ir < 0 || ir >= H || ic < 0 || ic >= W || tr < 0 || tr >= H || tc < 0 || tc >= W || init_dir[i] < 0 || init_dir[i] > 3) {
             set_err("fl_load_env: agent %d position/direction out of range", i);
             return FL_ERR_ARG;
         }
+        if (grid[(size_t)ir * W + ic] == 0 || grid[(size_t)tr * W + tc] == 0) { set_err("fl_load_env: agent %d starts or ends on a cell without rail", i); return FL_ERR_ARG; }
         if (!(speed[i] > 0.0) || speed[i] > 1.0) { set_err("fl_load_env: agent %d speed %g not in (0, 1]", i, speed[i]); return FL_ERR_ARG; }
         const int max_count = (int)(1.0 / speed[i]) - 1;  // SpeedCounter.max_count (step_utils/speed_counter.py:39-41)
         if (max_count < 0 || max_count > 15) { set_err("fl_load_env: agent %d speed %g unsupported (max_count %d)", i, speed[i], max_count); return FL_ERR_ARG; }
-        h->h_init_pos[g] = ir * W + ic;
-        h->h_target[g] = tr * W + tc;
+        // unique targets in first-seen order (distance_map.py:71-79)
+        const int tcell = tr * W + tc;
+        size_t u = 0;
+        for (; u < ut.size(); u++)
+            if (ut[u] == tcell) break;
+        if (u == ut.size()) ut.push_back(tcell);
+        tslot[i] = (int)u;
+    }
+    if (h->committed && ((int)ut.size() > h->d.Ucap || (int)rail_cells > h->d.Rcap)) {
+        set_err("fl_load_env: env %d has %zu unique targets / %zu rail cells, the batch was committed for %d / %d (fl_reserve)", b,
+                ut.size(), rail_cells, h->d.Ucap, h->d.Rcap);
+        return FL_ERR_CAPACITY;
+    }
+    memcpy(&h->h_grid[b * HW], grid, HW * 2);
+    for (int i = 0; i < A; i++) {
+        const size_t g = (size_t)b * A + i;
+        h->h_init_pos[g] = init_pos[2 * i] * W + init_pos[2 * i + 1];
+        h->h_target[g] = target[2 * i] * W + target[2 * i + 1];
         h->h_earliest[g] = earliest[i];
         h->h_latest[g] = latest[i];
         h->h_speed[g] = speed[i];
-        h->h_spk[g] = (uint32_t)init_dir[i] | ((uint32_t)max_count << 2);
-        // unique targets in first-seen order (distance_map.py:71-79)
-        int u = 0;
-        for (; u < U; u++)
-            if (h->h_ut[(size_t)b * A + u] == h->h_target[g]) break;
-        if (u == U) h->h_ut[(size_t)b * A + U++] = h->h_target[g];
-        h->h_tslot[g] = u;
+        h->h_spk[g] = (uint32_t)init_dir[i] | ((uint32_t)((int)(1.0 / speed[i]) - 1) << 2);
+        h->h_tslot[g] = tslot[i];
+        h->h_ut[g] = i < (int)ut.size() ? ut[i] : 0;
     }
-    h->h_U[b] = U;
+    h->h_U[b] = (int)ut.size();
+    h->h_R[b] = (int)rail_cells;
     h->h_T[b] = max_episode_steps;
     h->h_thr[b] = malf_threshold;
     h->h_malf_min[b] = malf_min;
@@ -174,102 +277,77 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
     memcpy(&h->h_mt[(size_t)b * 624], mt_key, 624 * 4);
     h->h_mt_pos[b] = mt_pos;
     h->h_loaded[b] = 1;
+    h->h_dirty[b] = 1;
     return FL_OK;
 }
-
-template <typename T>
-static int upload(fl_batch *h, T *dst, const std::vector<T> &src) {
-    HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-    return FL_OK;
-}
-#define UPLOAD(dst, src)                    \
-    do {                                    \
-        int rc_ = upload(h, dst, src);      \
-        if (rc_ != FL_OK) return rc_;       \
-    } while (0)
 
 int fl_commit(fl_batch *h) {
     if (!h) return FL_ERR_ARG;
-    if (h->committed) { set_err("fl_commit: already committed"); return FL_ERR_ARG; }
     for (int b = 0; b < h->B; b++)
         if (!h->h_loaded[b]) { set_err("fl_commit: env %d was never loaded", b); return FL_ERR_ARG; }
     HIPCHK(hipSetDevice(h->device));
     const int B = h->B, A = h->A;
     const size_t BA = (size_t)B * A, HW = (size_t)h->H * h->W;
-    int Umax = 1;
-    for (int b = 0; b < B; b++) Umax = h->h_U[b] > Umax ? h->h_U[b] : Umax;
     FlDev &d = h->d;
-    d.Umax = Umax;
-    DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
-    DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
-    DALLOC(d.grid, B * HW); DALLOC(d.dm, (size_t)B * Umax * HW * 4); DALLOC(d.ut, (size_t)B * Umax);
-    DALLOC(d.seg, (size_t)B * HW * 4);
-    DALLOC(d.nh, (size_t)B * Umax * HW);
-    DALLOC(d.hop8, (size_t)B * Umax * HW * 4);
-    DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
-    DALLOC(d.spk, BA); DALLOC(d.speed, BA);
-    DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
-    std::vector<int> ut((size_t)B * Umax, 0);
-    for (int b = 0; b < B; b++)
-        for (int u = 0; u < h->h_U[b]; u++) ut[(size_t)b * Umax + u] = h->h_ut[(size_t)b * A + u];
-    UPLOAD(d.T, h->h_T); UPLOAD(d.mt_pos, h->h_mt_pos); UPLOAD(d.mt, h->h_mt); UPLOAD(d.malf_thr, h->h_thr);
-    UPLOAD(d.malf_min, h->h_malf_min); UPLOAD(d.malf_max, h->h_malf_max); UPLOAD(d.U, h->h_U);
-    UPLOAD(d.grid, h->h_grid); UPLOAD(d.ut, ut);
-    UPLOAD(d.init_pos, h->h_init_pos); UPLOAD(d.target, h->h_target); UPLOAD(d.earliest, h->h_earliest);
-    UPLOAD(d.latest, h->h_latest); UPLOAD(d.tslot, h->h_tslot); UPLOAD(d.spk, h->h_spk); UPLOAD(d.speed, h->h_speed);
-    // rail-cell compaction table
-    std::vector<int> rcount(B, 0);
-    int Rmax = 1;
-    for (int b = 0; b < B; b++) {
-        int r = 0;
-        for (size_t c = 0; c < HW; c++) r += h->h_grid[(size_t)b * HW + c] != 0;
-        rcount[b] = r;
-        Rmax = r > Rmax ? r : Rmax;
-    }
-    d.Rmax = Rmax;
-    DALLOC(d.R, B);
-    UPLOAD(d.R, rcount);
-    d.ridx = nullptr; d.rcell = nullptr; d.chop8 = nullptr;
-    std::vector<uint16_t> ridx;
-    std::vector<uint32_t> rcell;
-    if (Rmax <= 65534) {
-        DALLOC(d.ridx, B * HW);
-        DALLOC(d.rcell, (size_t)B * Rmax);
-        ridx.assign((size_t)B * HW, 0xFFFF);
-        rcell.assign((size_t)B * Rmax, 0);
+    if (!h->committed) {
+        int Ucap = h->reserve_U > 1 ? h->reserve_U : 1, Rcap = h->reserve_R > 1 ? h->reserve_R : 1;
         for (int b = 0; b < B; b++) {
-            int r = 0;
-            for (size_t c = 0; c < HW; c++)
-                if (h->h_grid[(size_t)b * HW + c] != 0) {
-                    rcell[(size_t)b * Rmax + r] = (uint32_t)c;
-                    ridx[(size_t)b * HW + c] = (uint16_t)r++;
-                }
+            Ucap = h->h_U[b] > Ucap ? h->h_U[b] : Ucap;
+            Rcap = h->h_R[b] > Rcap ? h->h_R[b] : Rcap;
         }
-        UPLOAD(d.ridx, ridx);
-        UPLOAD(d.rcell, rcell);
-        // the rail-state copy of the eight-hop table pays off where the full table falls out of the caches
-        if (Rmax * 4 <= 65534 && fl_obs_large_map(h->H, h->W)) DALLOC(d.chop8, (size_t)B * Umax * Rmax * 4);
+        d.Ucap = Ucap; d.Rcap = Rcap;
+        const size_t Scap = (size_t)Rcap * 4;
+        h->h_rcell.assign((size_t)B * Rcap, 0); h->h_rgrid.assign((size_t)B * Rcap, 0); h->h_nbr.assign((size_t)B * Scap, FL_R_NONE);
+        h->h_ut_r.assign((size_t)B * Ucap, 0);
+        if (h->H > h->W) h->h_rkey.assign((size_t)B * Rcap, 0);
+        DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
+        DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.R, B); DALLOC(d.K, B);
+        DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
+        DALLOC(d.grid, B * HW); DALLOC(d.ridx, B * HW);
+        DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
+        d.rkey = nullptr;
+        if (h->H > h->W) DALLOC(d.rkey, (size_t)B * Rcap);
+        DALLOC(d.ut_r, (size_t)B * Ucap);
+        DALLOC(d.dm, (size_t)B * Ucap * Scap); DALLOC(d.seg, (size_t)B * Scap);
+        DALLOC(d.nh, (size_t)B * Ucap * Rcap); DALLOC(d.hop8, (size_t)B * Ucap * Scap);
+        DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.init_r, BA); DALLOC(d.target_r, BA);
+        DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
+        DALLOC(d.spk, BA); DALLOC(d.speed, BA);
+        DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
+        DALLOC(h->mask_dev, B);
+        if (fl_step_prepare() != FL_OK) { set_err("fl_commit: hipFuncSetAttribute failed"); return FL_ERR_HIP; }
+        const int rc_dm = fl_dmap_prepare(d);
+        if (rc_dm != FL_OK) { set_err("fl_commit: %d rail cells per env do not fit the distance-map kernel's LDS", Rcap); return rc_dm; }
+        int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
+        if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
     }
-    DALLOC(h->mask_dev, B);
-    if (fl_step_prepare() != FL_OK) { set_err("fl_commit: hipFuncSetAttribute failed"); return FL_ERR_HIP; }
-    HIPCHK(hipStreamSynchronize(h->stream));  // `ut` and the compaction table are locals
-    fl_launch_distance_maps(d, h->stream);
+    // (re)build the host tables of every env loaded since the last commit and upload them; the device tables of exactly
+    // those envs are rebuilt below, their agents reset (fresh)
+    bool any = false;
+    for (int b = 0; b < B; b++) {
+        if (!h->h_dirty[b]) continue;
+        any = true;
+        build_rail_tables(h, b);
+        const int rc = upload_env(h, b);
+        if (rc != FL_OK) return rc;
+    }
+    if (!any) return FL_OK;
+    const bool all = !h->committed;
+    if (!all) HIPCHK(hipMemcpyAsync(h->mask_dev, h->h_dirty.data(), B, hipMemcpyHostToDevice, h->stream));
+    const uint8_t *mask = all ? nullptr : h->mask_dev;
+    fl_launch_distance_maps(d, mask, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_segments(d, h->stream);
+    fl_launch_segments(d, mask, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_nexthop(d, h->stream);
+    fl_launch_nexthop(d, mask, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_hop8(d, h->stream);
+    fl_launch_hop8(d, mask, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_reset(d, nullptr, 1, h->stream);
+    fl_launch_reset(d, mask, 1, h->stream);
     HIPCHK(hipGetLastError());
-    int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
-    if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
     HIPCHK(hipStreamSynchronize(h->stream));
+    std::fill(h->h_dirty.begin(), h->h_dirty.end(), 0);
     h->committed = true;
-    // host staging is no longer needed
-    h->h_grid.clear(); h->h_grid.shrink_to_fit();
-    h->h_mt.clear(); h->h_mt.shrink_to_fit();
     return fl_check(h);
 }
 
@@ -550,26 +628,43 @@ int fl_motion_check(int device, int n_cases, const int32_t *offsets, const int32
 int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot) {
     NEED_COMMIT(h);
     if (b < 0 || b >= h->B || !n_targets) { set_err("fl_distance_map: bad argument"); return FL_ERR_ARG; }
-    *n_targets = h->h_U[b];
-    const size_t HW = (size_t)h->H * h->W;
-    if (dm)
-        HIPCHK(hipMemcpyAsync(dm, h->d.dm + (size_t)b * h->d.Umax * HW * 4, (size_t)h->h_U[b] * HW * 4 * 2,
-                              hipMemcpyDeviceToHost, h->stream));
+    const int U = h->h_U[b], R = h->h_R[b];
+    *n_targets = U;
+    const size_t HW = (size_t)h->H * h->W, Scap = (size_t)h->d.Rcap * 4;
     if (target_slot) memcpy(target_slot, &h->h_tslot[(size_t)b * h->A], (size_t)h->A * 4);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (dm) {  // the resident map holds rail states only: expand it to the reference's dense [U][H][W][4]
+        std::vector<uint16_t> rs((size_t)U * Scap);
+        HIPCHK(hipMemcpyAsync(rs.data(), h->d.dm + (size_t)b * h->d.Ucap * Scap, rs.size() * 2, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const uint32_t *rcell = &h->h_rcell[(size_t)b * h->d.Rcap];
+        for (size_t k = 0; k < (size_t)U * HW * 4; k++) dm[k] = FL_INF16;
+        for (int u = 0; u < U; u++)
+            for (int r = 0; r < R; r++)
+                memcpy(&dm[((size_t)u * HW + rcell[r]) * 4], &rs[(size_t)u * Scap + (size_t)r * 4], 8);
+    }
+    return FL_OK;
+}
+
+static int rebuild_tables(fl_batch *h, const uint8_t *mask_dev) {
+    fl_launch_distance_maps(h->d, mask_dev, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_segments(h->d, mask_dev, h->stream);
+    HIPCHK(hipGetLastError());
+    fl_launch_nexthop(h->d, mask_dev, h->stream);
+    fl_launch_hop8(h->d, mask_dev, h->stream);
+    HIPCHK(hipGetLastError());
     return FL_OK;
 }
 
 int fl_distance_map_rebuild(fl_batch *h) {
     NEED_COMMIT(h);
-    fl_launch_distance_maps(h->d, h->stream);
-    HIPCHK(hipGetLastError());
-    fl_launch_segments(h->d, h->stream);
-    HIPCHK(hipGetLastError());
-    fl_launch_nexthop(h->d, h->stream);
-    fl_launch_hop8(h->d, h->stream);
-    HIPCHK(hipGetLastError());
-    return FL_OK;
+    return rebuild_tables(h, nullptr);
+}
+
+int fl_distance_map_rebuild_masked(fl_batch *h, const uint8_t *mask_dev) {
+    NEED_COMMIT(h);
+    if (!mask_dev) { set_err("fl_distance_map_rebuild_masked: null mask"); return FL_ERR_ARG; }
+    return rebuild_tables(h, mask_dev);
 }
 
 int fl_positions_map(fl_batch *h, int b, int32_t *out) {

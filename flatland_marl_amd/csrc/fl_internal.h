@@ -1,20 +1,29 @@
 // fl_internal.h -- device-side data layout and helpers shared by the HIP kernels (gfx950 only).
 //
 // HBM layout: struct-of-arrays over (env b, agent i), g = b * A + i.
-//   dynamic (20 B/agent): pos i32, old_pos i32, arrival i32, malf u32 (lo16 down counter, hi16 num_malfunctions),
-//                         pk u32 (packed small fields, see PK_* below)
-//   static  (36 B/agent): init_pos i32, target i32, earliest i32, latest i32, spk u32, tslot i32, speed f64
-//   per env: t, T, done_all, mt_pos, mt[624], malf_thr u64, malf_min/max, U, grid u16[H*W],
-//            dm u16[Umax][H*W][4] (0xFFFF = unreachable)
+//   dynamic (20 B/agent): pos i32 (cell id r * W + c, -1 = None), old_pos i32, arrival i32,
+//                         malf u32 (lo16 down counter, hi16 num_malfunctions), pk u32 (packed small fields, see PK_* below)
+//   static  (40 B/agent): init_pos i32, target i32 (cell ids, read by the step), init_r u16, target_r u16 (rail indices, read by
+//                         the observation kernels), earliest i32, latest i32, spk u32, tslot i32, speed f64
+//   per env: t, T, done_all, mt_pos, mt[624], malf_thr u64, malf_min/max, U, R, K, grid u16[H*W] (step only)
+//
+// RAIL-CELL INDEX SPACE.  Only 12-20 % of the cells of a Flatland map carry rail, so every static table of the observation
+// path is indexed by the env's rail cells in row-major order (rail index r in [0, R)) and by rail states s = r * 4 + o
+// (o = orientation), not by grid cells: ridx maps a cell to its rail index, nbr gives the rail index of the neighbour
+// in each direction.  At 150x150 (R = 2680 of 22500 cells) the tables are 8.4x smaller than their dense form:
+//   rgrid u16[Rcap] transitions, nbr u16[Rcap*4], snext u16[Scap] (successor of a single-transition state),
+//   dm u16[Ucap][Scap] (distance per unique target and rail state, 0xFFFF = unreachable), seg uint2[Scap], nh u16[Ucap][Rcap],
+//   hop8 u16[Ucap][Scap].  Rcap / Ucap = capacity of the batch (largest env, or fl_reserve), Scap = 4 * Rcap <= 65532.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define FL_INF16 0xFFFFu
 
-// static branch-walk table entry (uint2) of a start state (cell, dir): the walk of _explore_branch ignoring the
-// agent's own target.  x = end state (cell << 2 | dir) | kind << 20;  y = steps to the end | first "unusable
-// switch" offset << 16 (0xFFFF = none)
+#define FL_R_NONE 0xFFFFu  /* no rail cell / no such state (u16 tables) */
+
+// static branch-walk table entry (uint2) of a start state: the walk of _explore_branch ignoring the agent's own target.
+// x = end rail state | kind << 20;  y = steps to the end | first "unusable switch" offset << 16 (0xFFFF = none)
 enum { SEG_SWITCH = 0, SEG_DEAD_END = 1, SEG_ZERO = 2, SEG_CYCLE = 3 };
 #define SEG_END(e) ((int)((e).x & 0xFFFFFu))
 #define SEG_KIND(e) (((e).x >> 20) & 3u)
@@ -43,10 +52,9 @@ __host__ __device__ inline uint32_t pk_make(uint32_t dir, uint32_t old_dir, uint
 #define SPK_INIT_DIR(s) ((s)&3u)
 #define SPK_MAX_COUNT(s) (((s) >> 2) & 15u)
 
-#define FL_HOP_NONE 0xFFFFFFFFu
-
 struct FlDev {
-    int B, A, H, W, Umax;
+    int B, A, H, W;
+    int Ucap, Rcap;  // capacity per env: unique targets, rail cells (rail states: 4 * Rcap)
     // per env
     int *t;
     int *T;
@@ -55,25 +63,26 @@ struct FlDev {
     uint32_t *mt;  // [B][624]
     uint64_t *malf_thr;
     int *malf_min, *malf_max;
-    int *U;
+    int *U;    // [B] unique targets
+    int *R;    // [B] rail cells
+    int *K;    // [B] prediction keys (R, or the distinct col * W + row values of the rail cells when H > W)
     int *err;  // [B] first error code raised by a kernel for env b (0 = none)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
     int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
-    uint16_t *grid;  // [B][H*W]
-    uint16_t *dm;    // [B][Umax][H*W][4]
-    int *ut;         // [B][Umax] unique target cells
-    uint2 *seg;      // [B][H*W*4] static branch-walk table per (cell, orientation), see fl_dmap.hip k_segments
-    uint16_t *nh;    // [B][Umax][H*W] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
-    // rail-cell compaction (built on the host at commit): index of a cell among the env's rail cells in row-major order
-    int Rmax;        // most rail cells of any env
-    int *R;          // [B] rail cells of the env
-    uint16_t *ridx;  // [B][H*W], 0xFFFF = no rail; nullptr if Rmax > 65534
-    uint32_t *rcell; // [B][Rmax] cell of rail index r (with ridx)
-    uint16_t *chop8; // [B][Umax][Rmax*4] hop8 in rail-state space (rail index * 4 + orientation, 0xFFFF = none): 16x smaller at
-                     // 150x150, so the path walk of large maps gathers from the last-level cache; nullptr when not built
-    uint32_t *hop8;  // [B][Umax][H*W*4] state after eight greedy hops, FL_HOP_NONE if the path ends earlier (k_hop8)
+    uint16_t *grid;   // [B][H*W] transition bitmap per cell (step kernel)
+    uint16_t *ridx;   // [B][H*W] rail index of a cell, FL_R_NONE = no rail
+    uint16_t *rgrid;  // [B][Rcap] transition bitmap per rail cell
+    uint16_t *nbr;    // [B][Rcap*4] rail index of the neighbour of rail cell r in direction m (N,E,S,W), FL_R_NONE = none
+    uint16_t *snext;  // [B][Scap] successor state of a state with exactly one transition (k_segments), FL_R_NONE otherwise
+    uint16_t *rkey;   // [B][Rcap] compact prediction key of a rail cell; nullptr when H <= W (key = rail index)
+    uint16_t *ut_r;   // [B][Ucap] rail index of unique target u
+    uint16_t *dm;     // [B][Ucap][Scap] distance map
+    uint2 *seg;       // [B][Scap] static branch-walk table, see fl_dmap.hip k_segments
+    uint16_t *nh;     // [B][Ucap][Rcap] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
+    uint16_t *hop8;   // [B][Ucap][Scap] state after eight greedy hops, FL_R_NONE if the path ends earlier (k_hop8)
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
+    uint16_t *init_r, *target_r;
     uint32_t *spk;
     double *speed;
     // dynamic per agent
@@ -125,11 +134,13 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
     return r >= 95 ? 0u : r >= 90 ? 4u : r >= 85 ? 3u : r >= 80 ? 1u : 2u;
 }
 
-// kernel launchers (defined in the .hip files)
-void fl_launch_distance_maps(const FlDev &d, hipStream_t s);
-void fl_launch_segments(const FlDev &d, hipStream_t s);
-void fl_launch_nexthop(const FlDev &d, hipStream_t s);
-void fl_launch_hop8(const FlDev &d, hipStream_t s);  // also the rail-state copy (chop8) when allocated  // after fl_launch_nexthop
+// kernel launchers (defined in the .hip files).  mask_dev: u8[B] or nullptr (= every env): only the envs with a non-zero
+// entry are rebuilt.
+void fl_launch_distance_maps(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
+void fl_launch_segments(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);   // seg + snext
+void fl_launch_nexthop(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
+void fl_launch_hop8(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);       // after fl_launch_nexthop
+int fl_dmap_prepare(const FlDev &d);                                               // LDS attribute / size check
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
 void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
                            long long *no_out, long long *eo_out, hipStream_t s);

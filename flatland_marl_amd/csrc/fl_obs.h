@@ -9,9 +9,7 @@
 
 struct FlObsScratch {
     int pred_cap;      // waypoints kept per agent (pred_depth + 2)
-    uint32_t *path;    // [B][A][pred_cap] predicted waypoints: cell << 2 | dir
-    int keys;          // prediction keys per env: (W - 1) * W + H (key = col * W + row, tool.h:391-398)
-    int *cell_head;    // [B][keys + 1] CSR offsets of the per-key prediction index (used when they do not fit LDS)
+    uint16_t *path;    // [B][A][pred_cap] predicted waypoints: rail state (rail index << 2 | direction)
     long long *dbg;    // [B][32] phase clocks of diagnostic builds (-DFL_OBS_TIMING)
     uint32_t *cell_items;  // [B][items_cap] prediction items (IT_* packing, fl_obs.hip) when they do not fit LDS
     size_t items_cap;
@@ -27,4 +25,3 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[8]);  // diagnostic
-bool fl_obs_large_map(int H, int W);  // prediction keys do not fit LDS: the launches run the large-map kernels

@@ -9,8 +9,13 @@
 //   flatland_cutils/src/feature_parser.cpp:3-98 AgentAttrParser::get_features
 //   flatland-rl/flatland/envs/observations.py:60-494 + predictions.py:97-180   upstream TreeObsForRailEnv
 //
-// Layout of one launch (gfx950): one workgroup (up to 16 wavefronts) per env.  The env's rail bitmap and an occupied-cell
-// table are staged in LDS once.  Then, concurrently: eight lanes per agent walk its predicted path (static next-hop /
+// Everything is indexed by RAIL CELLS (rail index r, rail state s = r * 4 + orientation; fl_internal.h), not by grid cells:
+// the per-cell words, the neighbour / successor tables, the prediction keys and their time masks of a 150x150 map
+// (2680 rail cells) fit LDS like those of a 30x30 one; on small maps the static distance / segment / next-hop tables of
+// the env are staged in LDS too (TAB_LDS), so that no gather of the kernel leaves the CU.
+//
+// Layout of one launch (gfx950): one workgroup (up to 16 wavefronts) per env.  The env's rail words, neighbour tables and
+// an occupied-cell table are staged in LDS once.  Then, concurrently: eight lanes per agent walk its predicted path (static next-hop /
 // eight-hop tables), one wavefront does the per-agent part (deadlock fixpoint, valid actions, 83-float attribute row) and
 // the other wavefronts derive the topology of the trees from the static segment table (pass A).  A per-key index of
 // prediction items (+ per-key time-bucket masks) is built in LDS.  Pass B splits the visited cells of all trees evenly over
@@ -26,13 +31,8 @@
 #include "../../include/flatland_hip.h"
 
 #define OBS_NT 1024
-#define OBS_CSR_LDS_MAX_KEYS 6143    // the per-key CSR offsets live in LDS up to this many keys, in HBM scratch beyond
 #ifndef CF_CHUNK
 #define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
-#endif
-#ifndef OBS_NBK
-#define OBS_NBK 4                    // time buckets per rail cell of the HBM-resident prediction index (large maps)
-#define OBS_BK_SHIFT 7               // ... of 128 steps each (the last one takes the rest); 4 x 128 measured best at 150x150
 #endif
 #ifndef OBS_GLB_BATCH
 #define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
@@ -60,31 +60,28 @@
 
 // ---------------------------------------------------------------------------------------------- context
 struct ObsCtx {
-    int A, H, W, HW;
-    bool keycell;                 // prediction keys (col * W + row, tool.h:391-398) are injective (H <= W): index by cell id
-    const uint32_t *cellw;        // LDS per cell: rail bitmap (low 16) | occupied-cell table index (high 16, 0xFFFF = none)
-    // large maps (keys not in LDS): the rail bitmap alone, u16 per cell, and the occupied cells in a small hash set whose
-    // slot index plays the role of the table index above
-    const uint16_t *cell16;       // LDS per cell rail bitmap, nullptr = cellw layout
-    const int *hkey;              // LDS [hmask + 1] cell id or -1
-    int hmask;
+    int A, R;
+    int SS;                       // stride (in rail states) between the per-target slabs of dm / hop8
+    const uint32_t *cellw;        // LDS per rail cell: rail bitmap (low 16) | occupied-cell table index (high 16, 0xFFFF = none)
+    const uint16_t *nbr;          // LDS [R * 4]: rail index of the neighbour in direction m, FL_R_NONE
+    const uint16_t *snext;        // LDS [R * 4] successor of a single-transition state, or nullptr (derived from cellw + nbr)
+    const uint16_t *rkey;         // LDS [R] compact prediction key (col * W + row collides when H > W, tool.h:391-398); nullptr: key = r
     const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
     const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
-    const uint32_t *cell_target;  // LDS bitmap: some agent's target (upstream location_has_target)
-    const int *a_vpos;            // LDS per agent: virtual position (cell)
+    const uint32_t *cell_target;  // LDS bitmap over rail cells: some agent's target (upstream location_has_target)
+    const int *a_vpos;            // LDS per agent: virtual position (rail index)
     const uint8_t *a_dir, *a_state;
     const uint16_t *a_malf;       // real down counter
     const double *a_speed;
     const uint16_t *a_tpc;        // times per cell of the predictor
     const int *a_tslot;
-    const int *a_target;
-    const uint16_t *bk_ridx;      // HBM [HW]: large maps key the index by (rail index, time bucket) instead of the cell; nullptr = by cell
-    const int *csr_end;           // [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0); LDS or HBM
+    const int *a_target;          // rail index
+    const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
     int Tn;                       // number of predicted time entries (0 = no predictor)
-    const uint16_t *dm;           // HBM env base [Umax][HW][4]
-    const uint2 *seg;             // HBM env base [HW * 4] static branch-walk table
+    const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
+    const uint2 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
     // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
@@ -95,29 +92,21 @@ struct ObsCtx {
     int dbg_base;
 };
 
-__host__ __device__ inline int obs_hash_cap(int A) { int c = 64; while (c < 2 * A) c <<= 1; return c; }
-__device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int cell) {
-    return X.cell16 ? (uint32_t)X.cell16[cell] : (X.cellw[cell] & 0xFFFFu);
-}
+__device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int r) { return X.cellw[r] & 0xFFFFu; }
 // occupied-cell table index of the cell, 0xFFFF = nobody on it and nobody waiting to depart from it
-__device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int cell) {
-    if (!X.cell16) return X.cellw[cell] >> 16;
-    int h = (int)(((uint32_t)cell * 2654435761u) >> 16) & X.hmask;
-    while (true) {
-        const int k = X.hkey[h];
-        if (k == cell) return (uint32_t)h;
-        if (k < 0) return 0xFFFFu;
-        h = (h + 1) & X.hmask;
-    }
+__device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int r) { return X.cellw[r] >> 16; }
+__device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int r) { return X.cellw[r]; }
+__device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? (int)X.rkey[r] : r; }
+// successor of a state with exactly one transition (chain interior): one LDS load when the table is resident
+__device__ __forceinline__ uint32_t chain_next(const ObsCtx &X, uint32_t s, uint32_t bits16) {
+    if (X.snext) return X.snext[s];
+    const uint32_t nd = first_dir(nibble(bits16, s & 3u));
+    return ((uint32_t)X.nbr[(s & ~3u) | nd] << 2) | nd;
 }
-__device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int cell) {
-    return X.cell16 ? (cw_bits(X, cell) | (cw_slot(X, cell) << 16)) : X.cellw[cell];
-}
-
-__device__ __forceinline__ int key_of(const ObsCtx &X, int cell) {
-    if (X.keycell) return cell;
-    const int r = cell / X.W;
-    return (cell - r * X.W) * X.W + r;
+// state reached by leaving rail cell r in direction m, -1 when there is no rail there
+__device__ __forceinline__ int state_towards(const ObsCtx &X, int r, uint32_t m) {
+    const uint32_t nr = X.nbr[r * 4 + (int)m];
+    return nr == FL_R_NONE ? -1 : (int)((nr << 2) | m);
 }
 
 // One node of a tree = one branch walk (_explore_branch: treeobs.cpp:258-610 / observations.py:256-494).
@@ -139,7 +128,7 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, i
     n.start = (cell << 2) | (int)dir;
     n.tot0 = tot0;
     const uint2 e = X.seg[n.start];
-    const uint32_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + n.start];
+    const uint32_t dv = X.dm[X.a_tslot[handle] * X.SS + n.start];
     const int len = SEG_LEN(e), unus = SEG_UNUS(e);
     if (dv != FL_INF16 && (int)dv <= len) {  // reaches its own target first
         n.nvis = (int)dv + 1;
@@ -157,11 +146,9 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, i
 }
 
 // advance k cells along a chain of single-transition cells (no features)
-__device__ __forceinline__ void skip_cells(const ObsCtx &X, int &cell, uint32_t &d, int k) {
-    for (int v = 0; v < k; v++) {
-        d = first_dir(nibble(cw_bits(X, cell), d));
-        cell = step_cell(cell, d, X.W);
-    }
+__device__ __forceinline__ uint32_t skip_cells(const ObsCtx &X, uint32_t s, int k) {
+    for (int v = 0; v < k; v++) s = chain_next(X, s, X.snext ? 0u : cw_bits(X, (int)(s >> 2)));
+    return s;
 }
 
 // per-team node table in LDS: CAP entries per field
@@ -249,18 +236,6 @@ __device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f 
 
 template <bool CUTILS, int CAP, bool ITL>
 __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
-    if (!ITL && X.bk_ridx) {  // (rail index, time bucket) lists: only the buckets the queried times fall in
-        const int kb = (int)X.bk_ridx[cell] * OBS_NBK;
-        const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_NBK - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_NBK - 1);
-        uint32_t f = 0;
-        for (int bb = b1; bb <= b2; bb++) {
-            const int kk = kb + bb;
-            const int hi = X.csr_end[kk], lo = kk > 0 ? X.csr_end[kk - 1] : 0;
-            if (hi > lo) f |= conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi);
-        }
-        if (conflict_hit(f)) atomicMin(&sc[F_PC * CAP + node], tot);
-        return;
-    }
     const int key = key_of(X, cell);
     const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
     if (hi <= lo) return;
@@ -376,9 +351,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         {
             const int nvis = vs[F_VIS * CAP + node], incl = vs[F_INCL * CAP + node];
             const int k = lpos - (incl - nvis);  // offset inside the node's walk
-            const int st = vs[F_START * CAP + node];
-            cell = st >> 2; dd = st & 3;
-            skip_cells(X, cell, dd, k);
+            const uint32_t st = skip_cells(X, (uint32_t)vs[F_START * CAP + node], k);
+            cell = (int)(st >> 2); dd = st & 3u;
 #ifdef FL_OBS_TIMING
             dbg_skip = k;
 #endif
@@ -434,7 +408,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                         const unsigned long long qm = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
                         cand = (X.tmask[key] & qm) != 0ull;
                     } else {
-                        cand = X.bk_ridx ? true : X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);  // bucketed: conflict_event looks
+                        cand = X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);
                     }
                 }
             }
@@ -448,8 +422,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             if (!CUTILS && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target) atomicMin(&sc[F_OT * CAP + node], tot);
             left--;
             if (left > 0) {  // keep walking along the only transition
-                dd = first_dir(nibble(cw & 0xFFFFu, dd));
-                cell = step_cell(cell, dd, X.W);
+                const uint32_t sn = chain_next(X, ((uint32_t)cell << 2) | dd, cw & 0xFFFFu);
+                cell = (int)(sn >> 2); dd = sn & 3u;
                 tot += 1;
             }
         }
@@ -545,7 +519,7 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
     const bool tgt = flags & ND_TARGET;
     double dist_min = 0;
     if (!tgt) {
-        const uint16_t dv = X.dm[((size_t)X.a_tslot[handle] * X.HW) * 4 + vs[F_END * CAP + k]];
+        const uint16_t dv = X.dm[X.a_tslot[handle] * X.SS + vs[F_END * CAP + k]];
         dist_min = dv == FL_INF16 ? INFINITY : (double)dv;
     }
     const int oa = vs[F_OA * CAP + k], pc = vs[F_PC * CAP + k], ot = vs[F_OT * CAP + k], un = vs[F_UNUS * CAP + k];
@@ -569,8 +543,8 @@ __device__ __forceinline__ int child_state(const ObsCtx &X, const NodeDesc &nd, 
     const uint32_t edir = nd.end & 3;
     const uint32_t pbits = nibble(cw_bits(X, ecell), edir);
     const uint32_t bd = (edir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
-    if (nd.flags & ND_DEAD_END) return ((pbits >> (3 - rev)) & 1) ? ((step_cell(ecell, rev, X.W) << 2) | (int)rev) : -1;
-    return ((pbits >> (3 - bd)) & 1) ? ((step_cell(ecell, bd, X.W) << 2) | (int)bd) : -1;
+    if (nd.flags & ND_DEAD_END) return ((pbits >> (3 - rev)) & 1) ? state_towards(X, ecell, rev) : -1;
+    return ((pbits >> (3 - bd)) & 1) ? state_towards(X, ecell, bd) : -1;
 }
 
 // scale_node (treeobs.cpp:111-152), float32 arithmetic
@@ -617,6 +591,19 @@ __device__ __forceinline__ int road_type_of(uint32_t cell) {  // loader.cpp:122-
 }
 
 
+// LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
+enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
+       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_LP, L_A_N, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
+       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_NH, L_CSR2, L_TMASKB, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
+#define L_ABSENT 0xFFFFFFFFu
+struct ObsLayout {
+    unsigned off[L_COUNT];  // byte offset into the dynamic LDS, L_ABSENT = not in this launch
+    unsigned total;         // bytes of dynamic LDS
+    int nt;                 // threads per workgroup
+    int wl_bytes;           // size of the pass B work lists
+    int tab_lds;            // the env's dm / seg / nh / hop8 tables are staged in LDS (kernel template TAB_LDS)
+};
+
 // ---------------------------------------------------------------------------------------------- kernel
 // outputs of the flatland_cutils builder and of the upstream dense tree builder (k_obs MODE 0 / 1 / 2 = both)
 struct ObsArgs {
@@ -629,13 +616,9 @@ struct ObsArgs {
     int n_tree_nodes;
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
     int tw_c, tw_t, tpw_t;  // node-table words per team of the cutils / upstream builder (0 = builder not in this launch), upstream teams per wavefront
-    int nh_lds_words;  // u16 entries of next-hop table staged in LDS (0: read it from HBM)
-    int wl_bytes;      // LDS bytes of the pass B work lists
-    int use_tmask;     // per-key time-bucket masks in LDS (needs the keys in LDS)
+    int use_tmask;     // per-key time-bucket masks in LDS
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
-    int partial_own;   // own scratch for the key scan (else it borrows the work-list area)
-    int items_lds;     // reserve LDS for the prediction items (maps whose items never fit keep them in HBM and spend the LDS elsewhere)
-    unsigned lds_bytes; // dynamic LDS of the launch (the kernel checks its own carving against it)
+    ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
 };
 
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
@@ -647,7 +630,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
                                               const int *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
                                               const double *a_speed, const int *a_tslot) {
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
-    const int A = X.A, W = X.W, HW = X.HW;
+    const int A = X.A;
     const int team = lane / TEAM, tl = lane % TEAM;
     const int D = P.max_depth, NN = P.n_tree_nodes;
     int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
@@ -667,7 +650,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         if (__popc(rbits) == 1) orientation = first_dir(rbits);
         double *out = P.tree_out + (size_t)g * NN * 12;
         if (have && tl == 0) {
-            const uint16_t dv = X.dm[((size_t)a_tslot[i] * HW + vpos) * 4 + dir];
+            const uint16_t dv = X.dm[a_tslot[i] * X.SS + vpos * 4 + (int)dir];
             double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
             root[9] = (double)a_malf[i];
@@ -681,7 +664,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         if (tl < 4) {
             const uint32_t bd = (orientation + (uint32_t)(tl + 3)) & 3u;
             c_index = 1 + tl * sz[1];
-            if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
+            if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
         }
         int width = 4;
         for (int level = 1; level <= D; level++) {
@@ -747,7 +730,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
                                               const int *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
     constexpr int CAP = 32;
-    const int A = X.A, W = X.W, HW = X.HW, N = P.max_nodes;
+    const int A = X.A, N = P.max_nodes;
     const int ia = have ? i : 0;
     const int g = b * A + ia;
     const int vpos = a_vpos[ia];
@@ -761,8 +744,8 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint16_t dv = FL_INF16;
         if (state == ST_DONE) dv = 0;
-        else dv = X.dm[((size_t)a_tslot[i] * HW + (is_off_map(state) ? d.init_pos[g] : a_pos[i])) * 4 +
-                       (is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
+        else dv = X.dm[a_tslot[i] * X.SS + (is_off_map(state) ? vpos : a_pos[i]) * 4 +  // off the map: vpos = initial position
+                       (int)(is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
         root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
         root[9] = (double)((d.malf[g] >> 16) != 0);
         root[10] = (double)(float)a_speed[i];
@@ -775,7 +758,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
     if (gl < 3) {
         c_act = gl - 1;
         const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
-        if ((rbits >> (3 - bd)) & 1) c_state = (step_cell(vpos, bd, W) << 2) | (int)bd;
+        if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
     }
     int n_cur = 3, node_base = 1, levels = 0;
     if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
@@ -926,61 +909,64 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
 
 // One observation build for the workgroup's env.  STAGE 0: stand-alone; the fused launch (both builders) runs STAGE 1
 // (cutils; also prepares what the second stage needs) and then STAGE 2 (upstream tree), which reuses the LDS-resident
-// rail bitmap / occupancy table / next-hop tables and the predicted paths of stage 1: the upstream predictor's path
+// rail words / occupancy table / static tables and the predicted paths of stage 1: the upstream predictor's path
 // is a prefix of the cutils one (same greedy descent, it only stops at the target and after fewer steps).
-template <bool CUTILS, bool CSR_LDS, int STAGE>
+// TAB_LDS: the env's distance map, segment, next-hop and eight-hop tables were staged in LDS (small maps).
+template <bool CUTILS, bool TAB_LDS, int STAGE>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int A = d.A, H = d.H, W = d.W, HW = H * W;
-    const bool keycell = H <= W;  // col * W + row is injective over the grid: use the cell id as prediction key
-    const int K = keycell ? HW : (W - 1) * W + H;
+    const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
+    const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
 
     extern __shared__ __align__(16) unsigned char lds[];
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { void *p = lds + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    constexpr bool CW16 = !CSR_LDS;  // large maps: u16 rail bitmap + hash set of the occupied cells (see ObsCtx)
-    const int HC = obs_hash_cap(A), n_slots_occ = CW16 ? HC : A;
-    uint32_t *cellw = (uint32_t *)carve(CW16 ? (size_t)HW * 2 : (size_t)HW * 4);  // rail bitmap | occupied-cell table index << 16
-    uint16_t *cell16 = reinterpret_cast<uint16_t *>(cellw);
-    int *hkey = (int *)carve(CW16 ? (size_t)HC * 4 : 16);
-    int *slot_agent = (int *)carve((size_t)n_slots_occ * 4);
-    int *slot_ready = (int *)carve((size_t)n_slots_occ * 4);
-    uint32_t *cell_target = (uint32_t *)carve((size_t)((HW + 31) / 32) * 4);
-    double *a_speed = (double *)carve((size_t)A * 8);
-    int *a_vpos = (int *)carve((size_t)A * 4);
-    int *a_pos = (int *)carve((size_t)A * 4);
-    int *a_tslot = (int *)carve((size_t)A * 4);
-    int *a_target = (int *)carve((size_t)A * 4);
-    uint16_t *a_malf = (uint16_t *)carve((size_t)A * 2);
-    uint16_t *a_tpc = (uint16_t *)carve((size_t)A * 2);
-    uint16_t *a_lp = (uint16_t *)carve((size_t)A * 2);
-    uint16_t *a_n = (uint16_t *)carve((size_t)A * 2);  // waypoints of the agent's predicted path
-    uint8_t *a_dir = (uint8_t *)carve((size_t)A);
-    uint8_t *a_state = (uint8_t *)carve((size_t)A);
-    uint8_t *a_free = (uint8_t *)carve((size_t)A);
-    uint8_t *a_dead = (uint8_t *)carve((size_t)A);
-    int *misc = (int *)carve(64 * 4);
-    int *team_meta = (int *)carve(256 * 4);
-    int *wave_scr = (int *)carve((size_t)obs_scr_words(nt >> 6, A, P.tw_c, P.tw_t, P.tpw_t) * 4);  // the teams' node tables
-    int *csr_lds = (int *)carve(CSR_LDS ? (size_t)(K + 1) * 4 : 16);
-    uint32_t *items_lds = (uint32_t *)carve(CSR_LDS && P.items_lds ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16);
-    uint32_t *wl_lds = (uint32_t *)carve((size_t)P.wl_bytes);  // pass B work lists; scratch of the key scan before that
-    int *partial = P.partial_own ? (int *)carve((size_t)nt * 4) : reinterpret_cast<int *>(wl_lds);
-    unsigned long long *tmask = (unsigned long long *)carve(CSR_LDS && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
-    uint16_t *nh_lds = (uint16_t *)carve((size_t)P.nh_lds_words * 2);
+    const ObsLayout &L = P.L;
+#define LDS_AT(T, which) reinterpret_cast<T *>(lds + L.off[which])
+#define LDS_OPT(T, which) (L.off[which] == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L.off[which]))
+    uint32_t *cellw = LDS_AT(uint32_t, L_CELLW);  // rail bitmap | occupied-cell table index << 16
+    uint16_t *nbr = LDS_AT(uint16_t, L_NBR);
+    uint16_t *snext = LDS_OPT(uint16_t, L_SNEXT);
+    uint16_t *rkey = LDS_OPT(uint16_t, L_RKEY);
+    int *slot_agent = LDS_AT(int, L_SLOT_AGENT);
+    int *slot_ready = LDS_AT(int, L_SLOT_READY);
+    uint32_t *cell_target = LDS_AT(uint32_t, L_CELL_TARGET);
+    double *a_speed = LDS_AT(double, L_A_SPEED);
+    int *a_vpos = LDS_AT(int, L_A_VPOS);
+    int *a_pos = LDS_AT(int, L_A_POS);
+    int *a_tslot = LDS_AT(int, L_A_TSLOT);
+    int *a_target = LDS_AT(int, L_A_TARGET);
+    uint16_t *a_malf = LDS_AT(uint16_t, L_A_MALF);
+    uint16_t *a_tpc = LDS_AT(uint16_t, L_A_TPC);
+    uint16_t *a_lp = LDS_AT(uint16_t, L_A_LP);
+    uint16_t *a_n = LDS_AT(uint16_t, L_A_N);  // waypoints of the agent's predicted path
+    uint8_t *a_dir = LDS_AT(uint8_t, L_A_DIR);
+    uint8_t *a_state = LDS_AT(uint8_t, L_A_STATE);
+    uint8_t *a_free = LDS_AT(uint8_t, L_A_FREE);
+    uint8_t *a_dead = LDS_AT(uint8_t, L_A_DEAD);
+    int *misc = LDS_AT(int, L_MISC);
+    int *team_meta = LDS_AT(int, L_TEAM_META);
+    int *wave_scr = LDS_AT(int, L_WAVE_SCR);  // the teams' node tables
+    int *csr = LDS_AT(int, L_CSR);
+    uint32_t *items_lds = LDS_OPT(uint32_t, L_ITEMS);
+    uint32_t *wl_lds = LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
+    int *partial = L.off[L_PARTIAL] == L_ABSENT ? reinterpret_cast<int *>(wl_lds) : LDS_AT(int, L_PARTIAL);
+    unsigned long long *tmask = LDS_OPT(unsigned long long, L_TMASK);
+    uint16_t *nh_lds = LDS_OPT(uint16_t, L_NH);
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
-    int *csr2 = (int *)carve(P.dual_index ? (size_t)(K + 1) * 4 : 16);
-    unsigned long long *tmaskb = (unsigned long long *)carve(P.dual_index && P.use_tmask ? (size_t)(K + 1) * 8 : 16);
-    uint32_t *items2 = (uint32_t *)carve(P.dual_index ? (size_t)OBS_ITEMS2_CAP * 4 : 16);
-    uint16_t *a_lp2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);
-    uint16_t *a_tpc2 = (uint16_t *)carve(P.dual_index ? (size_t)A * 2 : 16);
-    if (off > P.lds_bytes) {  // host-side sizing (obs_lds_bytes) and this carving disagree: refuse to run
-        if (tid == 0) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);
-        return;
-    }  // next-hop tables of the env's targets when they fit
+    int *csr2 = LDS_OPT(int, L_CSR2);
+    unsigned long long *tmaskb = LDS_OPT(unsigned long long, L_TMASKB);
+    uint32_t *items2 = LDS_OPT(uint32_t, L_ITEMS2);
+    uint16_t *a_lp2 = LDS_OPT(uint16_t, L_A_LP2);
+    uint16_t *a_tpc2 = LDS_OPT(uint16_t, L_A_TPC2);
+    // static tables of the env: LDS copies (TAB_LDS) or HBM
+    uint2 *seg_lds = TAB_LDS ? LDS_AT(uint2, L_SEG) : nullptr;
+    uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
+    uint16_t *hop8_lds = TAB_LDS ? LDS_AT(uint16_t, L_HOP8) : nullptr;
+    const uint2 *gseg = d.seg + (size_t)b * Scap;
+    const uint16_t *gdm = d.dm + (size_t)b * d.Ucap * Scap;
+    const uint16_t *ghop8 = d.hop8 + (size_t)b * d.Ucap * Scap;
+    const uint16_t *gnh = d.nh + (size_t)b * d.Ucap * Rcap;
 
-    const uint16_t *ggrid = d.grid + (size_t)b * HW;
     const int T = d.T[b], tnow = d.t[b];
 #ifdef FL_OBS_TIMING
 #define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 32 + (STAGE == 2 ? 16 : 0) + (k)] = (long long)wall_clock64(); } while (0)
@@ -993,66 +979,72 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     OBS_STAMP(0);
 
     const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
-    // ---- phase 0: stage the rail bitmap, clear the per-cell maps, per-agent snapshot into LDS
-    const uint16_t *gnh = d.nh + (size_t)b * d.Umax * HW;
-    const int nh_n = d.U[b] * HW;
-    const bool nh_in_lds = P.nh_lds_words >= nh_n && (STAGE == 0 ? my_pred_depth >= 0 : true);
+    const bool any_pred = STAGE == 0 ? my_pred_depth >= 0 : true;
+    const bool nh_in_lds = nh_lds != nullptr && any_pred;
+    // ---- phase 0: stage the rail words and the static tables, clear the per-cell maps, per-agent snapshot into LDS
     if (STAGE != 2) {
-    if (CW16) {
-        for (int c = tid; c < HW; c += nt) cell16[c] = ggrid[c];
-        for (int c = tid; c < HC; c += nt) hkey[c] = -1;
-    } else {
-        for (int c = tid; c < HW; c += nt) cellw[c] = (uint32_t)ggrid[c] | 0xFFFF0000u;
-    }
-    if (nh_in_lds) {
-        if ((((uintptr_t)gnh) & 3u) == 0 && (nh_n & 1) == 0) {  // two entries per load
-            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(gnh);
-            uint32_t *l2 = reinterpret_cast<uint32_t *>(nh_lds);
-            for (int c = tid; c < (nh_n >> 1); c += nt) l2[c] = g2[c];
-        } else {
-            for (int c = tid; c < nh_n; c += nt) nh_lds[c] = gnh[c];
+        {
+            const uint16_t *grg = d.rgrid + (size_t)b * Rcap;
+            for (int r = tid; r < R; r += nt) cellw[r] = (uint32_t)grg[r] | 0xFFFF0000u;
+            // u16 tables: two entries per load (every base is 4-byte aligned: Scap is a multiple of 4, Rcap * U pairs up below)
+            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(d.nbr + (size_t)b * Scap);
+            uint32_t *l2 = reinterpret_cast<uint32_t *>(nbr);
+            for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
+            if (snext) {
+                g2 = reinterpret_cast<const uint32_t *>(d.snext + (size_t)b * Scap);
+                l2 = reinterpret_cast<uint32_t *>(snext);
+                for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
+            }
+            if (rkey) {
+                const uint16_t *gk = d.rkey + (size_t)b * Rcap;
+                for (int r = tid; r < R; r += nt) rkey[r] = gk[r];
+            }
+            if (TAB_LDS) {
+                const uint2 *gs2 = reinterpret_cast<const uint2 *>(gdm);   // 8-byte pieces: Scap * 2 B is a multiple of 8
+                uint2 *ld2 = reinterpret_cast<uint2 *>(dm_lds);
+                const int n8 = U * Scap / 4;
+                for (int c = tid; c < n8; c += nt) ld2[c] = gs2[c];
+                gs2 = reinterpret_cast<const uint2 *>(ghop8);
+                ld2 = reinterpret_cast<uint2 *>(hop8_lds);
+                for (int c = tid; c < n8; c += nt) ld2[c] = gs2[c];
+                for (int c = tid; c < NS; c += nt) seg_lds[c] = gseg[c];
+            }
+            if (nh_in_lds)
+                for (int c = tid; c < U * Rcap; c += nt) nh_lds[c] = gnh[c];
         }
-    }
-    for (int i = tid; i < n_slots_occ; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
-    for (int c = tid; c < (HW + 31) / 32; c += nt) cell_target[c] = 0;
-    if (tid < 64) misc[tid] = 0;
-    for (int i = tid; i < A; i += nt) {
-        const int g = b * A + i;
-        const uint32_t pk = d.pk[g], spk = d.spk[g];
-        const uint32_t state = PK_STATE(pk);
-        const int pos = d.pos[g], init_pos = d.init_pos[g], target = d.target[g];
-        const double speed = d.speed[g];
-        a_pos[i] = pos;
-        a_vpos[i] = is_off_map(state) ? init_pos : (is_on_map(state) ? pos : target);  // loader.cpp:74-82
-        a_dir[i] = (uint8_t)PK_DIR(pk);
-        a_state[i] = (uint8_t)state;
-        a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
-        a_malf[i] = (uint16_t)(d.malf[g] & 0xFFFFu);
-        a_speed[i] = speed;
-        a_tslot[i] = d.tslot[g];
-        a_target[i] = target;
-        a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
-        if (CUTILS && STAGE == 1 && P.dual_index) a_tpc2[i] = (uint16_t)(int)(1.0 / speed);  // the upstream predictor's (predictions.py:139)
-        (void)spk;
-    }
-    __syncthreads();
-    // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
-    // Occupied cells get an entry in a small table; the dense per-cell array only holds the entry index.
-    for (int i = tid; i < A; i += nt) {
-        const uint32_t state = a_state[i];
-        const bool on = !is_off_map(state) && a_pos[i] >= 0, off = is_off_map(state);
-        if (on || off) {
-            const int c = on ? a_pos[i] : d.init_pos[b * A + i];
-            int slot = -1;
-            if (CW16) {  // the hash slot of the cell is its table entry
-                int h = (int)(((uint32_t)c * 2654435761u) >> 16) & (HC - 1);
-                while (true) {
-                    const int old = atomicCAS(&hkey[h], -1, c);
-                    if (old == -1 || old == c) break;
-                    h = (h + 1) & (HC - 1);
-                }
-                slot = h;
-            } else {
+        for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
+        for (int c = tid; c < (R + 31) / 32; c += nt) cell_target[c] = 0;
+        if (tid < 64) misc[tid] = 0;
+        const uint16_t *gridx = d.ridx + (size_t)b * d.H * d.W;
+        for (int i = tid; i < A; i += nt) {
+            const int g = b * A + i;
+            const uint32_t pk = d.pk[g];
+            const uint32_t state = PK_STATE(pk);
+            const int pos = d.pos[g];
+            const int init_r = d.init_r[g], target_r = d.target_r[g];
+            const double speed = d.speed[g];
+            const int pos_r = pos < 0 ? -1 : (int)gridx[pos];  // the dynamic state keeps cell ids (C-ABI, step kernel)
+            a_pos[i] = pos_r;
+            a_vpos[i] = is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r);  // loader.cpp:74-82
+            a_dir[i] = (uint8_t)PK_DIR(pk);
+            a_state[i] = (uint8_t)state;
+            a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
+            a_malf[i] = (uint16_t)(d.malf[g] & 0xFFFFu);
+            a_speed[i] = speed;
+            a_tslot[i] = d.tslot[g];
+            a_target[i] = target_r;
+            a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
+            if (CUTILS && STAGE == 1 && P.dual_index) a_tpc2[i] = (uint16_t)(int)(1.0 / speed);  // the upstream predictor's (predictions.py:139)
+        }
+        __syncthreads();
+        // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
+        // Occupied cells get an entry in a small table; the per-cell word only holds the entry index.
+        for (int i = tid; i < A; i += nt) {
+            const uint32_t state = a_state[i];
+            const bool on = !is_off_map(state) && a_pos[i] >= 0, off = is_off_map(state);
+            if (on || off) {
+                const int c = a_vpos[i];  // on the map: the position; off the map: the initial position
+                int slot = -1;
                 unsigned int cur = *(volatile unsigned int *)&cellw[c];
                 while (true) {  // claim (or find) the cell's table entry
                     const unsigned int have = cur >> 16;
@@ -1062,12 +1054,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     if (old == cur) break;
                     cur = old;
                 }
+                if (on) atomicMax(&slot_agent[slot], i);
+                else atomicAdd(&slot_ready[slot], 1);
             }
-            if (on) atomicMax(&slot_agent[slot], i);
-            else atomicAdd(&slot_ready[slot], 1);
+            if (!CUTILS || STAGE == 1) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
         }
-        if (!CUTILS || STAGE == 1) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
-    }
     } else {
         // second stage: only the predictor's times-per-cell differ (int(np.reciprocal(speed)), predictions.py:139)
         for (int i = tid; i < A; i += nt) a_tpc[i] = (uint16_t)(int)(1.0 / a_speed[i]);
@@ -1075,34 +1066,24 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     __syncthreads();
 
     ObsCtx X;
-    X.A = A; X.H = H; X.W = W; X.HW = HW;
-    X.keycell = keycell; X.cellw = cellw; X.cell16 = CW16 ? cell16 : nullptr; X.hkey = hkey; X.hmask = HC - 1; X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
-    X.seg = d.seg + (size_t)b * HW * 4;
+    X.A = A; X.R = R; X.SS = Scap;
+    X.cellw = cellw; X.nbr = nbr; X.snext = snext; X.rkey = rkey;
+    X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
+    X.seg = TAB_LDS ? seg_lds : gseg;
+    X.dm = TAB_LDS ? dm_lds : gdm;
     X.dbg = P.dbg ? P.dbg + (size_t)b * 32 : nullptr;
     X.dbg_base = STAGE == 2 ? 16 : 0;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
-    int *csr = CSR_LDS ? csr_lds : S.cell_head + (size_t)b * (S.keys + 1);
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
-    // large maps (keys in HBM, cell keys injective): the index is keyed by (rail index, bucket of 1 << OBS_BK_SHIFT time steps), which
-    // keeps the lists a conflict query scans short
-    const bool bk = !CSR_LDS && keycell && d.ridx != nullptr;
-    const uint16_t *g_ridx = bk ? d.ridx + (size_t)b * HW : nullptr;
-    const int KX = bk ? d.R[b] * OBS_NBK : K;  // csr keys of this env
-    X.bk_ridx = g_ridx;
-    // ... and its offsets are counted with LDS atomics in the place of the rail bitmap, which nothing reads while the
-    // index is built (the bitmap is staged again afterwards, the offsets go to HBM for the trees)
-    const bool csr_alias = bk && (size_t)(KX + 1) * 4 <= (size_t)HW * 2;
-    int *csr_w = csr_alias ? reinterpret_cast<int *>(cell16) : csr;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
-    X.tmask = (CSR_LDS && P.use_tmask && X.Tn > 0) ? tmask : nullptr;
-    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? P.wl_bytes / (8 * OBS_WL_OCC_DIV) : P.wl_bytes / 8;  // a share of the entries
-    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = P.wl_bytes / 8 - X.wl_occ_cap;
+    X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
+    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? L.wl_bytes / (8 * OBS_WL_OCC_DIV) : L.wl_bytes / 8;  // a share of the entries
+    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = L.wl_bytes / 8 - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
     X.tshift = X.Tn <= 64 ? 0 : OBS_TSHIFT;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
-    X.dm = d.dm + (size_t)b * d.Umax * HW * 4;
 
     OBS_STAMP(1);
     // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  ONE wavefront does all of it (wave-level
@@ -1116,12 +1097,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (is_on_map(a_state[i]) && !a_dead[i]) {
                 const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
                 if (bits == 0) fr = true;
-                const int r = a_pos[i] / W, c = a_pos[i] - r * W;
                 for (uint32_t m = 0; m < 4 && !fr; m++) {
                     if (!((bits >> (3 - m)) & 1)) continue;
-                    const int nr = r + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = c + (m == 1 ? 1 : m == 3 ? -1 : 0);
-                    if (nr < 0 || nc < 0 || nr >= H || nc >= W) { fr = true; continue; }
-                    const uint32_t sl = cw_slot(X, nr * W + nc);
+                    const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                    if (nr == FL_R_NONE) { fr = true; continue; }  // leaves the grid / the rail: nobody can be there
+                    const uint32_t sl = cw_slot(X, (int)nr);
                     if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
                 }
             }
@@ -1136,7 +1116,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     bool fr = false;
                     for (uint32_t m = 0; m < 4 && !fr; m++) {
                         if (!((bits >> (3 - m)) & 1)) continue;
-                        const uint32_t sl = cw_slot(X, step_cell(a_pos[i], m, W));
+                        const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                        const uint32_t sl = nr != FL_R_NONE ? cw_slot(X, (int)nr) : 0xFFFFu;
                         const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
                         if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
                     }
@@ -1159,14 +1140,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const uint32_t scount = PK_SCOUNT(pk), max_count = SPK_MAX_COUNT(spk), init_dir = SPK_INIT_DIR(spk);
             const uint32_t old_dir = PK_OLD_DIR(pk) == 4 ? dir : PK_OLD_DIR(pk);
             // update_dist_target (loader.cpp:163-179)
-            const size_t dmb = (size_t)a_tslot[i] * HW;
-            const uint16_t dv_init = X.dm[(dmb + d.init_pos[g]) * 4 + init_dir];
+            const int dmb = a_tslot[i] * X.SS;
+            const uint16_t dv_init = X.dm[dmb + (int)d.init_r[g] * 4 + (int)init_dir];
             const float init_dist = dv_init == FL_INF16 ? INFINITY : (float)dv_init;
             float dist_target;
             if (state == ST_DONE) dist_target = 0;
             else if (is_off_map(state)) dist_target = init_dist;
             else {
-                const uint16_t dv = X.dm[(dmb + pos) * 4 + dir];
+                const uint16_t dv = X.dm[dmb + pos * 4 + (int)dir];
                 dist_target = dv == FL_INF16 ? INFINITY : (float)dv;
             }
             // valid-action mask (loader.cpp:273-312)
@@ -1182,7 +1163,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         if ((bits >> (3 - nd)) & 1) {
                             va |= 1u << a;
                             cnt++;
-                            if (__popc(cw_bits(X, step_cell(pos, nd, W))) > 2) has_branch = true;
+                            const uint32_t nr = nbr[pos * 4 + (int)nd];
+                            if (nr != FL_R_NONE && __popc(cw_bits(X, (int)nr)) > 2) has_branch = true;
                         }
                     }
                     if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
@@ -1219,7 +1201,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             o[n++] = (float)is_on_map(state);
             for (int k = 15; k >= 0; k--) o[n++] = (float)((cell >> k) & 1u);
             for (int a = 0; a < 5; a++) o[n++] = (float)((va >> a) & 1u);
-            const float max_t = (float)T, max_dist_target = (float)((H + W) * 8);
+            const float max_t = (float)T, max_dist_target = (float)((d.H + d.W) * 8);
             const float f_step = (float)tnow / max_t;
             const float f_latest = (float)d.latest[g] / max_t;
             const float f_before = f_latest - f_step;
@@ -1257,8 +1239,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
         const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : 2;
-        if (!reuse && !(csr_alias && STAGE != 2)) {  // (aliased: stage 0 / 1 still read the bitmap during the walk, see below)
-            for (int k = tid; k <= KX; k += nt) csr_w[k] = 0;
+        if (!reuse) {
+            for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
@@ -1284,50 +1266,37 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int i = base + wsel * 8 + slot;
             const bool have = i < A;
             const int ia = have ? i : 0;
-            uint32_t *path = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            uint16_t *path = S.path + ((size_t)b * A + ia) * S.pred_cap;
             const int u = a_tslot[ia];
-            const uint32_t *h8 = d.hop8 + ((size_t)b * d.Umax + u) * HW * 4;
             uint32_t st = ((uint32_t)a_vpos[ia] << 2) | a_dir[ia];
             bool alive = have && j < n_max;
             auto lead_in = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
                 for (int h = 0; h < 7; h++) {
                     if (alive && h < j) {
                         const uint32_t hop = ((uint32_t)nh_u[st >> 2] >> (3u * (st & 3u))) & 7u;
-                        if (hop == 4u) alive = false;
-                        else st = ((uint32_t)step_cell((int)(st >> 2), hop, W) << 2) | hop;
+                        const uint32_t nr = hop == 4u ? (uint32_t)FL_R_NONE : (uint32_t)nbr[(st & ~3u) | hop];
+                        if (nr == FL_R_NONE) alive = false;
+                        else st = (nr << 2) | hop;
                     }
                 }
             };
-            // two call sites so that each keeps a static address space (LDS copy vs HBM table)
-            if (nh_in_lds) lead_in(nh_lds + (size_t)u * HW);
-            else lead_in(gnh + (size_t)u * HW);
-            int idx = j, last = -1;
-            if (!CSR_LDS && d.chop8) {
-                // large maps: jump in rail-state space through the 16x smaller table (the waypoints are translated back
-                // to cells off the dependent chain)
-                const uint16_t *c8 = d.chop8 + ((size_t)b * d.Umax + u) * d.Rmax * 4;
-                const uint32_t *rc = d.rcell + (size_t)b * d.Rmax;
-                uint32_t rs = alive ? (((uint32_t)d.ridx[(size_t)b * HW + (st >> 2)] << 2) | (st & 3u)) : 0u;
+            auto walk8 = [&](const uint16_t *h8) __attribute__((always_inline)) {
+                int idx = j, last = -1;
                 while (__any(alive)) {
                     if (alive) {
-                        path[idx] = (rc[rs >> 2] << 2) | (rs & 3u);
+                        path[idx] = (uint16_t)st;
                         last = idx;
-                        const uint32_t sn = idx + 8 < n_max ? (uint32_t)c8[rs] : 0xFFFFu;
-                        if (sn == 0xFFFFu) alive = false;
-                        else { rs = sn; idx += 8; }
+                        const uint32_t s8 = idx + 8 < n_max ? (uint32_t)h8[st] : (uint32_t)FL_R_NONE;
+                        if (s8 == FL_R_NONE) alive = false;
+                        else { st = s8; idx += 8; }
                     }
                 }
-            }
-            while (__any(alive)) {
-                if (alive) {
-                    path[idx] = st;
-                    last = idx;
-                    const uint32_t s8 = idx + 8 < n_max ? h8[st] : FL_HOP_NONE;
-                    if (s8 == FL_HOP_NONE) alive = false;
-                    else { st = s8; idx += 8; }
-                }
-            }
-            int m = last;
+                return last;
+            };
+            // separate call sites so that each keeps a static address space (LDS copy vs HBM table)
+            if (nh_in_lds) lead_in(nh_lds + u * Rcap);
+            else lead_in(gnh + (size_t)u * Rcap);
+            int m = TAB_LDS ? walk8(hop8_lds + u * Scap) : walk8(ghop8 + (size_t)u * Scap);
             m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
             if (have && j == 0) {
                 const int n = m + 1;  // lane 0 always records the current position
@@ -1352,25 +1321,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
         }
         __syncthreads();
-        if (csr_alias) {
-            for (int k = tid; k <= KX; k += nt) csr_w[k] = 0;
-            __syncthreads();
-        }
         // waypoints per key: only those that can be occupied within the horizon enter the index
         for (int i = wave; i < A; i += (nt >> 6)) {
-            const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i];
             const int lp2 = dual ? (int)a_lp2[i] : -1;
-            if (bk) {  // one count per time bucket the waypoint's interval touches
-                const int tpc = a_tpc[i], tlast = X.Tn - 1;
-                for (int k = lane; k <= lp; k += 64) {
-                    const int tlo = CUTILS ? (k == 0 ? 0 : (k - 1) * tpc + 1) : k * tpc, span = (CUTILS && k == 0) ? 1 : tpc;
-                    const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
-                    const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
-                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr_w[kb + bb], 1);
-                }
-                continue;
-            }
             for (int k = lane; k <= lp; k += 64) {
                 const int key = key_of(X, (int)(path[k] >> 2));
                 atomicAdd(&csr[key], 1);
@@ -1388,18 +1343,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
-                const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
                 const int lp = a_lp[i];
-                if (bk) {
-                    const int tpc = a_tpc[i], tlast = X.Tn - 1;
-                    for (int k = lane; k <= lp; k += 64) {
-                        const int tlo = k * tpc;
-                        const int thi = (k == lp || tlo + tpc - 1 >= tlast) ? tlast : tlo + tpc - 1;
-                        const int kb = (int)g_ridx[path[k] >> 2] * OBS_NBK;
-                        for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++) atomicAdd(&csr_w[kb + bb], 1);
-                    }
-                    continue;
-                }
                 for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
             }
         }
@@ -1408,10 +1353,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan.  With the second
         // index both counts share the scan, 16 bits each (the launcher guarantees totals below 65536).
         if (!reuse) {
-            const int chunk = (KX + 1 + nt - 1) / nt;
-            const int lo = min(tid * chunk, KX + 1), hi = min(lo + chunk, KX + 1);
+            const int chunk = (K + 1 + nt - 1) / nt;
+            const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
             int sum = 0;
-            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr_w[k];
+            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
@@ -1436,26 +1381,26 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     csr[k] = run & 0xFFFF; csr2[k] = (int)((unsigned)run >> 16);
                     run += v;
                 }
-                if (hi == KX + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
+                if (hi == K + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
             } else {
-                for (int k = lo; k < hi; k++) { const int v = csr_w[k]; csr_w[k] = run; run += v; }  // csr[k] = start of key k
-                if (hi == KX + 1 && lo < hi) misc[2] = run;                                       // total number of items
+                for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
+                if (hi == K + 1 && lo < hi) misc[2] = run;                                      // total number of items
             }
         }
         __syncthreads();
         if (reuse) {  // stage 1 built this index
             csr = csr2; X.csr_end = csr2; X.items_lds = items2;
             X.tmask = P.use_tmask ? tmaskb : nullptr;
-            if (!X.tmask) { X.wl_occ_cap = P.wl_bytes / 8; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
+            if (!X.tmask) { X.wl_occ_cap = L.wl_bytes / 8; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
-        const bool fit = CSR_LDS && P.items_lds && misc[2] <= OBS_ITEMS_LDS_CAP;
+        const bool fit = items_lds != nullptr && misc[2] <= OBS_ITEMS_LDS_CAP;
         const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
         for (int i = wave; !reuse && i < A; i += (nt >> 6)) {
-            const uint32_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
             for (int k = lane; k <= lp; k += 64) {
@@ -1471,14 +1416,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     span = tpc;
                 }
                 const bool to_end = k == lp || tlo + span - 1 >= tlast;
-                if (bk) {  // into the list of every time bucket the interval touches
-                    const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
-                                          ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
-                    const int thi = to_end ? tlast : tlo + span - 1, kb = (int)g_ridx[w >> 2] * OBS_NBK;
-                    for (int bb = min(tlo >> OBS_BK_SHIFT, OBS_NBK - 1); bb <= min(thi >> OBS_BK_SHIFT, OBS_NBK - 1); bb++)
-                        csr_items[atomicAdd(&csr_w[kb + bb], 1)] = item;
-                    continue;
-                }
                 const int key = key_of(X, (int)(w >> 2));
                 if (X.tmask) {  // time buckets this item covers
                     const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
@@ -1502,12 +1439,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         __syncthreads();
-        if (csr_alias && !reuse) {
-            for (int k = tid; k <= KX; k += nt) csr[k] = csr_w[k];
-            __syncthreads();
-            for (int c = tid; c < HW; c += nt) cell16[c] = ggrid[c];
-            __syncthreads();
-        }
     }
 
     OBS_STAMP(4);
@@ -1528,42 +1459,32 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
     }
     OBS_STAMP(5);
+#undef LDS_AT
+#undef LDS_OPT
 }
 
 // MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch
-template <int MODE, bool CSR_LDS>
+template <int MODE, bool TAB_LDS>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
-    if (MODE == 0) obs_body<true, CSR_LDS, 0>(d, S, P);
-    else if (MODE == 1) obs_body<false, CSR_LDS, 0>(d, S, P);
+    if (MODE == 0) obs_body<true, TAB_LDS, 0>(d, S, P);
+    else if (MODE == 1) obs_body<false, TAB_LDS, 0>(d, S, P);
     else {
-        obs_body<true, CSR_LDS, 1>(d, S, P);
+        obs_body<true, TAB_LDS, 1>(d, S, P);
         __syncthreads();
-        obs_body<false, CSR_LDS, 2>(d, S, P);
+        obs_body<false, TAB_LDS, 2>(d, S, P);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-bool fl_obs_large_map(int H, int W) {
-    const size_t K = H <= W ? (size_t)H * W : (size_t)(W - 1) * W + H;
-    return K > OBS_CSR_LDS_MAX_KEYS;
-}
-
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
-    o.keys = d.H <= d.W ? d.H * d.W : (d.W - 1) * d.W + d.H;
     o.items_cap = (size_t)d.A * o.pred_cap;
-    if (d.ridx && d.H <= d.W) {  // the (rail index, time bucket) keying of large maps: an item sits in every bucket it touches
-        if (d.Rmax * OBS_NBK > o.keys) o.keys = d.Rmax * OBS_NBK;
-        o.items_cap = (size_t)d.A * (2 * o.pred_cap + 2 * OBS_NBK);  // <= 2 buckets per item, <= 2 until-the-end items per agent
-    }
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;
-    if (hipMalloc(&p, BA * o.pred_cap * 4) != hipSuccess) return FL_ERR_HIP;
-    o.path = (uint32_t *)p; allocs.push_back(p);
+    if (hipMalloc(&p, BA * o.pred_cap * 2) != hipSuccess) return FL_ERR_HIP;
+    o.path = (uint16_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * o.items_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * (o.keys + 1) * 4) != hipSuccess) return FL_ERR_HIP;
-    o.cell_head = (int *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 32 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);
     (void)s;
@@ -1576,69 +1497,104 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-static size_t obs_lds_bytes(const FlDev &d, bool csr_lds, int nt, const ObsArgs &P, int nh_words, int wl_bytes, bool use_tmask, bool dual, bool items, bool partial_own) {
-    const size_t HW = (size_t)d.H * d.W, A = d.A;
-    const size_t K = d.H <= d.W ? HW : (size_t)(d.W - 1) * d.W + d.H;
-    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t HC = (size_t)obs_hash_cap(d.A);
-    return (csr_lds ? al(HW * 4) + 16 + 2 * al(A * 4) : al(HW * 2) + 3 * al(HC * 4)) + al(((HW + 31) / 32) * 4) + al(A * 8) + al(A * 4) * 4 + al(A * 2) * 4 + al(A) * 4 + al(64 * 4) + al(256 * 4) +
-           al((size_t)obs_scr_words(nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4) + al(csr_lds ? (K + 1) * 4 : 16) +
-           al(csr_lds && items ? (size_t)OBS_ITEMS_LDS_CAP * 4 : 16) + al((size_t)wl_bytes) + (partial_own ? al((size_t)nt * 4) : 0) + al(csr_lds && use_tmask ? (K + 1) * 8 : 16) +
-           al((size_t)nh_words * 2) + al(dual ? (K + 1) * 4 : 16) + al(dual && use_tmask ? (K + 1) * 8 : 16) +
-           al(dual ? (size_t)OBS_ITEMS2_CAP * 4 : 16) + 2 * al(dual ? A * 2 : 16) + 64;
+// what a launch may keep in LDS besides the arrays every launch needs
+struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial; };
+
+// carve the dynamic LDS of a launch: every array the kernel uses, in one place (the kernel follows ObsLayout::off)
+static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &o) {
+    ObsLayout L;
+    for (int k = 0; k < L_COUNT; k++) L.off[k] = L_ABSENT;
+    size_t off = 0;
+    auto put = [&](int which, size_t bytes) { L.off[which] = (unsigned)off; off += (bytes + 15) & ~(size_t)15; };
+    const size_t R = d.Rcap, NS = R * 4, A = d.A, K1 = R + 1, U = d.Ucap;
+    put(L_CELLW, R * 4);
+    put(L_NBR, NS * 2);
+    if (o.snext) put(L_SNEXT, NS * 2);
+    if (d.rkey) put(L_RKEY, R * 2);
+    put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
+    put(L_CELL_TARGET, ((R + 31) / 32) * 4);
+    put(L_A_SPEED, A * 8);
+    put(L_A_VPOS, A * 4); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 4); put(L_A_TARGET, A * 4);
+    put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2);
+    put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
+    put(L_MISC, 64 * 4); put(L_TEAM_META, 256 * 4);
+    put(L_WAVE_SCR, (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4);
+    put(L_CSR, K1 * 4);
+    if (o.items) put(L_ITEMS, (size_t)OBS_ITEMS_LDS_CAP * 4);
+    put(L_WL, (size_t)o.wl_bytes);
+    if (o.partial) put(L_PARTIAL, (size_t)o.nt * 4);
+    if (o.tmask) put(L_TMASK, K1 * 8);
+    if (o.nh || o.tab) put(L_NH, U * R * 2);
+    if (o.dual) {
+        put(L_CSR2, K1 * 4);
+        if (o.tmask) put(L_TMASKB, K1 * 8);
+        put(L_ITEMS2, (size_t)OBS_ITEMS2_CAP * 4);
+        put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2);
+    }
+    if (o.tab) { put(L_SEG, NS * 8); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
+    L.total = (unsigned)off;
+    L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
+    return L;
 }
 
-// pick (keys+items in LDS?, threads per workgroup) so that the workgroup's LDS fits 160 KiB; prefer more wavefronts
-static bool obs_pick_config(const FlDev &d, const ObsArgs &P, int &nh_words, int &wl_bytes, int &use_tmask, int &dual_index, int &items_lds, int &partial_own, bool &csr_lds, int &nt, size_t &lds) {
-    const size_t K = d.H <= d.W ? (size_t)d.H * d.W : (size_t)(d.W - 1) * d.W + d.H;
-    const int nts[3] = {OBS_NT, 512, 256};
-    // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes)
+// Choose what lives in LDS so that the workgroup fits 160 KiB.  Preference, measured on MI355X: the next-hop tables, then
+// the most wavefronts, then all static tables of the env (small maps), the work-list space, the time masks / second index /
+// LDS items, the successor table, own scan scratch.
+static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
+    // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes), FL_OBS_NO_TAB
     static const int force_nt = getenv("FL_OBS_NT") ? atoi(getenv("FL_OBS_NT")) : 0;
     static const size_t lds_limit = getenv("FL_OBS_LDS_LIMIT") ? (size_t)atol(getenv("FL_OBS_LDS_LIMIT")) : (size_t)160 * 1024;
-    // preference: everything in LDS with the most wavefronts; then drop the next-hop tables (<= 24 KiB for all targets
-    // of an env, else they are read from HBM anyway), then the prediction index
-    const int nh_fit = (size_t)d.Umax * d.H * d.W * 2 <= 24 * 1024 ? d.Umax * d.H * d.W : 0;
-    for (int c = 0; c < 4; c++) {
-        csr_lds = (c < 2) && K <= OBS_CSR_LDS_MAX_KEYS;
-        nh_words = (c % 2 == 0) ? nh_fit : 0;
-        if ((c < 2 && !csr_lds) || (c % 2 == 0 && nh_fit == 0)) continue;
+    static const bool no_tab = getenv("FL_OBS_NO_TAB") != nullptr;
+    const int nts[3] = {OBS_NT, 512, 256};
+    const bool nh_fit = (size_t)d.Ucap * d.Rcap * 2 <= 24 * 1024;  // beyond that the next-hop tables stay in HBM / L2
+    const bool dual_ok = P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
+                         (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
+    static const int opts[5][3] = {{1, 1, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {0, 0, 0}};  // masks, second index, items
+    ObsOptions o;
+    for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--)
         for (int k = 0; k < 3; k++) {
-            nt = nts[k];
-            if (force_nt && nt != force_nt) continue;
-            for (wl_bytes = 24 * 1024; wl_bytes >= 8 * 1024; wl_bytes /= 3) {  // a third of the work-list space still does
-                // first to go: the second index of the fused launch, then the LDS copy of the items (the time masks are
-                // worth more: they feed the work lists), then the masks
-                const bool dual_ok = csr_lds && P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
-                                     (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
-                static const int opts[5][3] = {{1, 1, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {0, 0, 0}};  // masks, second index, items
-                for (int opt = 0; opt < 5; opt++) {
-                    use_tmask = opts[opt][0]; dual_index = opts[opt][1]; items_lds = opts[opt][2];
-                    if (((use_tmask || items_lds) && !csr_lds) || (dual_index && !dual_ok)) continue;
-                    for (partial_own = 1; partial_own >= 0; partial_own--) {  // 4 KB of scan scratch: borrowed when tight
-                        lds = obs_lds_bytes(d, csr_lds, nt, P, nh_words, wl_bytes, use_tmask != 0, dual_index != 0, items_lds != 0, partial_own != 0);
-                        if (lds <= lds_limit) return true;
+            o.nt = nts[k];
+            if (force_nt && o.nt != force_nt) continue;
+            for (o.tab = (o.nh && !no_tab) ? 1 : 0; o.tab >= 0; o.tab--)
+                for (o.wl_bytes = 24 * 1024; o.wl_bytes >= 8 * 1024; o.wl_bytes /= 3)  // a third of the work-list space still does
+                    for (int opt = 0; opt < 5; opt++) {
+                        o.tmask = opts[opt][0]; o.dual = opts[opt][1]; o.items = opts[opt][2];
+                        if (o.dual && !dual_ok) continue;
+                        for (o.snext = 1; o.snext >= 0; o.snext--)
+                            for (o.partial = 1; o.partial >= 0; o.partial--) {  // 4 KB of scan scratch: borrowed when tight
+                                const ObsLayout L = obs_layout(d, P, o);
+                                if (L.total <= lds_limit) {
+                                    P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
+                                    return true;
+                                }
+                            }
                     }
-                }
-            }
         }
-    }
     return false;
 }
 
 template <typename KernelT>
-static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P0, size_t lds, int nt, hipStream_t s) {
-    ObsArgs P = P0;
-    P.lds_bytes = (unsigned)lds;
+static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     static const bool verbose = getenv("FL_OBS_VERBOSE") != nullptr;  // diagnostic: the configuration obs_pick_config chose
     static int printed = 0;
+    const ObsLayout &L = P.L;
     if (verbose && printed < 4) {
         printed++;
-        fprintf(stderr, "[fl_obs] %d threads, %zu B LDS: next-hop in LDS %d, work lists %d B, time masks %d, second index %d, items in LDS %d\n",
-                nt, lds, P.nh_lds_words > 0, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds);
+        fprintf(stderr, "[fl_obs] %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d\n",
+                L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT);
     }
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(d.B), dim3(nt), lds, s, d, o, P);
+    hipLaunchKernelGGL(kern, dim3(d.B), dim3(L.nt), L.total, s, d, o, P);
     return FL_OK;
+}
+
+static void obs_tree_args(ObsArgs &P, int max_depth, int tree_pred, double *tree_out) {
+    P.max_depth = max_depth; P.tree_pred = tree_pred; P.tree_out = tree_out;
+    int n = 0, p = 1;
+    for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
+    P.n_tree_nodes = n;
+    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
+    P.tpw_t = max_depth <= 2 ? 2 : 1;
 }
 
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -1649,9 +1605,8 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = F_WORDS * 32;
-    bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
-    return csr_lds ? obs_launch(k_obs<0, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<0, false>, d, o, P, lds, nt, s);
+    if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    return P.L.tab_lds ? obs_launch(k_obs<0, true>, d, o, P, s) : obs_launch(k_obs<0, false>, d, o, P, s);
 }
 
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -1662,43 +1617,31 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
-    P.max_depth = max_depth; P.tree_pred = tree_pred; P.tree_out = tree_out;
-    int n = 0, p = 1;
-    for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
-    P.n_tree_nodes = n;
     P.tw_c = F_WORDS * 32;
-    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
-    P.tpw_t = max_depth <= 2 ? 2 : 1;
-    bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
-    return csr_lds ? obs_launch(k_obs<2, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<2, false>, d, o, P, lds, nt, s);
+    obs_tree_args(P, max_depth, tree_pred, tree_out);
+    if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    return P.L.tab_lds ? obs_launch(k_obs<2, true>, d, o, P, s) : obs_launch(k_obs<2, false>, d, o, P, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
     if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
     ObsArgs P = {};
-    P.max_depth = max_depth; P.tree_pred = pred_depth; P.tree_out = out; P.dbg = o.dbg;
-    int n = 0, p = 1;
-    for (int k = 0; k <= max_depth; k++) { n += p; p *= 4; }
-    P.n_tree_nodes = n;
-    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
-    P.tpw_t = max_depth <= 2 ? 2 : 1;
-    bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
-    return csr_lds ? obs_launch(k_obs<1, true>, d, o, P, lds, nt, s) : obs_launch(k_obs<1, false>, d, o, P, lds, nt, s);
+    P.dbg = o.dbg;
+    obs_tree_args(P, max_depth, pred_depth, out);
+    if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    return P.L.tab_lds ? obs_launch(k_obs<1, true>, d, o, P, s) : obs_launch(k_obs<1, false>, d, o, P, s);
 }
 
-// diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth)
+// diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth):
+// threads, LDS bytes, static tables in LDS, next-hop in LDS, work-list bytes, time masks, second index, items in LDS
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[8]) {
     ObsArgs P = {};
-    P.pred_depth = pred_depth; P.max_depth = max_depth; P.tree_pred = tree_pred;
+    P.pred_depth = pred_depth;
     P.tw_c = F_WORDS * 32;
-    P.tw_t = max_depth <= 2 ? F_WORDS * 32 : F_WORDS * 88;
-    P.tpw_t = max_depth <= 2 ? 2 : 1;
-    bool csr_lds; int nt; size_t lds;
-    if (!obs_pick_config(d, P, P.nh_lds_words, P.wl_bytes, P.use_tmask, P.dual_index, P.items_lds, P.partial_own, csr_lds, nt, lds)) return FL_ERR_ARG;
-    out[0] = nt; out[1] = (int)lds; out[2] = csr_lds; out[3] = P.nh_lds_words > 0; out[4] = P.wl_bytes; out[5] = P.use_tmask;
-    out[6] = P.dual_index; out[7] = P.items_lds;
+    obs_tree_args(P, max_depth, tree_pred, nullptr);
+    if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    out[0] = P.L.nt; out[1] = (int)P.L.total; out[2] = P.L.tab_lds; out[3] = P.L.off[L_NH] != L_ABSENT; out[4] = P.L.wl_bytes; out[5] = P.use_tmask;
+    out[6] = P.dual_index; out[7] = P.L.off[L_ITEMS] != L_ABSENT;
     return FL_OK;
 }

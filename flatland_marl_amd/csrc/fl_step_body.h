@@ -354,8 +354,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         else {
             // len(shortest path) = distance-map value at (position, direction) + 1 waypoints, 0 if unreachable
             // (greedy strict descent of rail_env_shortest_paths.py:203-274 on a consistent BFS map)
-            const int pc = is_off_map(state) ? init_pos : pos;
-            const uint16_t dv = d.dm[(((size_t)b * d.Umax + d.tslot[g]) * HW + pc) * 4 + dir];
+            const uint32_t rr = is_off_map(state) ? (uint32_t)d.init_r[g] : (uint32_t)d.ridx[(size_t)b * HW + pos];
+            const uint16_t dv = d.dm[((size_t)b * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4) + rr * 4u + dir];
             const int len = (dv == FL_INF16) ? 0 : (int)dv + 1;
             const int travel = (int)ceil((double)len / d.speed[g]);  // agent_utils.py:129-136
             reward = is_off_map(state) ? -travel : (latest - t) - travel;

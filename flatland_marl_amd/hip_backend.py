@@ -25,8 +25,8 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
-           "fl_load_env", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_positions_map",
+           "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
+           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -70,6 +70,8 @@ def lib():
         L.fl_sync.argtypes = [vp]
         L.fl_load_env.argtypes = [vp, i32] + [vp] * 7 + [i32, u64, i32, i32, vp, i32]
         L.fl_commit.argtypes = [vp]
+        L.fl_reserve.argtypes = [vp, i32, i32]
+        L.fl_distance_map_rebuild_masked.argtypes = [vp, vp]
         L.fl_set_rng.argtypes = [vp, vp, vp]
         L.fl_get_rng.argtypes = [vp, vp, vp]
         L.fl_reset.argtypes = [vp, vp, i32]

@@ -4,11 +4,12 @@
  * Drop-in boundary for the reference's hot path.  Each entry point names the reference interface it
  * replaces (paths relative to /root/reference):
  *
- *   fl_create / fl_load_env / fl_commit   RailEnv.__init__ + reset() state hand-over
+ *   fl_create / fl_reserve / fl_load_env / fl_commit
+ *                                         RailEnv.__init__ + reset() state hand-over, also into a live batch
  *                                         (flatland-rl/flatland/envs/rail_env.py:100-207, 260-357) and
  *                                         flatland_cutils TreeObsForRailEnv.set_env()/reset()
  *                                         (flatland_cutils/src/treeobs.cpp:17-28, loader.cpp:207-219,329-333)
- *   fl_distance_map                       DistanceMap.get()/_compute (flatland/envs/distance_map.py:27-79)
+ *   fl_distance_map / _rebuild[_masked]   DistanceMap.get() / reset() + _compute() (flatland/envs/distance_map.py:27-79)
  *   fl_reset                              RailEnv.reset_agents() (rail_env.py:236-241, agent_utils.py:90-105)
  *   fl_step                               RailEnv.step(action_dict) (rail_env.py:501-634)
  *   fl_obs_cutils                         flatland_cutils.TreeObsForRailEnv.get_many() + get_properties()
@@ -73,14 +74,23 @@ void fl_destroy(fl_batch *h);
 int fl_set_stream(fl_batch *h, void *hip_stream);
 int fl_sync(fl_batch *h);
 
-/* Stage env b on the host side of the handle.  init_pos/target: int32[A][2] (row, col); speed: float64[A];
+/* Stage env b on the host side of the handle.  init_pos/target: int32[A][2] (row, col), both on rail cells; speed: float64[A];
  * malf_threshold = ceil((1 - exp(-rate)) * 2^53), 0 for no malfunctions (malfunction_generators.py:24-53);
- * mt_key[624], mt_pos: numpy RandomState (MT19937) state AFTER reset(). */
+ * mt_key[624], mt_pos: numpy RandomState (MT19937) state AFTER reset().
+ * After the first fl_commit the same call REPLACES env b of the live batch (RailEnv.reset(regenerate_rail=True,
+ * regenerate_schedule=True), rail_env.py:288-320): a new map, new agents, a new RNG state; it takes effect at the next
+ * fl_commit.  The new env has to fit the batch's capacities (FL_ERR_CAPACITY otherwise; see fl_reserve).  A refused call
+ * leaves the staged env unchanged. */
 int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_pos, const int32_t *init_dir,
                 const int32_t *target, const double *speed, const int32_t *earliest, const int32_t *latest,
                 int max_episode_steps, uint64_t malf_threshold, int malf_min, int malf_max,
                 const uint32_t *mt_key, int mt_pos);
-/* Upload all staged envs, build the distance maps on the GPU, reset all agents. */
+/* Before the first fl_commit: capacity per env for maps loaded later -- unique targets and rail cells.  Default: the
+ * largest values among the envs of the first commit. */
+int fl_reserve(fl_batch *h, int max_targets, int max_rail_cells);
+/* First call: upload all staged envs, build the distance maps and static tables on the GPU, reset all agents.
+ * Later calls: the same for exactly the envs loaded since the last commit (the rest of the batch keeps running state);
+ * no-op if there are none. */
 int fl_commit(fl_batch *h);
 /* Per-env RNG replacement after commit (host arrays: mt_key uint32[B][624], mt_pos int32[B]). */
 int fl_set_rng(fl_batch *h, const uint32_t *mt_key, const int32_t *mt_pos);
@@ -175,9 +185,12 @@ int fl_motion_check(int device, int n_cases, const int32_t *offsets, const int32
 /* distance map of env b: returns number of unique targets in *n_targets; dm u16[n][H][W][4] (0xFFFF = inf),
  * target_slot int32[A].  dm may be NULL to query n only. */
 int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *target_slot);
-/* Rebuild the distance maps (and the static branch-walk tables) of all envs on the GPU from the resident grids:
- * DistanceMap.reset() + _compute() (distance_map.py:47-79), e.g. inside the step loop at every auto-reset. */
+/* Rebuild the distance maps (and the static branch-walk / next-hop tables) of all envs on the GPU from the resident
+ * grids: DistanceMap.reset() + _compute() (distance_map.py:47-79). */
 int fl_distance_map_rebuild(fl_batch *h);
+/* Same for the envs with mask_dev[b] != 0 only (device u8[B], e.g. the done_all tensor of the step that just ran): the
+ * rebuild the reference does inside reset() (rail_env.py:288-295, 320), without a host round trip. */
+int fl_distance_map_rebuild_masked(fl_batch *h, const uint8_t *mask_dev);
 /* RailEnv.agent_positions (rail_env.py:360-367) of env b: int32[H][W], -1 = free */
 int fl_positions_map(fl_batch *h, int b, int32_t *out);
 /* ALGORITHMIC bytes per agent-step the bench prices the roofline with, for the given obs mix */
