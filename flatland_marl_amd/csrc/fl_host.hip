@@ -733,9 +733,9 @@ int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
 }
 
 // diagnostic (not part of the public header): copy the per-env phase clocks of a -DFL_OBS_TIMING build
-extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][32] */) {
+extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
     NEED_COMMIT(h);
-    HIPCHK(hipMemcpyAsync(out, h->obs.dbg, (size_t)h->B * 32 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->obs.dbg, (size_t)h->B * 64 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return FL_OK;
 }

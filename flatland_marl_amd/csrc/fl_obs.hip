@@ -46,6 +46,7 @@
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
 #define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
+#define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
@@ -69,13 +70,13 @@ struct ObsCtx {
     const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
     const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
     const uint32_t *cell_target;  // LDS bitmap over rail cells: some agent's target (upstream location_has_target)
-    const int *a_vpos;            // LDS per agent: virtual position (rail index)
+    const uint16_t *a_vpos;       // LDS per agent: virtual position (rail index)
     const uint8_t *a_dir, *a_state;
     const uint16_t *a_malf;       // real down counter
     const double *a_speed;
     const uint16_t *a_tpc;        // times per cell of the predictor
-    const int *a_tslot;
-    const int *a_target;          // rail index
+    const uint16_t *a_tslot;
+    const uint16_t *a_target;     // rail index
     const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
@@ -85,6 +86,7 @@ struct ObsCtx {
     // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
+    bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
     int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
     const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
     int tshift;
@@ -227,7 +229,7 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, 
     // separate call sites so that each keeps a static address space; whole lists in HBM scratch (large maps without time
     // masks) are fetched in bigger batches: their round trips are what the scan costs
     if (ITL) scan(X.items_lds, std::integral_constant<int, 4>());
-    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, 4>());  // chunked work-list entries: short ranges
+    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK>());  // chunked work-list entries: the whole chunk in flight at once
     else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
     return flags;
 }
@@ -240,6 +242,12 @@ __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int nod
     const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
     if (hi <= lo) return;
     if (conflict_hit(conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi))) atomicMin(&sc[F_PC * CAP + node], tot);
+}
+
+// flag word of a conflict work-list entry (other lanes OR their bits into it)
+__device__ __forceinline__ uint32_t wl_flags(const ObsCtx &X, const uint2 *e) {
+    if (X.wl_hbm) return __hip_atomic_load(&e->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e->y;
 }
 
 // append e to a work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
@@ -258,7 +266,8 @@ __device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool w
 }
 
 #ifdef FL_OBS_TIMING
-#define TREE_STAMP(X, k) do { __syncthreads(); if (threadIdx.x == 0 && (X).dbg) (X).dbg[(X).dbg_base + (k)] = (long long)wall_clock64(); } while (0)
+// accumulates the time since the previous stamp of this stage in slot k (summed over the rounds of trees)
+#define TREE_STAMP(X, k) do { __syncthreads(); if (threadIdx.x == 0 && (X).dbg) { const long long now_ = (long long)wall_clock64(); (X).dbg[(X).dbg_base + (k)] += now_ - (X).dbg[(X).dbg_base + 15]; (X).dbg[(X).dbg_base + 15] = now_; } } while (0)
 #else
 #define TREE_STAMP(X, k) do {} while (0)
 #endif
@@ -360,7 +369,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             left = nvis - k;
         }
 #ifdef FL_OBS_TIMING
-        if (X.dbg && lane == 0) atomicMax((unsigned long long *)&X.dbg[12], (unsigned long long)((long long)wall_clock64() - dbg_t1));
+        if (X.dbg && lane == 0) atomicMax((unsigned long long *)&X.dbg[24], (unsigned long long)((long long)wall_clock64() - dbg_t1));
 #endif
         // ONE loop over the lane's cells (lanes of a wave run it in lock step); node / team boundaries are side branches
         for (; pos < end; pos++) {
@@ -431,10 +440,9 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #ifdef FL_OBS_TIMING
     if (X.dbg && lane == 0) {
         const long long dbg_t2 = (long long)wall_clock64();
-        if (tid == 0) X.dbg[X.dbg_base + 13] = dbg_t1;  // wavefront 0 enters the slice code
         // slowest lane of the env: slice-loop ticks << 40 | cells per lane << 20 | cells skipped
-        atomicMax((unsigned long long *)&X.dbg[14], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)q << 20) | (unsigned long long)dbg_skip);
-        atomicMax((unsigned long long *)&X.dbg[15], (unsigned long long)total);
+        atomicMax((unsigned long long *)&X.dbg[25], ((unsigned long long)(dbg_t2 - dbg_t1) << 40) | ((unsigned long long)q << 20) | (unsigned long long)dbg_skip);
+        atomicMax((unsigned long long *)&X.dbg[26], (unsigned long long)total);
     }
 #endif
     __syncthreads();
@@ -442,7 +450,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     // step 2: one list entry per lane
     const int n_occ = min(X.wl_cnt[0], X.wl_occ_cap), n_cf = min(X.wl_cnt[1], X.wl_cf_cap);
 #ifdef FL_OBS_TIMING
-    if (X.dbg && tid == 0) { X.dbg[X.dbg_base + 9] = n_occ; X.dbg[X.dbg_base + 10] = n_cf; }
+    if (X.dbg && tid == 0) { X.dbg[X.dbg_base + 9] += n_occ; X.dbg[X.dbg_base + 10] += n_cf; }
 #endif
     for (int e = tid; e < n_occ; e += nt) {
         const uint2 w = X.wl_occ[e];
@@ -451,7 +459,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     }
     // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes
     // further entries for the rest of its list.  First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) |
-    // node << 24; the others: chunk | index of the first entry << 6 | CF_MORE.
+    // node << 24; the others: chunk | index of the first entry << 6 (17 bits) | CF_MORE.
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
         int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0;
@@ -482,8 +490,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const uint2 w = X.wl_cf[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         const bool more = (w.y & CF_MORE) != 0;
-        const int first = more ? (int)((w.y >> 6) & 0xFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
-        const uint32_t fy = more ? X.wl_cf[first].y : w.y;
+        const int first = more ? (int)((w.y >> 6) & 0x1FFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
+        const uint32_t fy = more ? wl_flags(X, &X.wl_cf[first]) : w.y;
         const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
         const int handle = team_meta[128 + team];
         const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
@@ -501,7 +509,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     __syncthreads();
     if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
         for (int e = tid; e < n_cf2; e += nt) {
-            const uint2 w = X.wl_cf[e];
+            uint2 w = X.wl_cf[e];
+            w.y = wl_flags(X, &X.wl_cf[e]);
             if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) atomicMin(&(scr0 + (int)(w.x >> 24) * team_words)[F_PC * CAP + (int)(w.y >> 24)], (int)(w.y & 511u));
         }
@@ -617,6 +626,7 @@ struct ObsArgs {
     long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
     int tw_c, tw_t, tpw_t;  // node-table words per team of the cutils / upstream builder (0 = builder not in this launch), upstream teams per wavefront
     int use_tmask;     // per-key time-bucket masks in LDS
+    int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
 };
@@ -627,8 +637,8 @@ struct ObsArgs {
 template <int TEAM, int CAP, bool ITL>
 __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                               int nwaves, int *wave_scr0, int *team_meta,
-                                              const int *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
-                                              const double *a_speed, const int *a_tslot) {
+                                              const uint16_t *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
+                                              const double *a_speed, const uint16_t *a_tslot) {
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
     const int A = X.A;
     const int team = lane / TEAM, tl = lane % TEAM;
@@ -719,6 +729,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             }
         }
         team_sync();
+        TREE_STAMP(X, 8);
     }
 }
 
@@ -726,9 +737,9 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 // lanes per agent, two teams per wavefront.  Only wave-level synchronisation, so a wavefront can run it whenever the
 // rail bitmap and the agent snapshot are in LDS (the workgroup overlaps it with the path walk of phase 2).
 __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
-                                              int gl, int *scr, const int *a_vpos, const int *a_pos,
+                                              int gl, int *scr, const uint16_t *a_vpos, const int *a_pos,
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
-                                              const int *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
+                                              const uint16_t *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
     constexpr int CAP = 32;
     const int A = X.A, N = P.max_nodes;
     const int ia = have ? i : 0;
@@ -815,8 +826,8 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
 template <bool ITL>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                              int nwaves, int *wave_scr, int *team_meta,
-                                             const int *a_vpos, const int *a_pos, const uint8_t *a_dir,
-                                             const uint8_t *a_state, const double *a_speed, const int *a_tslot,
+                                             const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
+                                             const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot,
                                              float max_dist, bool hoisted) {
     const int A = X.A;
     {
@@ -903,6 +914,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                 }
             }
             team_sync();
+            TREE_STAMP(X, 16);
         }
     }
 }
@@ -911,9 +923,11 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
 // (cutils; also prepares what the second stage needs) and then STAGE 2 (upstream tree), which reuses the LDS-resident
 // rail words / occupancy table / static tables and the predicted paths of stage 1: the upstream predictor's path
 // is a prefix of the cutils one (same greedy descent, it only stops at the target and after fewer steps).
-// TAB_LDS: the env's distance map, segment, next-hop and eight-hop tables were staged in LDS (small maps).
-template <bool CUTILS, bool TAB_LDS, int STAGE>
+// VAR 1 (small maps): the env's distance map, segment, next-hop and eight-hop tables are staged in LDS.  VAR 2 (large maps):
+// the pass B work lists live in HBM scratch, which leaves the LDS to the time masks and lifts the cap on their entries.
+template <bool CUTILS, int VAR, int STAGE>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
+    constexpr bool TAB_LDS = VAR == 1, WL_HBM = VAR == 2;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
@@ -931,10 +945,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *slot_ready = LDS_AT(int, L_SLOT_READY);
     uint32_t *cell_target = LDS_AT(uint32_t, L_CELL_TARGET);
     double *a_speed = LDS_AT(double, L_A_SPEED);
-    int *a_vpos = LDS_AT(int, L_A_VPOS);
+    uint16_t *a_vpos = LDS_AT(uint16_t, L_A_VPOS);
     int *a_pos = LDS_AT(int, L_A_POS);
-    int *a_tslot = LDS_AT(int, L_A_TSLOT);
-    int *a_target = LDS_AT(int, L_A_TARGET);
+    uint16_t *a_tslot = LDS_AT(uint16_t, L_A_TSLOT);
+    uint16_t *a_target = LDS_AT(uint16_t, L_A_TARGET);
     uint16_t *a_malf = LDS_AT(uint16_t, L_A_MALF);
     uint16_t *a_tpc = LDS_AT(uint16_t, L_A_TPC);
     uint16_t *a_lp = LDS_AT(uint16_t, L_A_LP);
@@ -948,8 +962,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *wave_scr = LDS_AT(int, L_WAVE_SCR);  // the teams' node tables
     int *csr = LDS_AT(int, L_CSR);
     uint32_t *items_lds = LDS_OPT(uint32_t, L_ITEMS);
-    uint32_t *wl_lds = LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
-    int *partial = L.off[L_PARTIAL] == L_ABSENT ? reinterpret_cast<int *>(wl_lds) : LDS_AT(int, L_PARTIAL);
+    uint32_t *wl_lds = WL_HBM ? nullptr : LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
+    int *partial = (WL_HBM || L.off[L_PARTIAL] != L_ABSENT) ? LDS_AT(int, L_PARTIAL) : reinterpret_cast<int *>(wl_lds);
+    const int wl_entries = WL_HBM ? S.wl_cap : L.wl_bytes / 8;
     unsigned long long *tmask = LDS_OPT(unsigned long long, L_TMASK);
     uint16_t *nh_lds = LDS_OPT(uint16_t, L_NH);
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
@@ -969,12 +984,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 
     const int T = d.T[b], tnow = d.t[b];
 #ifdef FL_OBS_TIMING
-#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 32 + (STAGE == 2 ? 16 : 0) + (k)] = (long long)wall_clock64(); } while (0)
+#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) { const long long now_ = (long long)wall_clock64(); P.dbg[(size_t)b * 64 + (STAGE == 2 ? 32 : 0) + (k)] = now_; P.dbg[(size_t)b * 64 + (STAGE == 2 ? 32 : 0) + 15] = now_; } } while (0)
 #else
 #define OBS_STAMP(k) do {} while (0)
 #endif
 #ifdef FL_OBS_TIMING
-    if (tid == 0 && STAGE != 2) { P.dbg[(size_t)b * 32 + 12] = 0; P.dbg[(size_t)b * 32 + 14] = 0; P.dbg[(size_t)b * 32 + 15] = 0; }
+    if (tid < 64 && STAGE != 2) P.dbg[(size_t)b * 64 + tid] = 0;
+    __syncthreads();
 #endif
     OBS_STAMP(0);
 
@@ -1025,14 +1041,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const double speed = d.speed[g];
             const int pos_r = pos < 0 ? -1 : (int)gridx[pos];  // the dynamic state keeps cell ids (C-ABI, step kernel)
             a_pos[i] = pos_r;
-            a_vpos[i] = is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r);  // loader.cpp:74-82
+            a_vpos[i] = (uint16_t)(is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r));  // loader.cpp:74-82
             a_dir[i] = (uint8_t)PK_DIR(pk);
             a_state[i] = (uint8_t)state;
             a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
             a_malf[i] = (uint16_t)(d.malf[g] & 0xFFFFu);
             a_speed[i] = speed;
-            a_tslot[i] = d.tslot[g];
-            a_target[i] = target_r;
+            a_tslot[i] = (uint16_t)d.tslot[g];
+            a_target[i] = (uint16_t)target_r;
             a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
             if (CUTILS && STAGE == 1 && P.dual_index) a_tpc2[i] = (uint16_t)(int)(1.0 / speed);  // the upstream predictor's (predictions.py:139)
         }
@@ -1071,8 +1087,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
     X.seg = TAB_LDS ? seg_lds : gseg;
     X.dm = TAB_LDS ? dm_lds : gdm;
-    X.dbg = P.dbg ? P.dbg + (size_t)b * 32 : nullptr;
-    X.dbg_base = STAGE == 2 ? 16 : 0;
+    X.dbg = P.dbg ? P.dbg + (size_t)b * 64 : nullptr;
+    X.dbg_base = STAGE == 2 ? 32 : 0;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
@@ -1080,10 +1096,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
-    X.wl_occ = reinterpret_cast<uint2 *>(wl_lds); X.wl_occ_cap = X.tmask ? L.wl_bytes / (8 * OBS_WL_OCC_DIV) : L.wl_bytes / 8;  // a share of the entries
-    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = L.wl_bytes / 8 - X.wl_occ_cap;
+    X.wl_hbm = WL_HBM;
+    X.wl_occ = WL_HBM ? S.wl + (size_t)b * S.wl_cap : reinterpret_cast<uint2 *>(wl_lds);
+    X.wl_occ_cap = X.tmask ? wl_entries / OBS_WL_OCC_DIV : wl_entries;  // a share of the entries
+    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
-    X.tshift = X.Tn <= 64 ? 0 : OBS_TSHIFT;  // bucket = min(t >> tshift, 63): fine where the traffic is, one catch-all bucket for late times
+    X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = min(t >> tshift, 63)
 
     OBS_STAMP(1);
     // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  ONE wavefront does all of it (wave-level
@@ -1238,7 +1256,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // then starts at its trees.  misc[4] tells stage 2 that the second index is complete.
         const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
         const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
-        const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : 2;
+        const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
@@ -1251,7 +1269,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // nw_walk wavefronts walk, the one before them does phase 1, and every wavefront (the walkers afterwards) runs pass A
         // of the first round of cutils trees for its two agents -- none of that needs the prediction index.
         const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
-        if (do_p1 && p1_beside_walk && wave == w_first - 1) phase1();
+        if (do_p1 && p1_beside_walk && wave == w_first - 1) {
+            phase1();
+#ifdef FL_OBS_TIMING
+            if (lane == 0) atomicMax((unsigned long long *)&X.dbg[20], (unsigned long long)wall_clock64());
+#endif
+        }
         if (wsel >= 0) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path: its wavefronts issue first
         // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265): the choice
         // at every (target, cell, orientation) is static (k_nexthop), so the predicted path is the chain of next-hops from
@@ -1313,6 +1336,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         if (wsel >= 0) __builtin_amdgcn_s_setprio(0);
+#ifdef FL_OBS_TIMING
+        if (wsel >= 0 && lane == 0) atomicMax((unsigned long long *)&X.dbg[21], (unsigned long long)wall_clock64());
+#endif
         if (CUTILS) {
             const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
             int node_base, levels;
@@ -1320,6 +1346,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                           a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T, node_base, levels);
             if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
         }
+#ifdef FL_OBS_TIMING
+        if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
+#endif
         __syncthreads();
         // waypoints per key: only those that can be occupied within the horizon enter the index
         for (int i = wave; i < A; i += (nt >> 6)) {
@@ -1391,7 +1420,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (reuse) {  // stage 1 built this index
             csr = csr2; X.csr_end = csr2; X.items_lds = items2;
             X.tmask = P.use_tmask ? tmaskb : nullptr;
-            if (!X.tmask) { X.wl_occ_cap = L.wl_bytes / 8; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
+            if (!X.tmask) { X.wl_occ_cap = wl_entries; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
         const bool fit = items_lds != nullptr && misc[2] <= OBS_ITEMS_LDS_CAP;
         const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
@@ -1463,15 +1492,15 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #undef LDS_OPT
 }
 
-// MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch
-template <int MODE, bool TAB_LDS>
+// MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch; VAR: see obs_body
+template <int MODE, int VAR>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
-    if (MODE == 0) obs_body<true, TAB_LDS, 0>(d, S, P);
-    else if (MODE == 1) obs_body<false, TAB_LDS, 0>(d, S, P);
+    if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
+    else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else {
-        obs_body<true, TAB_LDS, 1>(d, S, P);
+        obs_body<true, VAR, 1>(d, S, P);
         __syncthreads();
-        obs_body<false, TAB_LDS, 2>(d, S, P);
+        obs_body<false, VAR, 2>(d, S, P);
     }
 }
 
@@ -1485,8 +1514,11 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.path = (uint16_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * o.items_cap * 4) != hipSuccess) return FL_ERR_HIP;
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * 32 * 8) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * 64 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);
+    o.wl_cap = OBS_WL_HBM_ENTRIES;
+    if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
+    o.wl = (uint2 *)p; allocs.push_back(p);
     (void)s;
     return FL_OK;
 }
@@ -1514,15 +1546,15 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
     put(L_CELL_TARGET, ((R + 31) / 32) * 4);
     put(L_A_SPEED, A * 8);
-    put(L_A_VPOS, A * 4); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 4); put(L_A_TARGET, A * 4);
+    put(L_A_VPOS, A * 2); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 2); put(L_A_TARGET, A * 2);
     put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2);
     put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
     put(L_MISC, 64 * 4); put(L_TEAM_META, 256 * 4);
     put(L_WAVE_SCR, (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4);
     put(L_CSR, K1 * 4);
     if (o.items) put(L_ITEMS, (size_t)OBS_ITEMS_LDS_CAP * 4);
-    put(L_WL, (size_t)o.wl_bytes);
-    if (o.partial) put(L_PARTIAL, (size_t)o.nt * 4);
+    if (o.wl_bytes) put(L_WL, (size_t)o.wl_bytes);       // 0: the work lists live in HBM scratch
+    if (o.partial || !o.wl_bytes) put(L_PARTIAL, (size_t)o.nt * 4);
     if (o.tmask) put(L_TMASK, K1 * 8);
     if (o.nh || o.tab) put(L_NH, U * R * 2);
     if (o.dual) {
@@ -1537,39 +1569,72 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     return L;
 }
 
-// Choose what lives in LDS so that the workgroup fits 160 KiB.  Preference, measured on MI355X: the next-hop tables, then
-// the most wavefronts, then all static tables of the env (small maps), the work-list space, the time masks / second index /
-// LDS items, the successor table, own scan scratch.
+// Choose what lives in LDS so that the workgroup fits 160 KiB.
 static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes), FL_OBS_NO_TAB
     static const int force_nt = getenv("FL_OBS_NT") ? atoi(getenv("FL_OBS_NT")) : 0;
     static const size_t lds_limit = getenv("FL_OBS_LDS_LIMIT") ? (size_t)atol(getenv("FL_OBS_LDS_LIMIT")) : (size_t)160 * 1024;
     static const bool no_tab = getenv("FL_OBS_NO_TAB") != nullptr;
+    // FL_OBS_FORCE="nt=512,wl=8192,tab=0,nh=1,tmask=1,dual=0,items=0,snext=1": only configurations with these values
+    struct Force { int nt = -1, wl = -1, tab = -1, nh = -1, tmask = -1, dual = -1, items = -1, snext = -1; };
+    static const Force force = [] {
+        Force f;
+        const char *e = getenv("FL_OBS_FORCE");
+        if (!e) return f;
+        const struct { const char *k; int *v; } keys[] = {{"nt=", &f.nt}, {"wl=", &f.wl}, {"tab=", &f.tab}, {"nh=", &f.nh},
+                                                         {"tmask=", &f.tmask}, {"dual=", &f.dual}, {"items=", &f.items}, {"snext=", &f.snext}};
+        for (const auto &kv : keys) {
+            const char *q = strstr(e, kv.k);
+            if (q && (q == e || q[-1] == ',')) *kv.v = atoi(q + strlen(kv.k));
+        }
+        return f;
+    }();
+    auto ok = [](int forced, int v) { return forced < 0 || forced == v; };
     const int nts[3] = {OBS_NT, 512, 256};
     const bool nh_fit = (size_t)d.Ucap * d.Rcap * 2 <= 24 * 1024;  // beyond that the next-hop tables stay in HBM / L2
     const bool dual_ok = P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
                          (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
     static const int opts[5][3] = {{1, 1, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {0, 0, 0}};  // masks, second index, items
+    // Order of preference, from same-box A/B runs (tools/obs_sweep.py): the most wavefronts; the full work-list space; the LDS
+    // copy of the items, the time masks and the second index; the successor table; the next-hop tables; own scan scratch.
+    // The env's distance / segment / eight-hop tables join them when there is room left (small maps): they make no
+    // difference in time (their gathers hit L2 and hide behind the rest) but replace narrow HBM gathers with one coalesced read.
     ObsOptions o;
-    for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--)
-        for (int k = 0; k < 3; k++) {
-            o.nt = nts[k];
-            if (force_nt && o.nt != force_nt) continue;
-            for (o.tab = (o.nh && !no_tab) ? 1 : 0; o.tab >= 0; o.tab--)
-                for (o.wl_bytes = 24 * 1024; o.wl_bytes >= 8 * 1024; o.wl_bytes /= 3)  // a third of the work-list space still does
-                    for (int opt = 0; opt < 5; opt++) {
-                        o.tmask = opts[opt][0]; o.dual = opts[opt][1]; o.items = opts[opt][2];
-                        if (o.dual && !dual_ok) continue;
-                        for (o.snext = 1; o.snext >= 0; o.snext--)
-                            for (o.partial = 1; o.partial >= 0; o.partial--) {  // 4 KB of scan scratch: borrowed when tight
-                                const ObsLayout L = obs_layout(d, P, o);
-                                if (L.total <= lds_limit) {
-                                    P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
-                                    return true;
-                                }
-                            }
-                    }
+    o.tab = 0;
+    for (int k = 0; k < 3; k++) {
+        o.nt = nts[k];
+        if ((force_nt && o.nt != force_nt) || !ok(force.nt, o.nt)) continue;
+        // work lists: in LDS when everything else fits beside them (small maps), else in HBM scratch (the LDS goes to the time
+        // masks, the items and the second index; no cap on the entries), else LDS lists with whatever still fits
+        for (int wk = 0; wk < 4; wk++) {
+            o.wl_bytes = wk == 0 || wk == 2 ? 24 * 1024 : wk == 1 ? 0 : 8 * 1024;
+            for (int opt = 0; opt < (wk == 0 ? 1 + !dual_ok : 5); opt++) {
+                o.tmask = opts[opt][0]; o.dual = opts[opt][1]; o.items = opts[opt][2];
+                if (o.dual && !dual_ok) continue;
+                if (!ok(force.wl, o.wl_bytes) || !ok(force.tmask, o.tmask) || !ok(force.dual, o.dual) || !ok(force.items, o.items)) continue;
+                for (o.snext = 1; o.snext >= 0; o.snext--)
+                    for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--)
+                        for (o.partial = 1; o.partial >= 0; o.partial--) {  // 4 KB of scan scratch: borrowed when tight
+                            if (!ok(force.snext, o.snext) || !ok(force.nh, o.nh)) continue;
+                            ObsLayout L = obs_layout(d, P, o);
+                            if (L.total > lds_limit) continue;
+                            if (!no_tab && force.tab != 0 && nh_fit && o.wl_bytes) {
+                                ObsOptions ot = o;
+                                ot.tab = 1;
+                                const ObsLayout Lt = obs_layout(d, P, ot);
+                                if (Lt.total <= lds_limit) L = Lt;
+                                else if (force.tab == 1) continue;
+                            } else if (force.tab == 1) continue;
+                            P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
+                            // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
+                            // whole horizon measured slower on every map size)
+                            static const int force_tshift = getenv("FL_OBS_TSHIFT") ? atoi(getenv("FL_OBS_TSHIFT")) : -1;
+                            P.tshift = force_tshift >= 0 ? force_tshift : OBS_TSHIFT;
+                            return true;
+                        }
+            }
         }
+    }
     return false;
 }
 
@@ -1606,7 +1671,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = F_WORDS * 32;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    return P.L.tab_lds ? obs_launch(k_obs<0, true>, d, o, P, s) : obs_launch(k_obs<0, false>, d, o, P, s);
+    return P.L.tab_lds ? obs_launch(k_obs<0, 1>, d, o, P, s) : P.L.wl_bytes == 0 ? obs_launch(k_obs<0, 2>, d, o, P, s) : obs_launch(k_obs<0, 0>, d, o, P, s);
 }
 
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -1620,7 +1685,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.tw_c = F_WORDS * 32;
     obs_tree_args(P, max_depth, tree_pred, tree_out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    return P.L.tab_lds ? obs_launch(k_obs<2, true>, d, o, P, s) : obs_launch(k_obs<2, false>, d, o, P, s);
+    return P.L.tab_lds ? obs_launch(k_obs<2, 1>, d, o, P, s) : P.L.wl_bytes == 0 ? obs_launch(k_obs<2, 2>, d, o, P, s) : obs_launch(k_obs<2, 0>, d, o, P, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
@@ -1630,7 +1695,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.dbg = o.dbg;
     obs_tree_args(P, max_depth, pred_depth, out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    return P.L.tab_lds ? obs_launch(k_obs<1, true>, d, o, P, s) : obs_launch(k_obs<1, false>, d, o, P, s);
+    return P.L.tab_lds ? obs_launch(k_obs<1, 1>, d, o, P, s) : P.L.wl_bytes == 0 ? obs_launch(k_obs<1, 2>, d, o, P, s) : obs_launch(k_obs<1, 0>, d, o, P, s);
 }
 
 // diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth):

@@ -146,10 +146,11 @@ class BatchedRailEnv:
     `envs` is a list of B mappings with the static description of each env, as produced by the
     reference after reset(): grid u16[H,W], init_pos i32[A,2], init_dir i32[A], target i32[A,2],
     speed f64[A], earliest i32[A], latest i32[A], T, malf_rate, malf_min, malf_max, mt_key u32[624], mt_pos.
-    All envs of one batch share (A, H, W).
+    All envs of one batch share (A, H, W).  reserve = (max unique targets, max rail cells) leaves room for maps loaded
+    into the live batch later (replace_env); default: the largest env of `envs`.
     """
 
-    def __init__(self, envs, device=0, max_nodes=31, pred_depth=500):
+    def __init__(self, envs, device=0, max_nodes=31, pred_depth=500, reserve=None):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -166,17 +167,10 @@ class BatchedRailEnv:
         _chk(L.fl_create(self.B, self.A, self.H, self.W, device, C.byref(h)))
         self.h = h
         self.T = np.zeros(self.B, dtype=np.int32)
+        if reserve is not None:
+            _chk(L.fl_reserve(h, int(reserve[0]), int(reserve[1])))
         for b, e in enumerate(envs):
-            grid = np.ascontiguousarray(e["grid"], dtype=np.uint16)
-            assert grid.shape == (self.H, self.W) and len(e["init_dir"]) == self.A
-            a32 = lambda k: np.ascontiguousarray(e[k], dtype=np.int32)  # noqa: E731
-            ip, idr, tg, ea, la = a32("init_pos"), a32("init_dir"), a32("target"), a32("earliest"), a32("latest")
-            sp = np.ascontiguousarray(e["speed"], dtype=np.float64)
-            key = np.ascontiguousarray(e["mt_key"], dtype=np.uint32)
-            self.T[b] = int(e["T"])
-            _chk(L.fl_load_env(h, b, _p(grid), _p(ip), _p(idr), _p(tg), _p(sp), _p(ea), _p(la), int(e["T"]),
-                               malf_threshold(float(e["malf_rate"])), int(e["malf_min"]), int(e["malf_max"]),
-                               _p(key), int(e["mt_pos"])))
+            self._load(b, e)
         with torch.cuda.device(self.device):
             _chk(L.fl_commit(h))
         B, A = self.B, self.A
@@ -186,6 +180,30 @@ class BatchedRailEnv:
         self._obs = None
         self._tree = {}
         self.use_torch_stream()
+
+    def _load(self, b, e):
+        grid = np.ascontiguousarray(e["grid"], dtype=np.uint16)
+        assert grid.shape == (self.H, self.W) and len(e["init_dir"]) == self.A
+        a32 = lambda k: np.ascontiguousarray(e[k], dtype=np.int32)  # noqa: E731
+        ip, idr, tg, ea, la = a32("init_pos"), a32("init_dir"), a32("target"), a32("earliest"), a32("latest")
+        sp = np.ascontiguousarray(e["speed"], dtype=np.float64)
+        key = np.ascontiguousarray(e["mt_key"], dtype=np.uint32)
+        _chk(lib().fl_load_env(self.h, b, _p(grid), _p(ip), _p(idr), _p(tg), _p(sp), _p(ea), _p(la), int(e["T"]),
+                               malf_threshold(float(e["malf_rate"])), int(e["malf_min"]), int(e["malf_max"]),
+                               _p(key), int(e["mt_pos"])))
+        self.T[b] = int(e["T"])
+
+    def replace_env(self, b, env, commit=True):
+        """RailEnv.reset(regenerate_rail=True, regenerate_schedule=True) for env b of the live batch (rail_env.py:288-320):
+        a new map, new agents and a new RNG state; its distance maps and static tables are rebuilt on the GPU, its agents
+        reset, the other envs keep running.  commit=False stages several replacements for one commit()."""
+        self._load(b, env)
+        if commit:
+            self.commit()
+
+    def commit(self):
+        with self.torch.cuda.device(self.device):
+            _chk(lib().fl_commit(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -205,6 +223,12 @@ class BatchedRailEnv:
 
     # ---- dynamics
     def reset(self, mask=None, fresh=True):
+        """mask: host array-like [B], a uint8 device tensor [B] (no host round trip), or None (= all envs)."""
+        t = self.torch
+        if isinstance(mask, t.Tensor) and mask.is_cuda:
+            assert mask.dtype == t.uint8 and mask.numel() == self.B and mask.is_contiguous()
+            _chk(lib().fl_reset_dev(self.h, mask.data_ptr(), int(fresh)))
+            return
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _chk(lib().fl_reset(self.h, None if m is None else _p(m), int(fresh)))
 
@@ -395,9 +419,14 @@ class BatchedRailEnv:
         _chk(lib().fl_distance_map(self.h, b, C.byref(n), _p(dm), _p(slot)))
         return dm, slot
 
-    def rebuild_distance_maps(self):
-        """DistanceMap.reset() + _compute() for every env, on the GPU (asynchronous on the handle's stream)."""
-        _chk(lib().fl_distance_map_rebuild(self.h))
+    def rebuild_distance_maps(self, mask=None):
+        """DistanceMap.reset() + _compute() on the GPU (asynchronous on the handle's stream) for every env, or for the
+        envs with a non-zero entry in `mask` (uint8 device tensor [B], e.g. the done_all tensor of the last step)."""
+        if mask is None:
+            _chk(lib().fl_distance_map_rebuild(self.h))
+        else:
+            assert mask.is_cuda and mask.dtype == self.torch.uint8 and mask.numel() == self.B and mask.is_contiguous()
+            _chk(lib().fl_distance_map_rebuild_masked(self.h, mask.data_ptr()))
 
     def positions_map(self, b):
         out = np.zeros((self.H, self.W), dtype=np.int32)
