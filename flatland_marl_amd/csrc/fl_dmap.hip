@@ -17,6 +17,32 @@
 #define DM_QCAP 4096       /* BFS ring buffer per target: states discovered and not yet expanded */
 #define DM_WAVES 4         /* targets (wavefronts) per workgroup; they share the LDS copy of the env's nbr / rgrid */
 
+// Which envs a (re)build covers: list[0 .. *count) = the envs with mask[b] != 0 (all envs without a mask), in ascending
+// order.  The table kernels loop over (listed env, piece of work) pairs with a grid that does not depend on the count, so
+// a masked rebuild in the step loop -- usually no env or one -- costs four near-empty launches, not four launches of
+// B * Ucap * ... workgroups that exit at once.
+__global__ __launch_bounds__(1024) void k_env_list(int B, const uint8_t *__restrict__ mask, int *__restrict__ list, int *__restrict__ count) {
+    __shared__ int wave_tot[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + (int)threadIdx.x;
+        const bool on = b < B && (!mask || mask[b] != 0);
+        const unsigned long long m = __ballot(on);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; w++) t += wave_tot[w]; base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -28,15 +54,16 @@ __device__ __forceinline__ void wave_sync() {
 // wavefront has no barriers to pay; its queue is a ring in LDS, the visited set a bitmap in LDS, the env's neighbour
 // table and rail bitmap are staged in LDS once per workgroup.  Distances go straight to HBM, unreached states get
 // 0xFFFF at the end (each address written once).
-__global__ __launch_bounds__(64 * DM_WAVES) void k_distance_map(FlDev d, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(64 * DM_WAVES) void k_distance_map(FlDev d, const int *__restrict__ env_list, const int *__restrict__ env_count) {
     const int per = (d.Ucap + DM_WAVES - 1) / DM_WAVES;
-    const int b = blockIdx.x / per, u0 = (blockIdx.x % per) * DM_WAVES;
-    if (mask && !mask[b]) return;
+    const int n_work = *env_count * per;
+    extern __shared__ uint32_t lds[];
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    const int b = env_list[work / per], u0 = (work % per) * DM_WAVES;
     const int U = d.U[b];
-    if (u0 >= U) return;
+    if (u0 >= U) continue;   // (block-uniform)
     const int R = d.R[b], S = R * 4, Scap = d.Rcap * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    extern __shared__ uint32_t lds[];
     uint16_t *nbr = reinterpret_cast<uint16_t *>(lds);                  // [Scap]
     uint16_t *rg = nbr + Scap;                                          // [Rcap] (+ pad to a word)
     const int bw = (Scap + 31) / 32;
@@ -51,7 +78,7 @@ __global__ __launch_bounds__(64 * DM_WAVES) void k_distance_map(FlDev d, const u
     }
     __syncthreads();
     const int u = u0 + wave;
-    if (u < U) {  // no workgroup barrier below this point
+    if (u < U) {  // no workgroup barrier inside this block
         uint32_t *bm = bitmaps + wave * bw;
         uint16_t *q = queues + wave * DM_QCAP;
         uint16_t *out = d.dm + ((size_t)b * d.Ucap + u) * Scap;
@@ -117,6 +144,8 @@ __global__ __launch_bounds__(64 * DM_WAVES) void k_distance_map(FlDev d, const u
             if (!((bm[s >> 5] >> (s & 31)) & 1u)) out[s] = FL_INF16;
         if (overflow && lane == 0) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);
     }
+    __syncthreads();  // the next piece of work reuses the LDS
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- segment table
@@ -137,14 +166,15 @@ __device__ __forceinline__ int seg_next(const uint16_t *rg, const uint16_t *nbr,
     return (int)((nr << 2) | nd);
 }
 
-__global__ __launch_bounds__(256) void k_segments(FlDev d, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict__ env_list, const int *__restrict__ env_count) {
     const int Scap = d.Rcap * 4;
     const int per_env = (Scap + 255) / 256;
-    const int b = blockIdx.x / per_env;
-    if (mask && !mask[b]) return;
-    const int s0 = (blockIdx.x % per_env) * 256 + threadIdx.x;
+    const int n_work = *env_count * per_env;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    const int b = env_list[work / per_env];
+    const int s0 = (work % per_env) * 256 + threadIdx.x;
     const int S = d.R[b] * 4;
-    if (s0 >= Scap) return;
+    if (s0 >= Scap) continue;
     uint2 out = make_uint2((uint32_t)s0 | (SEG_ZERO << 20), 0xFFFF0000u);
     uint16_t sn = FL_R_NONE;
     if (s0 < S) {
@@ -196,6 +226,7 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const uint8_t *__rest
     }
     d.seg[(size_t)b * Scap + s0] = out;
     d.snext[(size_t)b * Scap + s0] = sn;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- next-hop table
@@ -203,13 +234,14 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const uint8_t *__rest
 // greedily: among the valid move actions in the order left, forward, right (a dead end only offers its reverse exit)
 // they take the first one with the smallest distance, if it is finite.  On a BFS map that choice is static per
 // (target, rail cell, orientation); it is tabulated here, 3 bits per orientation (4 = nothing closer), 12 bits per cell.
-__global__ __launch_bounds__(256) void k_nexthop(FlDev d, const uint8_t *__restrict__ mask) {
-    const int per_bu = (d.Rcap + 255) / 256;
-    const int bu = blockIdx.x / per_bu;
-    const int b = bu / d.Ucap, u = bu % d.Ucap;
-    if (mask && !mask[b]) return;
-    const int r = (blockIdx.x % per_bu) * 256 + threadIdx.x;
-    if (r >= d.Rcap) return;
+__global__ __launch_bounds__(256) void k_nexthop(FlDev d, const int *__restrict__ env_list, const int *__restrict__ env_count) {
+    const int per_bu = (d.Rcap + 255) / 256, per_env = d.Ucap * per_bu;
+    const int n_work = *env_count * per_env;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    const int b = env_list[work / per_env], u = (work % per_env) / per_bu;
+    const int bu = b * d.Ucap + u;
+    const int r = (work % per_bu) * 256 + threadIdx.x;
+    if (r >= d.Rcap) continue;
     const int Scap = d.Rcap * 4;
     uint32_t out = 0x924;  // 4 | 4<<3 | 4<<6 | 4<<9
     if (u < d.U[b] && r < d.R[b]) {
@@ -242,19 +274,21 @@ __global__ __launch_bounds__(256) void k_nexthop(FlDev d, const uint8_t *__restr
         }
     }
     d.nh[(size_t)bu * d.Rcap + r] = (uint16_t)out;
+    }
 }
 
 // Eight greedy hops at once: hop8[b][u][s] = the state reached from s after eight next-hops towards target u, or
 // FL_R_NONE when the greedy path ends earlier.  The observation kernels walk a predicted path with eight lanes, lane j
 // covering the waypoints j, j + 8, j + 16, ... (a chain of gathers an eighth as long as the single-step chain).
-__global__ __launch_bounds__(256) void k_hop8(FlDev d, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(256) void k_hop8(FlDev d, const int *__restrict__ env_list, const int *__restrict__ env_count) {
     const int Scap = d.Rcap * 4;
-    const int per_bu = (Scap + 255) / 256;
-    const int bu = blockIdx.x / per_bu;
-    const int b = bu / d.Ucap, u = bu % d.Ucap;
-    if (mask && !mask[b]) return;
-    const int s0 = (blockIdx.x % per_bu) * 256 + threadIdx.x;
-    if (s0 >= Scap) return;
+    const int per_bu = (Scap + 255) / 256, per_env = d.Ucap * per_bu;
+    const int n_work = *env_count * per_env;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    const int b = env_list[work / per_env], u = (work % per_env) / per_bu;
+    const int bu = b * d.Ucap + u;
+    const int s0 = (work % per_bu) * 256 + threadIdx.x;
+    if (s0 >= Scap) continue;
     const uint16_t *nh = d.nh + (size_t)bu * d.Rcap;
     const uint16_t *nbr = d.nbr + (size_t)b * Scap;
     uint32_t st = (uint32_t)s0;
@@ -269,6 +303,7 @@ __global__ __launch_bounds__(256) void k_hop8(FlDev d, const uint8_t *__restrict
         }
     }
     d.hop8[(size_t)bu * Scap + s0] = ok ? (uint16_t)st : (uint16_t)FL_R_NONE;
+    }
 }
 
 static size_t dm_lds_bytes(const FlDev &d) {
@@ -282,21 +317,34 @@ int fl_dmap_prepare(const FlDev &d) {
     return FL_OK;
 }
 
+// grid of a table kernel: every piece of work of a full build gets its own workgroup; a masked rebuild (count unknown on
+// the host, usually tiny) gets a fixed modest grid whose workgroups loop
+static unsigned table_grid(const FlDev &d, bool masked, size_t per_env) {
+    const size_t full = (size_t)d.B * per_env;
+    const size_t g = masked ? (full < 2048 ? full : 2048) : full;
+    return (unsigned)(g > 0x7fffffffull ? 0x7fffffffull : g);
+}
+
+void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_list, dim3(1), dim3(1024), 0, s, d.B, mask_dev, d.env_list, d.env_list + d.B);
+}
+
 void fl_launch_distance_maps(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    const int per = (d.Ucap + DM_WAVES - 1) / DM_WAVES;
-    hipLaunchKernelGGL(k_distance_map, dim3(d.B * per), dim3(64 * DM_WAVES), dm_lds_bytes(d), s, d, mask_dev);
+    const size_t per = (d.Ucap + DM_WAVES - 1) / DM_WAVES;
+    hipLaunchKernelGGL(k_distance_map, dim3(table_grid(d, mask_dev != nullptr, per)), dim3(64 * DM_WAVES), dm_lds_bytes(d), s, d, d.env_list, d.env_list + d.B);
 }
 
 void fl_launch_segments(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    const int Scap = d.Rcap * 4;
-    hipLaunchKernelGGL(k_segments, dim3(d.B * ((Scap + 255) / 256)), dim3(256), 0, s, d, mask_dev);
+    const size_t per = ((size_t)d.Rcap * 4 + 255) / 256;
+    hipLaunchKernelGGL(k_segments, dim3(table_grid(d, mask_dev != nullptr, per)), dim3(256), 0, s, d, d.env_list, d.env_list + d.B);
 }
 
 void fl_launch_nexthop(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    hipLaunchKernelGGL(k_nexthop, dim3((unsigned)((size_t)d.B * d.Ucap * ((d.Rcap + 255) / 256))), dim3(256), 0, s, d, mask_dev);
+    const size_t per = (size_t)d.Ucap * ((d.Rcap + 255) / 256);
+    hipLaunchKernelGGL(k_nexthop, dim3(table_grid(d, mask_dev != nullptr, per)), dim3(256), 0, s, d, d.env_list, d.env_list + d.B);
 }
 
 void fl_launch_hop8(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    const int Scap = d.Rcap * 4;
-    hipLaunchKernelGGL(k_hop8, dim3((unsigned)((size_t)d.B * d.Ucap * ((Scap + 255) / 256))), dim3(256), 0, s, d, mask_dev);
+    const size_t per = (size_t)d.Ucap * (((size_t)d.Rcap * 4 + 255) / 256);
+    hipLaunchKernelGGL(k_hop8, dim3(table_grid(d, mask_dev != nullptr, per)), dim3(256), 0, s, d, d.env_list, d.env_list + d.B);
 }

@@ -302,7 +302,7 @@ int fl_commit(fl_batch *h) {
         if (h->H > h->W) h->h_rkey.assign((size_t)B * Rcap, 0);
         DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
         DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.R, B); DALLOC(d.K, B);
-        DALLOC(d.err, B); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
+        DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
         DALLOC(d.grid, B * HW); DALLOC(d.ridx, B * HW);
         DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
         d.rkey = nullptr;
@@ -335,6 +335,7 @@ int fl_commit(fl_batch *h) {
     const bool all = !h->committed;
     if (!all) HIPCHK(hipMemcpyAsync(h->mask_dev, h->h_dirty.data(), B, hipMemcpyHostToDevice, h->stream));
     const uint8_t *mask = all ? nullptr : h->mask_dev;
+    fl_launch_env_list(d, mask, h->stream);
     fl_launch_distance_maps(d, mask, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_segments(d, mask, h->stream);
@@ -646,6 +647,7 @@ int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *t
 }
 
 static int rebuild_tables(fl_batch *h, const uint8_t *mask_dev) {
+    fl_launch_env_list(h->d, mask_dev, h->stream);
     fl_launch_distance_maps(h->d, mask_dev, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_segments(h->d, mask_dev, h->stream);

@@ -67,6 +67,7 @@ struct FlDev {
     int *R;    // [B] rail cells
     int *K;    // [B] prediction keys (R, or the distinct col * W + row values of the rail cells when H > W)
     int *err;  // [B] first error code raised by a kernel for env b (0 = none)
+    int *env_list;  // [B + 1] scratch of the table (re)builds: the envs being rebuilt, their number at [B] (k_env_list)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
     int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
     uint16_t *grid;   // [B][H*W] transition bitmap per cell (step kernel)
@@ -135,7 +136,8 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 }
 
 // kernel launchers (defined in the .hip files).  mask_dev: u8[B] or nullptr (= every env): only the envs with a non-zero
-// entry are rebuilt.
+// entry are rebuilt.  fl_launch_env_list turns the mask into d.env_list and goes first.
+void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 void fl_launch_distance_maps(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 void fl_launch_segments(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);   // seg + snext
 void fl_launch_nexthop(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);

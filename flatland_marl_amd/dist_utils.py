@@ -46,6 +46,17 @@ def reduce_metrics(metrics):
     return metrics
 
 
+def gather_agent_steps(metrics, device=None):
+    """all-gather of every rank's agent-step counter (metrics[2]): lets a scaling run confirm that N ranks took part and
+    that the shards were equal (weak scaling).  Reporting only, like reduce_metrics."""
+    mine = metrics[2:3].clone()
+    if dist.is_available() and dist.is_initialized():
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        return [int(p.item()) for p in parts]
+    return [int(mine.item())]
+
+
 def max_over_ranks(seconds, device=None):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized():

@@ -1,0 +1,146 @@
+"""Reset-time generators: ctypes binding of include/flatland_gen.h (csrc/gen/libflatland_gen.so, host C++) with the
+reference's names -- `sparse_rail_generator` (flatland/envs/rail_generators.py:161-292), `sparse_line_generator`
+(envs/line_generators.py:57-165), `timetable_generator` (envs/timetable_generators.py:21-96) -- folded into
+`generate_env`, which returns what RailEnv.reset(regenerate_rail=True, regenerate_schedule=True) leaves behind: the static
+description `BatchedRailEnv` / `RailEnv` / `fl_load_env` take, bit for bit the reference's for the same MT19937 state.
+
+The seed -> MT19937 state mapping of RailEnv._seed (gym 0.14 `seeding.np_random`, rail_env.py:210-222) is restated in
+`np_random` below; gym is absent from this image, so that one mapping is parity-unpinned -- every
+golden vector pins the state itself."""
+import ctypes as C
+import hashlib
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "gen", "libflatland_gen.so")
+SYMBOLS = ("flg_last_error", "flg_city_positions", "flg_generate")
+_lib = None
+
+
+def build(force=False):
+    env = dict(os.environ)
+    if force:
+        env["FORCE"] = "1"
+    subprocess.check_call([os.path.join(HERE, "csrc", "gen", "build.sh")], env=env, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s is missing: build it with flatland_marl_amd/csrc/gen/build.sh" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.flg_last_error.restype = C.c_char_p
+        L.flg_city_positions.argtypes = [i32] * 6 + [vp, C.POINTER(i32), C.POINTER(i32), vp]
+        L.flg_generate.argtypes = [i32] * 7 + [vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GeneratorError(ValueError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GeneratorError(lib().flg_last_error().decode())
+
+
+def np_random(seed):
+    """gym 0.14 seeding.np_random(seed) -> numpy RandomState (parity-unpinned restatement, see module docstring)."""
+    if not (isinstance(seed, (int, np.integer)) and seed >= 0):
+        raise ValueError("Seed must be a non-negative integer, not {}".format(seed))
+    seed = int(seed) % 2 ** 64
+    h = hashlib.sha512(str(seed).encode("utf8")).digest()[:8]
+    h += b"\0" * 4                                   # _bigint_from_bytes pads to a whole number of 32-bit words (+ one)
+    big = sum(2 ** (32 * i) * v for i, v in enumerate(struct.unpack("3I", h)))
+    ints = []
+    while big > 0:
+        big, mod = divmod(big, 2 ** 32)
+        ints.append(mod)
+    return np.random.RandomState(ints or [0])
+
+
+class SparseRailGen:
+    """parameters of flatland.envs.rail_generators.sparse_rail_generator (rail_generators.py:164-193)"""
+
+    def __init__(self, max_num_cities=2, grid_mode=False, max_rails_between_cities=2, max_rail_pairs_in_city=2, seed=None):
+        self.max_num_cities, self.grid_mode = int(max_num_cities), bool(grid_mode)
+        self.max_rails_between_cities, self.max_rail_pairs_in_city = int(max_rails_between_cities), int(max_rail_pairs_in_city)
+        self.seed = seed
+
+
+class SparseLineGen:
+    """parameters of flatland.envs.line_generators.sparse_line_generator (line_generators.py:57-70)"""
+
+    def __init__(self, speed_ratio_map=None, seed=1):
+        self.speed_ratio_map, self.seed = speed_ratio_map, seed
+
+
+def sparse_rail_generator(*args, **kwargs):
+    return SparseRailGen(*args, **kwargs)
+
+
+def sparse_line_generator(speed_ratio_map=None, seed=1):
+    return SparseLineGen(speed_ratio_map, seed)
+
+
+def generate_env(width, height, number_of_agents, rail_generator, line_generator, mt_key, mt_pos, malf_rate=0.0, malf_min=0,
+                 malf_max=0, neighbour_order="numpy", hints=None):
+    """What RailEnv.reset() generates (rail_env.py:288-320), from the env's np_random state (mt_key u32[624], mt_pos):
+    returns the static description (grid, init_pos, init_dir, target, speed, earliest, latest, T, malfunction parameters
+    and the MT19937 state AFTER reset()).  neighbour_order "numpy": the cities are ordered by distance with np.argsort like
+    the reference does (its unstable tie order included); "stable": without numpy's help.  `hints`: optional dict that
+    receives city_positions / city_orientations / train_stations."""
+    L = lib()
+    rg, lg = rail_generator, line_generator
+    if rg.seed is not None:                      # SparseRailGen(seed=...) re-seeds (rail_generators.py:221-222)
+        st = np.random.RandomState(rg.seed).get_state()
+        mt_key, mt_pos = st[1], st[2]
+    key = np.ascontiguousarray(mt_key, dtype=np.uint32).copy()
+    pos = C.c_int(int(mt_pos))
+    n = C.c_int(0)
+    cities = np.zeros((max(rg.max_num_cities, 2), 2), dtype=np.int32)
+    _chk(L.flg_city_positions(int(width), int(height), rg.max_num_cities, int(rg.grid_mode), rg.max_rails_between_cities,
+                              rg.max_rail_pairs_in_city, _p(key), C.byref(pos), C.byref(n), _p(cities)))
+    nc = n.value
+    cities = np.ascontiguousarray(cities[:nc])
+    order = None
+    if neighbour_order == "numpy":
+        dist = np.abs(cities[:, None, :] - cities[None, :, :]).sum(-1)
+        order = np.ascontiguousarray(np.stack([np.argsort(list(map(int, row))) for row in dist]), dtype=np.int32)
+    srm = list((lg.speed_ratio_map or {}).items())
+    sv = np.array([s for s, _ in srm], dtype=np.float64)
+    sp = np.array([p for _, p in srm], dtype=np.float64)
+    A = int(number_of_agents)
+    max_st = 2 * max(rg.max_rail_pairs_in_city, 1)
+    grid = np.zeros((int(height), int(width)), dtype=np.uint16)
+    orient = np.zeros(nc, dtype=np.int32)
+    nst = np.zeros(nc, dtype=np.int32)
+    stations = np.zeros((nc, max_st, 3), dtype=np.int32)
+    ip, tg = np.zeros((A, 2), dtype=np.int32), np.zeros((A, 2), dtype=np.int32)
+    idr, ea, la = (np.zeros(A, dtype=np.int32) for _ in range(3))
+    speed = np.zeros(A, dtype=np.float64)
+    T = C.c_int(0)
+    _chk(L.flg_generate(int(width), int(height), A, int(rg.grid_mode), rg.max_rails_between_cities, rg.max_rail_pairs_in_city, nc,
+                        _p(cities), None if order is None else _p(order), len(srm), _p(sv) if len(srm) else None,
+                        _p(sp) if len(srm) else None, _p(key), C.byref(pos), _p(grid), _p(orient), _p(nst), _p(stations), max_st,
+                        _p(ip), _p(idr), _p(tg), _p(speed), _p(ea), _p(la), C.byref(T)))
+    if hints is not None:
+        hints.update(city_positions=[tuple(map(int, c)) for c in cities], city_orientations=[int(o) for o in orient],
+                     train_stations=[[((int(s[0]), int(s[1])), int(s[2])) for s in stations[c, :nst[c]]] for c in range(nc)],
+                     neighbour_order=order)
+    return dict(grid=grid, init_pos=ip, init_dir=idr, target=tg, speed=speed, earliest=ea, latest=la, T=np.int32(T.value),
+                malf_rate=np.float64(malf_rate), malf_min=np.int32(malf_min), malf_max=np.int32(malf_max),
+                mt_key=key, mt_pos=np.int32(pos.value))
+

@@ -4,15 +4,31 @@
 `flatland_cutils.TreeObsForRailEnv` (flatland_cutils/src/main.cpp:17-22) and of the caller
 `LocalTestEnvWrapper` (solution/eval_env.py:97-114), so solution/plfActor.py consumes it unchanged.
 
-Everything is computed by the HIP kernels through the C-ABI; this file only reshapes tensors into the
-reference's dicts / lists.  Map / line / timetable generators are out of scope:
-an env is created from the static description the reference produces at reset().
+Everything of step() / the observations is computed by the HIP kernels through the C-ABI; this file only reshapes tensors
+into the reference's dicts / lists.  reset(regenerate_rail=True, regenerate_schedule=True) runs the native host generators
+(flatland_marl_amd/generators.py -> csrc/gen) on the env's MT19937 stream; an env can also be created from the static
+description a reference env has after reset() (RailEnv.from_static, flatland_marl_amd.from_reference_env).
 """
+import collections
 from enum import IntEnum
 
 import numpy as np
 
+from . import generators
 from .hip_backend import BatchedRailEnv, EpisodeDoneError, FlatlandHipError
+
+# flatland.envs.malfunction_generators.MalfunctionParameters / ParamMalfunctionGen (malfunction_generators.py:19-53)
+MalfunctionParameters = collections.namedtuple("MalfunctionParameters", ["malfunction_rate", "min_duration", "max_duration"])
+
+
+class ParamMalfunctionGen:
+    def __init__(self, parameters):
+        self.MFP = parameters
+
+
+class NoMalfunctionGen(ParamMalfunctionGen):
+    def __init__(self):
+        super().__init__(MalfunctionParameters(0.0, 0, 0))
 
 
 class TrainState(IntEnum):  # flatland/envs/step_utils/states.py:5-25
@@ -153,7 +169,9 @@ class ObservationBuilder:
         raise NotImplementedError
 
     def get(self, handle=0):
-        return self.get_many([handle])
+        """ONE agent's observation (core/env_observation_builder.py:56-73); the builders compute whole batches, so this is
+        get_many([handle]) unpacked"""
+        return self.get_many([handle])[handle]
 
 
 class TreeObsForRailEnv(ObservationBuilder):
@@ -180,6 +198,10 @@ class TreeObsForRailEnv(ObservationBuilder):
         return (L["agent_attr"][h].tolist(),
                 (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(),
                  L["edge_order"][h].tolist()))
+
+    def get(self, handle=0):
+        attr, (nodes, adj, node_order, edge_order) = self.get_many([handle])
+        return attr[0], (nodes[0], adj[0], node_order[0], edge_order[0])
 
     def get_properties(self):
         """treeobs.cpp:612-640"""
@@ -217,23 +239,78 @@ class TreeObsUpstream(ObservationBuilder):
 
 
 class RailEnv:
-    """B = 1 view with the reference's attribute / method surface (rail_env.py:35-777)."""
+    """B = 1 view with the reference's constructor, attribute and method surface (rail_env.py:35-777)."""
 
-    def __init__(self, static, obs_builder_object=None, device=0):
+    def __init__(self, width, height, rail_generator=None, line_generator=None, number_of_agents=2, obs_builder_object=None,
+                 malfunction_generator_and_process_data=None, malfunction_generator=None, remove_agents_at_target=True,
+                 random_seed=None, record_steps=False, *, device=0):
+        """Same arguments as flatland.envs.rail_env.RailEnv (rail_env.py:100-112).  rail_generator / line_generator:
+        generators.sparse_rail_generator(...) / sparse_line_generator(...) (the Round-2 generators; others: build the env
+        with the reference and use RailEnv.from_static).  Nothing is generated before reset(), like the reference."""
+        if not remove_agents_at_target:
+            raise NotImplementedError("remove_agents_at_target=False is unused by the solution and not supported")
+        if malfunction_generator_and_process_data is not None:
+            raise NotImplementedError("the deprecated malfunction closures are not supported; pass malfunction_generator")
+        self.width, self.height = int(width), int(height)
+        self.rail_generator = rail_generator if rail_generator is not None else generators.sparse_rail_generator()
+        self.line_generator = line_generator if line_generator is not None else generators.sparse_line_generator()
+        self.number_of_agents = int(number_of_agents)
+        self.malfunction_generator = malfunction_generator if malfunction_generator is not None else NoMalfunctionGen()
+        self.remove_agents_at_target = True
+        self.record_steps = record_steps
+        self._device = device
+        self.obs_builder = obs_builder_object if obs_builder_object is not None else TreeObsForRailEnv()
+        self.np_random = None
+        self.random_seed = None
+        if random_seed:
+            self._seed(random_seed)
+        self.num_resets = 0
+        self._static, self._hints, self._batch = None, None, None
+        self.rail, self.agents, self.distance_map = None, [], None
+        self._max_episode_steps = None
+        self._elapsed_steps = 0
+        self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
+        self.rewards_dict = {}
+        self.obs_dict = None
+
+    @classmethod
+    def from_static(cls, static, obs_builder_object=None, device=0):
+        """an env from the static description a (reference) env has after reset(): no generators involved"""
+        H, W = np.asarray(static["grid"]).shape
+        mfp = MalfunctionParameters(float(static["malf_rate"]), int(static["malf_min"]), int(static["malf_max"]))
+        env = cls(W, H, number_of_agents=len(static["init_dir"]), obs_builder_object=obs_builder_object,
+                  malfunction_generator=ParamMalfunctionGen(mfp), device=device)
+        env._adopt(static)
+        return env
+
+    def _seed(self, seed):  # rail_env.py:210-222
+        self.np_random = generators.np_random(seed)
+        self.random_seed = seed
+        return [seed]
+
+    def _rng_state(self):
+        """the env's MT19937 stream: on the device while a batch exists (the step's malfunction draws advance it there)"""
+        if self._batch is not None:
+            key, pos = self._batch.rng_state()
+            return key[0], int(pos[0])
+        if self.np_random is None:
+            self.np_random = np.random.RandomState()     # unseeded env, like gym's seeding.np_random(None)
+        st = self.np_random.get_state()
+        return np.asarray(st[1], dtype=np.uint32), int(st[2])
+
+    def _adopt(self, static):
+        """(re)create the B = 1 batch for a new static description"""
+        if self._batch is not None:
+            self._batch.close()
         self._static = static
-        self._batch = BatchedRailEnv([static], device=device)
+        self._batch = BatchedRailEnv([static], device=self._device)
         self.rail = _Rail(static["grid"])
         self.height, self.width = self.rail.height, self.rail.width
         self.number_of_agents = self._batch.A
         self._max_episode_steps = int(static["T"])
         self.agents = [EnvAgent(i, static) for i in range(self.number_of_agents)]
         self.distance_map = _DistanceMap(self)
-        self.obs_builder = obs_builder_object if obs_builder_object is not None else TreeObsForRailEnv()
         self.obs_builder.set_env(self)
-        self._elapsed_steps = 0
-        self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
-        self.rewards_dict = {i: 0 for i in range(self.number_of_agents)}
-        self.obs_dict = None
 
     def get_num_agents(self):
         return len(self.agents)
@@ -261,11 +338,31 @@ class RailEnv:
         self.obs_dict = self.obs_builder.get_many(list(range(self.get_num_agents())))
         return self.obs_dict
 
-    def reset(self, regenerate_rail=False, regenerate_schedule=False, *, random_seed=None):
-        if regenerate_rail or regenerate_schedule or random_seed is not None:
-            raise NotImplementedError("rail / line / timetable generation is outside the accelerated hot path; "
-                                      "create the env from the static description of a generated env")
-        self._batch.reset(fresh=True)
+    def reset(self, regenerate_rail=True, regenerate_schedule=True, *, random_seed=None):
+        """rail_env.py:260-357.  regenerate_rail: a new map, lines and timetable on the env's own MT19937 stream; neither flag:
+        EnvAgent.reset() for every agent; regenerate_schedule alone fails like the reference does with the sparse generators."""
+        if random_seed:
+            self._seed(random_seed)
+            if self._batch is not None:       # the device copy of the stream follows the re-seed
+                st = self.np_random.get_state()
+                self._batch.set_rng_state(np.asarray(st[1], dtype=np.uint32)[None], np.array([st[2]], dtype=np.int32))
+        mfp = self.malfunction_generator.MFP
+        if regenerate_rail or self._static is None:
+            if self._static is not None and self._hints is None and not isinstance(self.rail_generator, generators.SparseRailGen):
+                raise NotImplementedError("this env was created from a static description without a rail generator")
+            key, pos = self._rng_state()
+            hints = {}
+            static = generators.generate_env(self.width, self.height, self.number_of_agents, self.rail_generator, self.line_generator,
+                                             key, pos, mfp.malfunction_rate, mfp.min_duration, mfp.max_duration, hints=hints)
+            self._hints = hints
+            self._adopt(static)
+        elif regenerate_schedule:
+            # the reference passes no hints to the line generator on this path and SparseLineGen fails on them
+            # (rail_env.py:311-316, line_generators.py:96): same error here
+            raise TypeError("'NoneType' object is not subscriptable")
+        else:
+            self._batch.reset(fresh=False)      # EnvAgent.reset() literally: arrival_time survives (agent_utils.py:90-105)
+        self.num_resets += 1
         self.obs_builder.reset()
         self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
         self.rewards_dict = {i: 0 for i in range(self.number_of_agents)}

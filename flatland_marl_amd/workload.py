@@ -1,5 +1,6 @@
-"""Synthetic bench workloads: K base envs generated once by the reference (committed as
-static fixtures under tests/golden/), tiled to B replicas; each replica has its own MT19937 state
+"""Synthetic bench workloads: K base envs generated once by the reference (their static descriptions
+-- grid, agents, timetable, malfunction parameters, post-reset MT state -- are package data under flatland_marl_amd/data/,
+exported from the golden fixtures of the same name by oracle/refharness/capture_golden.py), tiled to B replicas; each replica has its own MT19937 state
 (numpy RandomState([replica_id])) and its own counter-hash action stream; envs auto-reset at episode end.
 
 Replica 0 of rank 0 reuses the MT state and action-stream seed of a committed golden episode, so its
@@ -9,8 +10,7 @@ import os
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 STATIC_KEYS = ("grid", "init_pos", "init_dir", "target", "speed", "earliest", "latest", "T",
                "malf_rate", "malf_min", "malf_max", "mt_key", "mt_pos")
@@ -33,7 +33,7 @@ WORKLOADS = {
 
 
 def load_static(name):
-    z = np.load(os.path.join(GOLD, name + ".npz"))
+    z = np.load(os.path.join(DATA, name + ".npz"))
     return {k: z[k] for k in STATIC_KEYS}
 
 

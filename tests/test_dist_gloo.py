@@ -28,8 +28,9 @@ def _worker(rank, world, port, out):
     dist_utils.barrier()
     red = dist_utils.reduce_metrics(metrics.clone())
     tmax = dist_utils.max_over_ranks(1.0 + rank)
+    per_rank = dist_utils.gather_agent_steps(metrics)
     envs, seed = wl.make_envs("cfg2", B=3, rank=rank)
-    out[rank] = dict(shard=(lo, hi), red=red.tolist(), tmax=tmax, keys=[int(e["mt_key"][1]) for e in envs], seed=seed)
+    out[rank] = dict(shard=(lo, hi), red=red.tolist(), tmax=tmax, per_rank=per_rank, keys=[int(e["mt_key"][1]) for e in envs], seed=seed)
     dist_utils.shutdown()
 
 
@@ -41,6 +42,7 @@ def test_metrics_allreduce_and_sharding_world2():
     assert out[0]["shard"] == (0, 6) and out[1]["shard"] == (6, 11)
     assert out[0]["red"] == out[1]["red"] == [-30, 3, 11 * 20, 2]
     assert out[0]["tmax"] == out[1]["tmax"] == 2.0
+    assert out[0]["per_rank"] == out[1]["per_rank"] == [6 * 20, 5 * 20]
     # weak scaling: rank r owns global replicas [3r, 3r+3), each with its own MT19937 state
     assert len(set(out[0]["keys"]) | set(out[1]["keys"])) == 6
     assert out[0]["seed"] == out[1]["seed"]

@@ -16,10 +16,10 @@ def _action_dict(row):
 def test_facade_episode_matches_reference(name):
     from flatland_marl_amd.rail_env import RailEnv, TreeObsForRailEnv, LocalTestEnvWrapper, TrainState
     fx = util.load(name)
-    env = RailEnv(util.static_of(fx), obs_builder_object=TreeObsForRailEnv(31, 500))
+    env = RailEnv.from_static(util.static_of(fx), obs_builder_object=TreeObsForRailEnv(31, 500))
     wrapper = LocalTestEnvWrapper(env)
     obs_steps = {int(t): k for k, t in enumerate(fx["obs_steps"])}
-    obs, info = env.reset()
+    obs, info = env.reset(regenerate_rail=False, regenerate_schedule=False)
     assert set(info) == {"action_required", "malfunction", "speed", "state"}
     np.testing.assert_array_equal(np.array(obs[0], dtype=np.float32), fx["o_attr"][0])
     A = env.get_num_agents()
@@ -65,8 +65,8 @@ def test_facade_episode_matches_reference(name):
 def test_upstream_tree_builder_and_positions_map():
     from flatland_marl_amd.rail_env import RailEnv, TreeObsUpstream
     fx = util.load("cfg1_uniform")
-    env = RailEnv(util.static_of(fx), obs_builder_object=TreeObsUpstream(2, 30))
-    obs, _ = env.reset()
+    env = RailEnv.from_static(util.static_of(fx), obs_builder_object=TreeObsUpstream(2, 30))
+    obs, _ = env.reset(False, False)
     py_steps = {int(t): k for k, t in enumerate(fx["py_steps"])}
     np.testing.assert_array_equal(np.stack([obs[i] for i in range(env.get_num_agents())]), fx["py_d2_p30"][py_steps[0]])
     for t, row in enumerate(fx["actions"][:60]):
@@ -80,3 +80,42 @@ def test_upstream_tree_builder_and_positions_map():
         if r >= 0:
             exp[r, c] = i
     np.testing.assert_array_equal(pm, exp)
+
+
+def test_reference_style_constructor_generates_the_golden_env_and_steps_like_it():
+    """RailEnv(width, height, rail_generator, line_generator, number_of_agents, obs_builder_object, malfunction_generator,
+    random_seed) + reset(): the native generators reproduce the env of the golden fixture (same CSV row, same seed), and the
+    episode then runs like the golden one; reset() again draws a new rail from the running stream."""
+    from flatland_marl_amd import generators as gen
+    from flatland_marl_amd.rail_env import RailEnv, TreeObsForRailEnv, MalfunctionParameters, ParamMalfunctionGen
+    fx, g = util.load("cfg1_uniform"), util.load("gen_Test_0_L0")
+    env = RailEnv(width=int(g["width"]), height=int(g["height"]),
+                  rail_generator=gen.sparse_rail_generator(max_num_cities=int(g["max_num_cities"]), grid_mode=False,
+                                                           max_rails_between_cities=int(g["max_rails_between_cities"]),
+                                                           max_rail_pairs_in_city=int(g["max_rail_pairs_in_city"])),
+                  line_generator=gen.sparse_line_generator(dict(zip(g["speed_values"].tolist(), g["speed_probs"].tolist()))),
+                  number_of_agents=int(g["n_agents"]), obs_builder_object=TreeObsForRailEnv(31, 500),
+                  malfunction_generator=ParamMalfunctionGen(MalfunctionParameters(float(fx["malf_rate"]), int(fx["malf_min"]), int(fx["malf_max"]))),
+                  random_seed=int(g["random_seed"]))
+    obs, info = env.reset()
+    np.testing.assert_array_equal(env.rail.grid, fx["grid"])
+    assert env._max_episode_steps == int(fx["T"])
+    assert [a.initial_position for a in env.agents] == [tuple(p) for p in fx["init_pos"].tolist()]
+    assert [a.earliest_departure for a in env.agents] == fx["earliest"].tolist()
+    np.testing.assert_array_equal(np.array(obs[0], dtype=np.float32), fx["o_attr"][0])
+    one = env.obs_builder.get(3)
+    np.testing.assert_array_equal(np.array(one[0], dtype=np.float32), fx["o_attr"][0][3])
+    assert np.array(one[1][0]).shape == (31, 12)
+    A = env.get_num_agents()
+    for t, row in enumerate(util.actions_of(fx)[:60]):
+        obs, rew, dones, info = env.step(_action_dict(row))
+        assert [int(info["state"][i]) for i in range(A)] == fx["s_state"][t].tolist()
+        assert [a.position for a in env.agents] == [None if r < 0 else (int(r), int(c)) for r, c in zip(fx["s_row"][t], fx["s_col"][t])]
+    grid0 = env.rail.grid.copy()
+    with pytest.raises(TypeError):                                    # the reference fails the same way (no hints on this path)
+        env.reset(regenerate_rail=False, regenerate_schedule=True)
+    env.reset()                                                       # a new rail from the running stream
+    assert env.rail.grid.shape == grid0.shape and env.num_resets == 2 and not np.array_equal(env.rail.grid, grid0)
+    env.step({i: 2 for i in range(A)})
+    env.reset(False, False)
+    assert env._elapsed_steps == 0 and np.array_equal(env.rail.grid, env._static["grid"])

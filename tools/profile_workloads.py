@@ -1,0 +1,89 @@
+"""Profiles of record (run on the GPU box): for every bench workload, one `rocprofv3 --kernel-trace --stats` run and two
+PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) over
+
+    python3 bench.py --no-cpu-baseline --no-extra-workloads --workload W --tree-depth D [--dm-rebuild] --steps N
+
+Writes gpurun_out/prof_<tag>/: <tag>_<W>_d<D>_kernel_stats.csv (copied verbatim from rocprofv3), <tag>_<W>_d<D>_bench.json,
+and pmc_traffic.json (per workload and kernel: mean FETCH_SIZE / WRITE_SIZE per launch, HBM bytes per launch =
+2 * FETCH_SIZE + WRITE_SIZE KiB -- on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads; the factor is an
+upper bound for narrow gathers -- stamped with the sha of the kernel sources).  Copy what is to be judged into profiles/.
+
+  python tools/profile_workloads.py r02 [cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha only; nothing touches the GPU at import)
+
+NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
+         "k_distance_map": "k_distance_map", "k_hop8": "k_hop8", "k_nexthop": "k_nexthop", "k_segments": "k_segments"}
+tag = sys.argv[1]
+specs = sys.argv[2:] or ["cfg2:2", "cfg3:3", "cfg4:2", "cfg5:3:rebuild"]
+out_dir = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+os.makedirs(out_dir, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+traffic = {}
+sha = bench.kernel_source_sha()
+
+
+def run(args, bench_args, tmp):
+    shutil.rmtree(tmp, ignore_errors=True)
+    cmd = ["rocprofv3"] + args + ["-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py")] + bench_args
+    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    if p.returncode != 0:
+        print("FAILED:", " ".join(cmd), p.stderr[-400:], flush=True)
+    return p
+
+
+def pmc_mean(tmp, counter):
+    acc, n = collections.defaultdict(list), collections.Counter()
+    for path in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] != counter:
+                continue
+            for k, v in NAMES.items():
+                if k in row["Kernel_Name"]:
+                    acc[v].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+for spec in specs:
+    parts = spec.split(":")
+    w, depth, rebuild = parts[0], int(parts[1]), len(parts) > 2
+    key = "%s_d%d" % (w, depth)
+    steps = {"cfg2": 300, "cfg3": 100, "cfg4": 100, "cfg5": 60}[w]
+    bargs = ["--no-cpu-baseline", "--no-extra-workloads", "--workload", w, "--tree-depth", str(depth), "--steps", str(steps), "--warmup", "20"]
+    if rebuild:
+        bargs.append("--dm-rebuild")
+    tmp = "/tmp/prof_%s_%d" % (key, os.getpid())
+    p = run(["--kernel-trace", "--stats", "--output-format", "csv"], bargs, tmp)
+    stats = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, key)))
+    try:
+        json.dump(json.loads(p.stdout.strip().splitlines()[-1]), open(os.path.join(out_dir, "%s_%s_bench.json" % (tag, key)), "w"), indent=1)
+    except Exception:
+        pass
+    run(["--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv"], bargs, tmp)
+    f, nf = pmc_mean(tmp, "FETCH_SIZE")
+    run(["--pmc", "WRITE_SIZE", "--kernel-trace", "--output-format", "csv"], bargs, tmp)
+    wv, nw = pmc_mean(tmp, "WRITE_SIZE")
+    shutil.rmtree(tmp, ignore_errors=True)
+    import flatland_marl_amd.workload as wl
+    traffic[key] = {k: dict(envs=wl.WORKLOADS[w]["B"], tag=tag, kernel_source_sha=sha, launches=min(nf[k], nw.get(k, 0)),
+                            fetch_size_kib=f[k], write_size_kib=wv.get(k, 0.0), hbm_bytes_per_launch=(2 * f[k] + wv.get(k, 0.0)) * 1024)
+                    for k in f}
+    print(key, {k: (round(v["fetch_size_kib"]), round(v["write_size_kib"])) for k, v in traffic[key].items()}, flush=True)
+    kept = os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, key))
+    if os.path.exists(kept):
+        for row in list(csv.DictReader(open(kept)))[:6]:
+            print("   ", row.get("Name", "")[:40], row.get("Calls"), row.get("AverageNs"), flush=True)
+json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
