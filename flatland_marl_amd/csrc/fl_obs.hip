@@ -47,6 +47,11 @@
 #define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
+// Large maps (items in HBM, hundreds of agents): inside a key's list the items are grouped by bucket of 64 time steps, an
+// item sits in every bucket its interval touches, and a conflict query scans only the buckets its three time steps fall in
+// (an eighth of a busy cell's list instead of all of it).
+#define OBS_BK_NB 8
+#define OBS_BK_SHIFT 6
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
@@ -80,6 +85,8 @@ struct ObsCtx {
     const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
+    const uint16_t *bk_rel;       // HBM [K * OBS_BK_NB]: end of time bucket b inside key k's list, relative to the list's start;
+                                  // nullptr = lists not bucketed
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
     const uint2 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
@@ -99,6 +106,20 @@ __device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int r) { return X.c
 __device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int r) { return X.cellw[r] >> 16; }
 __device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int r) { return X.cellw[r]; }
 __device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? (int)X.rkey[r] : r; }
+// items of rail cell r's key a conflict query at predicted time pt has to look at: [lo, hi)
+__device__ __forceinline__ void list_range(const ObsCtx &X, int r, int pt, int &lo, int &hi) {
+    const int key = key_of(X, r);
+    const int base = key > 0 ? X.csr_end[key - 1] : 0;
+    if (X.bk_rel) {
+        const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+        const uint16_t *rel = X.bk_rel + (size_t)key * OBS_BK_NB;
+        lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
+        hi = base + (int)rel[b2];
+    } else {
+        lo = base;
+        hi = X.csr_end[key];
+    }
+}
 // successor of a state with exactly one transition (chain interior): one LDS load when the table is resident
 __device__ __forceinline__ uint32_t chain_next(const ObsCtx &X, uint32_t s, uint32_t bits16) {
     if (X.snext) return X.snext[s];
@@ -238,8 +259,8 @@ __device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f 
 
 template <bool CUTILS, int CAP, bool ITL>
 __device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
-    const int key = key_of(X, cell);
-    const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+    int lo, hi;
+    list_range(X, cell, pt, lo, hi);
     if (hi <= lo) return;
     if (conflict_hit(conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi))) atomicMin(&sc[F_PC * CAP + node], tot);
 }
@@ -467,16 +488,16 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         if (e < n_cf) {
             w = X.wl_cf[e];
             cell = (int)((w.x & 0xFFFFFFu) >> 2);
-            const int key = key_of(X, cell);
-            hi = X.csr_end[key]; lo = key > 0 ? X.csr_end[key - 1] : 0;
-            nch = min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63);  // an absurdly long list: the last chunk takes the rest
+            handle = team_meta[128 + (int)(w.x >> 24)];
+            tot = (int)(w.y & 511u);
+            const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
+            list_range(X, cell, pt, lo, hi);
+            nch = max(min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
             X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
         }
         for (int j = 1; __any(j < nch); j++) {
             if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
                 // list full: this chunk is scanned here
-                handle = team_meta[128 + (int)(w.x >> 24)];
-                tot = (int)(w.y & 511u);
                 const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
                 const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + j * CF_CHUNK, j == 62 ? hi : min(hi, lo + (j + 1) * CF_CHUNK));
                 if (f) atomicOr(&X.wl_cf[e].y, f << 15);
@@ -495,8 +516,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
         const int handle = team_meta[128 + team];
         const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
-        const int key = key_of(X, cell);
-        const int hi = X.csr_end[key], lo = key > 0 ? X.csr_end[key - 1] : 0;
+        int lo, hi;
+        list_range(X, cell, pt, lo, hi);
         const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
         if (nch == 1) {
             if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(fy >> 24)], tot);
@@ -628,6 +649,7 @@ struct ObsArgs {
     int use_tmask;     // per-key time-bucket masks in LDS
     int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
+    int bk;            // large maps: the cutils index is grouped by time bucket (OBS_BK_NB); built in the node tables' LDS
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
 };
 
@@ -1092,7 +1114,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
-    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items;
+    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
@@ -1242,8 +1264,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 
     // eight walker lanes per agent, on at least four wavefronts (consecutive wavefronts of a workgroup land on different
     // SIMDs): a lone wavefront issues at the full rate of its SIMD
-    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min(nt >> 6, max(4, (A + 7) / 8)) : 0;
     const bool do_p1 = CUTILS && STAGE != 2;
+    // (with hundreds of agents every wavefront would walk: one of them is kept back for phase 1, which then runs beside the walk)
+    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(4, (A + 7) / 8)) : 0;
     const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
         if (wave == 0) phase1();
@@ -1257,9 +1280,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
         const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
+        // large maps: bucketed lists (OBS_BK_NB).  Their per-(key, bucket) counters -- u16, two per word -- live in the node
+        // tables' LDS while the index is built (so no tree work is hoisted beside the walk), the offsets go to HBM afterwards
+        const bool bk = CUTILS && STAGE != 2 && P.bk != 0 && X.Tn > 64 && X.tmask != nullptr;
+        uint32_t *bkc = reinterpret_cast<uint32_t *>(wave_scr);
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
+            if (bk) for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) bkc[k] = 0u;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
         __syncthreads();
@@ -1339,7 +1367,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (wsel >= 0 && lane == 0) atomicMax((unsigned long long *)&X.dbg[21], (unsigned long long)wall_clock64());
 #endif
-        if (CUTILS) {
+        if (CUTILS && !bk) {
             const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
             int node_base, levels;
             cutils_pass_a(X, d, P, b, team_id, team_id < A, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32),
@@ -1355,6 +1383,21 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i];
             const int lp2 = dual ? (int)a_lp2[i] : -1;
+            if (bk) {  // one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+                const int tpc = a_tpc[i], tlast = X.Tn - 1;
+                for (int k = lane; k <= lp; k += 64) {
+                    const int key = key_of(X, (int)(path[k] >> 2));
+                    const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
+                    const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
+                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    for (int bb = b1; bb <= b2; bb++) {
+                        const int kb = key * OBS_BK_NB + bb;
+                        atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                    }
+                    atomicAdd(&csr[key], b2 - b1 + 1);
+                }
+                continue;
+            }
             for (int k = lane; k <= lp; k += 64) {
                 const int key = key_of(X, (int)(path[k] >> 2));
                 atomicAdd(&csr[key], 1);
@@ -1422,6 +1465,19 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             X.tmask = P.use_tmask ? tmaskb : nullptr;
             if (!X.tmask) { X.wl_occ_cap = wl_entries; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
+        if (bk) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
+            for (int key = tid; key < K; key += nt) {
+                uint32_t *w4 = bkc + key * (OBS_BK_NB / 2);
+                uint32_t run = 0;
+#pragma unroll
+                for (int q = 0; q < OBS_BK_NB / 2; q++) {
+                    const uint32_t v = w4[q], c0 = v & 0xFFFFu, c1 = v >> 16;
+                    w4[q] = run | ((run + c0) << 16);
+                    run += c0 + c1;
+                }
+            }
+            __syncthreads();
+        }
         const bool fit = items_lds != nullptr && misc[2] <= OBS_ITEMS_LDS_CAP;
         const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
@@ -1450,9 +1506,20 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
                     atomicOr(&tmask[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
                 }
+                const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                                      ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
+                    const int thi = to_end ? tlast : tlo + span - 1;
+                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    for (int bb = b1; bb <= b2; bb++) {
+                        const int kb = key * OBS_BK_NB + bb;
+                        const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                        csr_items[csr[key] + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
+                    }
+                    continue;
+                }
                 const int slot = atomicAdd(&csr[key], 1);
-                csr_items[slot] = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
-                                  ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                csr_items[slot] = item;
                 if (k <= lp2) {  // the same waypoint in the upstream predictor's index: w(t) = min(t / tpc, lp)
                     const int tlo2 = k * tpc2, tlast2 = Tn2 - 1;
                     const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
@@ -1468,6 +1535,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         __syncthreads();
+        if (bk) {  // bucket ends of every key to HBM (the node tables take their LDS back), list of key k = [csr[k], csr[k + 1])
+            uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
+            for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) g[k] = bkc[k];
+            X.csr_end = csr + 1;
+            X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
+            __syncthreads();
+        }
     }
 
     OBS_STAMP(4);
@@ -1478,8 +1552,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (CUTILS) {
-        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
-        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0);
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
     } else if (P.max_depth <= 2) {
         if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
         else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
@@ -1507,7 +1581,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 // ---------------------------------------------------------------------------------------------- host side
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
-    o.items_cap = (size_t)d.A * o.pred_cap;
+    o.items_cap = (size_t)d.A * (o.pred_cap + 2 * OBS_BK_NB + 2);  // bucketed lists: an item sits in every time bucket it touches
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;
     if (hipMalloc(&p, BA * o.pred_cap * 2) != hipSuccess) return FL_ERR_HIP;
@@ -1516,6 +1590,8 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 64 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);
+    if (hipMalloc(&p, (size_t)d.B * d.Rcap * OBS_BK_NB * 2 + 16) != hipSuccess) return FL_ERR_HIP;
+    o.bk_rel = (uint16_t *)p; allocs.push_back(p);
     o.wl_cap = OBS_WL_HBM_ENTRIES;
     if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
     o.wl = (uint2 *)p; allocs.push_back(p);
@@ -1611,6 +1687,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             for (int opt = 0; opt < (wk == 0 ? 1 + !dual_ok : 5); opt++) {
                 o.tmask = opts[opt][0]; o.dual = opts[opt][1]; o.items = opts[opt][2];
                 if (o.dual && !dual_ok) continue;
+                if (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP) continue;  // hundreds of agents: their items never fit the LDS copy
                 if (!ok(force.wl, o.wl_bytes) || !ok(force.tmask, o.tmask) || !ok(force.dual, o.dual) || !ok(force.items, o.items)) continue;
                 for (o.snext = 1; o.snext >= 0; o.snext--)
                     for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--)
@@ -1626,6 +1703,9 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                 else if (force.tab == 1) continue;
                             } else if (force.tab == 1) continue;
                             P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
+                            static const bool no_bk = getenv("FL_OBS_NO_BK") != nullptr;
+                            P.bk = !no_bk && o.wl_bytes == 0 && !o.items && o.tmask && !o.dual && P.tw_c != 0 && P.pred_depth + 1 > 64 &&
+                                   (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4 >= (size_t)d.Rcap * OBS_BK_NB * 2;
                             // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
                             // whole horizon measured slower on every map size)
                             static const int force_tshift = getenv("FL_OBS_TSHIFT") ? atoi(getenv("FL_OBS_TSHIFT")) : -1;

@@ -301,6 +301,10 @@ def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=
         n_arr = sum(1 for a_ in env.agents if a_.position is None and a_.state != TrainState.READY_TO_DEPART)
         total = sum(env.rewards_dict.values())
         out["final_metric"] = np.array([n_arr / A, total, 1 + total / env._max_episode_steps / A])
+        # the evaluator's two scores, computed from the reference env exactly as flatland/evaluators/service.py does:
+        # normalized reward (:875-879) and percentage complete = agents in state DONE / agents (:900-913)
+        complete = sum(1 for a_ in env.agents if a_.state == TrainState.DONE)
+        out["evaluator_scores"] = np.array([1.0 + total / (env._max_episode_steps * A), complete * 1.0 / max(A, 1)])
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **out)
     arrived = int(np.sum(per_step["state"][-1] == 6))

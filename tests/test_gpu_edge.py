@@ -184,7 +184,8 @@ def test_action_required_filter_info_and_scores_match_reference():
     assert bool(done_all.cpu().numpy()[0])
     scores = env.info()["scores"].cpu().numpy()[0]
     assert scores[0] == fx["final_metric"][2]                   # 1 + sum(rewards) / T / A (eval_env.py:92, service.py:875-879)
-    assert scores[1] == (fx["s_state"][-1] == 6).sum() / env.A
+    # both evaluator scores as captured from the reference env objects (service.py:875-879, 900-913)
+    np.testing.assert_array_equal(scores, fx["evaluator_scores"])
 
 
 @pytest.mark.parametrize("name,B,depth,pred", [("cfg2_spfollow", 6, 2, 30), ("cfg0_tall_spfollow", 3, 3, 30),
@@ -282,7 +283,7 @@ def test_fused_step_after_episode_end_raises_like_the_reference():
     ("cfg4", 2, dict(nt=1024, tab=0, wl=24576, tmask=1, dual=1, items=1)),
     ("cfg4", 3, dict(nt=1024, tab=0, wl=0, tmask=1, dual=0, items=1)),
     ("cfg5", 2, dict(nt=1024, tab=0, wl=0, tmask=1, dual=0, items=0)),
-    ("cfg5", 3, dict(nt=512, tab=0, wl=0, tmask=1, dual=0, items=1)),
+    ("cfg5", 3, dict(nt=512, tab=0, wl=0, tmask=1, dual=0, items=0)),
 ])
 def test_observation_launch_configuration_of_the_bench_workloads(workload, depth, expect):
     import ctypes
