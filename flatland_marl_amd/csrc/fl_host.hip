@@ -197,23 +197,23 @@ static void build_rail_tables(fl_batch *h, int b) {
     for (int u = 0; u < Ucap; u++) h->h_ut_r[(size_t)b * Ucap + u] = u < h->h_U[b] ? ridx[h->h_ut[(size_t)b * A + u]] : 0;
 }
 
-// upload everything fl_load_env staged for env b (device arrays exist)
-static int upload_env(fl_batch *h, int b) {
-    const int A = h->A, Rcap = h->d.Rcap, Ucap = h->d.Ucap;
+// upload everything fl_load_env staged for envs [b0, b0 + nb) (device arrays exist): one copy per array
+static int upload_envs(fl_batch *h, int b0, int nb) {
+    const size_t A = h->A, Rcap = h->d.Rcap, Ucap = h->d.Ucap, n = (size_t)nb, b = (size_t)b0;
     const size_t HW = (size_t)h->H * h->W;
     FlDev &d = h->d;
-    UPLOAD_RANGE(d.T, h->h_T, b, 1); UPLOAD_RANGE(d.mt_pos, h->h_mt_pos, b, 1); UPLOAD_RANGE(d.mt, h->h_mt, (size_t)b * 624, 624);
-    UPLOAD_RANGE(d.malf_thr, h->h_thr, b, 1); UPLOAD_RANGE(d.malf_min, h->h_malf_min, b, 1); UPLOAD_RANGE(d.malf_max, h->h_malf_max, b, 1);
-    UPLOAD_RANGE(d.U, h->h_U, b, 1); UPLOAD_RANGE(d.R, h->h_R, b, 1); UPLOAD_RANGE(d.K, h->h_K, b, 1);
-    UPLOAD_RANGE(d.grid, h->h_grid, b * HW, HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, HW);
-    UPLOAD_RANGE(d.rgrid, h->h_rgrid, (size_t)b * Rcap, Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, (size_t)b * Rcap * 4, (size_t)Rcap * 4);
-    if (d.rkey) UPLOAD_RANGE(d.rkey, h->h_rkey, (size_t)b * Rcap, Rcap);
-    UPLOAD_RANGE(d.ut_r, h->h_ut_r, (size_t)b * Ucap, Ucap);
-    const size_t g0 = (size_t)b * A;
-    UPLOAD_RANGE(d.init_pos, h->h_init_pos, g0, A); UPLOAD_RANGE(d.target, h->h_target, g0, A);
-    UPLOAD_RANGE(d.init_r, h->h_init_r, g0, A); UPLOAD_RANGE(d.target_r, h->h_target_r, g0, A);
-    UPLOAD_RANGE(d.earliest, h->h_earliest, g0, A); UPLOAD_RANGE(d.latest, h->h_latest, g0, A);
-    UPLOAD_RANGE(d.tslot, h->h_tslot, g0, A); UPLOAD_RANGE(d.spk, h->h_spk, g0, A); UPLOAD_RANGE(d.speed, h->h_speed, g0, A);
+    UPLOAD_RANGE(d.T, h->h_T, b, n); UPLOAD_RANGE(d.mt_pos, h->h_mt_pos, b, n); UPLOAD_RANGE(d.mt, h->h_mt, b * 624, n * 624);
+    UPLOAD_RANGE(d.malf_thr, h->h_thr, b, n); UPLOAD_RANGE(d.malf_min, h->h_malf_min, b, n); UPLOAD_RANGE(d.malf_max, h->h_malf_max, b, n);
+    UPLOAD_RANGE(d.U, h->h_U, b, n); UPLOAD_RANGE(d.R, h->h_R, b, n); UPLOAD_RANGE(d.K, h->h_K, b, n);
+    UPLOAD_RANGE(d.grid, h->h_grid, b * HW, n * HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, n * HW);
+    UPLOAD_RANGE(d.rgrid, h->h_rgrid, b * Rcap, n * Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, b * Rcap * 4, n * Rcap * 4);
+    if (d.rkey) UPLOAD_RANGE(d.rkey, h->h_rkey, b * Rcap, n * Rcap);
+    UPLOAD_RANGE(d.ut_r, h->h_ut_r, b * Ucap, n * Ucap);
+    const size_t g0 = b * A, ng = n * A;
+    UPLOAD_RANGE(d.init_pos, h->h_init_pos, g0, ng); UPLOAD_RANGE(d.target, h->h_target, g0, ng);
+    UPLOAD_RANGE(d.init_r, h->h_init_r, g0, ng); UPLOAD_RANGE(d.target_r, h->h_target_r, g0, ng);
+    UPLOAD_RANGE(d.earliest, h->h_earliest, g0, ng); UPLOAD_RANGE(d.latest, h->h_latest, g0, ng);
+    UPLOAD_RANGE(d.tslot, h->h_tslot, g0, ng); UPLOAD_RANGE(d.spk, h->h_spk, g0, ng); UPLOAD_RANGE(d.speed, h->h_speed, g0, ng);
     return FL_OK;
 }
 
@@ -328,10 +328,16 @@ int fl_commit(fl_batch *h) {
         if (!h->h_dirty[b]) continue;
         any = true;
         build_rail_tables(h, b);
-        const int rc = upload_env(h, b);
-        if (rc != FL_OK) return rc;
     }
     if (!any) return FL_OK;
+    for (int b = 0; b < B;) {  // one set of copies per run of consecutive dirty envs (the first commit: one set in all)
+        if (!h->h_dirty[b]) { b++; continue; }
+        int e = b;
+        while (e < B && h->h_dirty[e]) e++;
+        const int rc = upload_envs(h, b, e - b);
+        if (rc != FL_OK) return rc;
+        b = e;
+    }
     const bool all = !h->committed;
     if (!all) HIPCHK(hipMemcpyAsync(h->mask_dev, h->h_dirty.data(), B, hipMemcpyHostToDevice, h->stream));
     const uint8_t *mask = all ? nullptr : h->mask_dev;
