@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict
     const int s0 = (work % per_env) * 256 + threadIdx.x;
     const int S = d.R[b] * 4;
     if (s0 >= Scap) continue;
-    uint2 out = make_uint2((uint32_t)s0 | (SEG_ZERO << 20), 0xFFFF0000u);
+    uint4 out = make_uint4((uint32_t)s0 | (SEG_ZERO << 20), 0xFFFF0000u, 0xFFFFFFFFu, 0xFFFFFFFFu);
     uint16_t sn = FL_R_NONE;
     if (s0 < S) {
         const uint16_t *rg = d.rgrid + (size_t)b * d.Rcap, *nbr = d.nbr + (size_t)b * Scap;
@@ -222,7 +222,22 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict
             } else if (num > 1) { kind = SEG_SWITCH; break; }
             else { kind = SEG_ZERO; break; }
         }
-        out = make_uint2((uint32_t)cur | (kind << 20), (uint32_t)k | ((uint32_t)unus << 16));
+        // children of the end state (switch: the transitions left / forward / right / back of the arrival direction; dead end:
+        // the reversed directions, treeobs.cpp:583-608)
+        uint32_t kid[4] = {FL_R_NONE, FL_R_NONE, FL_R_NONE, FL_R_NONE};
+        if (kind == SEG_SWITCH || kind == SEG_DEAD_END) {
+            const uint32_t ecell = (uint32_t)cur >> 2, edir = (uint32_t)cur & 3u;
+            const uint32_t pbits = nibble(rg[ecell], edir);
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t bd = (edir + c + 3u) & 3u;
+                const uint32_t use = kind == SEG_DEAD_END ? (bd + 2u) & 3u : bd;
+                if ((pbits >> (3u - use)) & 1u) {
+                    const uint32_t nr = nbr[ecell * 4u + use];
+                    if (nr != FL_R_NONE) kid[c] = (nr << 2) | use;
+                }
+            }
+        }
+        out = make_uint4((uint32_t)cur | (kind << 20), (uint32_t)k | ((uint32_t)unus << 16), kid[0] | (kid[1] << 16), kid[2] | (kid[3] << 16));
     }
     d.seg[(size_t)b * Scap + s0] = out;
     d.snext[(size_t)b * Scap + s0] = sn;

@@ -52,6 +52,7 @@ struct fl_batch {
     std::vector<double> h_speed;
     std::vector<uint64_t> h_thr;
     std::vector<uint8_t> h_loaded, h_dirty;  // dirty: loaded since the last commit
+    std::vector<uint8_t> h_rtype;
     uint8_t *mask_dev;   // [B] staging of host-side env masks (fl_reset, fl_commit after a live replacement)
     FlObsScratch obs;
 };
@@ -154,6 +155,28 @@ static int upload_range(fl_batch *h, T *dst, const std::vector<T> &src, size_t f
         if (rc_ != FL_OK) return rc_;                           \
     } while (0)
 
+// RailEnvTransitions.transition_list (core/grid/rail_env_grid.py:28-38)
+static const uint16_t k_transition_list[11] = {0x0000, 0x8020, 0x9220, 0x8421, 0x9621, 0xCC33, 0x5202, 0x2000, 0x4002, 0x1200, 0xC022};
+// rotate_transition (flatland_cutils/src/tool.h:300-335): each nibble rotated right by k, then the word by 4k
+static uint32_t rotate_transition(uint32_t cell, int k) {
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t nib = (cell >> ((3 - i) * 4)) & 15u;
+        nib = ((nib >> k) | (nib << (4 - k))) & 15u;
+        v |= nib << ((3 - i) * 4);
+    }
+    return ((v >> (4 * k)) | (v << (16 - 4 * k))) & 0xFFFFu;
+}
+// road_type of a cell (flatland_cutils/src/loader.cpp:122-161): the first basic transition one of its four rotations equals
+static int road_type_of(uint32_t cell) {
+    for (int rot = 0; rot < 4; rot++) {
+        const uint32_t t = rot == 0 ? cell : rotate_transition(cell, rot);
+        for (int k = 0; k < 11; k++)
+            if (k_transition_list[k] == t) return k;
+    }
+    return 0;
+}
+
 // rail-cell index space of env b (fl_internal.h): ridx / rcell / rgrid / nbr / rkey, the agents' and targets' rail indices
 static void build_rail_tables(fl_batch *h, int b) {
     const int A = h->A, H = h->H, W = h->W, Rcap = h->d.Rcap, Ucap = h->d.Ucap;
@@ -164,7 +187,7 @@ static void build_rail_tables(fl_batch *h, int b) {
     uint16_t *rgrid = &h->h_rgrid[(size_t)b * Rcap], *nbr = &h->h_nbr[(size_t)b * Rcap * 4];
     int R = 0;
     for (size_t c = 0; c < HW; c++) {
-        if (grid[c]) { ridx[c] = (uint16_t)R; rcell[R] = (uint32_t)c; rgrid[R] = grid[c]; R++; }
+        if (grid[c]) { ridx[c] = (uint16_t)R; rcell[R] = (uint32_t)c; rgrid[R] = grid[c]; h->h_rtype[(size_t)b * Rcap + R] = (uint8_t)road_type_of(grid[c]); R++; }
         else ridx[c] = FL_R_NONE;
     }
     for (int r = R; r < Rcap; r++) { rcell[r] = 0; rgrid[r] = 0; }
@@ -206,7 +229,7 @@ static int upload_envs(fl_batch *h, int b0, int nb) {
     UPLOAD_RANGE(d.malf_thr, h->h_thr, b, n); UPLOAD_RANGE(d.malf_min, h->h_malf_min, b, n); UPLOAD_RANGE(d.malf_max, h->h_malf_max, b, n);
     UPLOAD_RANGE(d.U, h->h_U, b, n); UPLOAD_RANGE(d.R, h->h_R, b, n); UPLOAD_RANGE(d.K, h->h_K, b, n);
     UPLOAD_RANGE(d.grid, h->h_grid, b * HW, n * HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, n * HW);
-    UPLOAD_RANGE(d.rgrid, h->h_rgrid, b * Rcap, n * Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, b * Rcap * 4, n * Rcap * 4);
+    UPLOAD_RANGE(d.rgrid, h->h_rgrid, b * Rcap, n * Rcap); UPLOAD_RANGE(d.rtype, h->h_rtype, b * Rcap, n * Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, b * Rcap * 4, n * Rcap * 4);
     if (d.rkey) UPLOAD_RANGE(d.rkey, h->h_rkey, b * Rcap, n * Rcap);
     UPLOAD_RANGE(d.ut_r, h->h_ut_r, b * Ucap, n * Ucap);
     const size_t g0 = b * A, ng = n * A;
@@ -297,14 +320,14 @@ int fl_commit(fl_batch *h) {
         }
         d.Ucap = Ucap; d.Rcap = Rcap;
         const size_t Scap = (size_t)Rcap * 4;
-        h->h_rcell.assign((size_t)B * Rcap, 0); h->h_rgrid.assign((size_t)B * Rcap, 0); h->h_nbr.assign((size_t)B * Scap, FL_R_NONE);
+        h->h_rcell.assign((size_t)B * Rcap, 0); h->h_rgrid.assign((size_t)B * Rcap, 0); h->h_rtype.assign((size_t)B * Rcap, 0); h->h_nbr.assign((size_t)B * Scap, FL_R_NONE);
         h->h_ut_r.assign((size_t)B * Ucap, 0);
         if (h->H > h->W) h->h_rkey.assign((size_t)B * Rcap, 0);
         DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
         DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.R, B); DALLOC(d.K, B);
         DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
         DALLOC(d.grid, B * HW); DALLOC(d.ridx, B * HW);
-        DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
+        DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.rtype, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
         d.rkey = nullptr;
         if (h->H > h->W) DALLOC(d.rkey, (size_t)B * Rcap);
         DALLOC(d.ut_r, (size_t)B * Ucap);

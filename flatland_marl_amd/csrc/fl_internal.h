@@ -12,7 +12,7 @@
 // (o = orientation), not by grid cells: ridx maps a cell to its rail index, nbr gives the rail index of the neighbour
 // in each direction.  At 150x150 (R = 2680 of 22500 cells) the tables are 8.4x smaller than their dense form:
 //   rgrid u16[Rcap] transitions, nbr u16[Rcap*4], snext u16[Scap] (successor of a single-transition state),
-//   dm u16[Ucap][Scap] (distance per unique target and rail state, 0xFFFF = unreachable), seg uint2[Scap], nh u16[Ucap][Rcap],
+//   dm u16[Ucap][Scap] (distance per unique target and rail state, 0xFFFF = unreachable), seg uint4[Scap], nh u16[Ucap][Rcap],
 //   hop8 u16[Ucap][Scap].  Rcap / Ucap = capacity of the batch (largest env, or fl_reserve), Scap = 4 * Rcap <= 65532.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,8 +22,10 @@
 
 #define FL_R_NONE 0xFFFFu  /* no rail cell / no such state (u16 tables) */
 
-// static branch-walk table entry (uint2) of a start state: the walk of _explore_branch ignoring the agent's own target.
-// x = end rail state | kind << 20;  y = steps to the end | first "unusable switch" offset << 16 (0xFFFF = none)
+// static branch-walk table entry (uint4) of a start state: the walk of _explore_branch ignoring the agent's own target.
+// x = end rail state | kind << 20;  y = steps to the end | first "unusable switch" offset << 16 (0xFFFF = none);
+// z, w = the start states of the end state's children left, forward | right, back (u16 each, FL_R_NONE = null cell):
+// treeobs.cpp:583-608 / observations.py:464-489 are a function of the end state alone
 enum { SEG_SWITCH = 0, SEG_DEAD_END = 1, SEG_ZERO = 2, SEG_CYCLE = 3 };
 #define SEG_END(e) ((int)((e).x & 0xFFFFFu))
 #define SEG_KIND(e) (((e).x >> 20) & 3u)
@@ -73,12 +75,13 @@ struct FlDev {
     uint16_t *grid;   // [B][H*W] transition bitmap per cell (step kernel)
     uint16_t *ridx;   // [B][H*W] rail index of a cell, FL_R_NONE = no rail
     uint16_t *rgrid;  // [B][Rcap] transition bitmap per rail cell
+    uint8_t *rtype;   // [B][Rcap] flatland_cutils road_type 0..10 of the cell (loader.cpp:122-161: index of the matching basic transition)
     uint16_t *nbr;    // [B][Rcap*4] rail index of the neighbour of rail cell r in direction m (N,E,S,W), FL_R_NONE = none
     uint16_t *snext;  // [B][Scap] successor state of a state with exactly one transition (k_segments), FL_R_NONE otherwise
     uint16_t *rkey;   // [B][Rcap] compact prediction key of a rail cell; nullptr when H <= W (key = rail index)
     uint16_t *ut_r;   // [B][Ucap] rail index of unique target u
     uint16_t *dm;     // [B][Ucap][Scap] distance map
-    uint2 *seg;       // [B][Scap] static branch-walk table, see fl_dmap.hip k_segments
+    uint4 *seg;       // [B][Scap] static branch-walk table, see fl_dmap.hip k_segments
     uint16_t *nh;     // [B][Ucap][Rcap] next hop of the greedy distance-map descent: 3 bits per orientation (4 = none)
     uint16_t *hop8;   // [B][Ucap][Scap] state after eight greedy hops, FL_R_NONE if the path ends earlier (k_hop8)
     // static per agent

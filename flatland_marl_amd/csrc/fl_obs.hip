@@ -89,7 +89,7 @@ struct ObsCtx {
                                   // nullptr = lists not bucketed
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
-    const uint2 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
+    const uint4 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
     // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
@@ -143,19 +143,22 @@ struct NodeDesc {
     int end;        // end state (direction unknown / irrelevant when the walk stops at the target)
     uint32_t flags; // bit 0 target stop, 1 switch, 2 dead end, 3 terminal (zero transition or cycle), 4 zero transition
     int unus;       // tot_dist of the first unusable switch or -1
+    uint32_t kids01, kids23;  // start states of the end state's children (u16 each, FL_R_NONE = null), valid for switch / dead end
 };
 enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO = 16 };
 
-__device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, int handle, int cell, uint32_t dir, int tot0) {
+// dm_t = the distance slab of the agent's target, target = its rail index (per-agent constants, hoisted by the callers)
+__device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, const uint16_t *dm_t, int target, int start, int tot0) {
     NodeDesc n;
-    n.start = (cell << 2) | (int)dir;
+    n.start = start;
     n.tot0 = tot0;
-    const uint2 e = X.seg[n.start];
-    const uint32_t dv = X.dm[X.a_tslot[handle] * X.SS + n.start];
+    const uint4 e = X.seg[start];
+    const uint32_t dv = dm_t[start];
     const int len = SEG_LEN(e), unus = SEG_UNUS(e);
+    n.kids01 = e.z; n.kids23 = e.w;
     if (dv != FL_INF16 && (int)dv <= len) {  // reaches its own target first
         n.nvis = (int)dv + 1;
-        n.end = (X.a_target[handle] << 2);
+        n.end = target << 2;
         n.flags = ND_TARGET;
         n.unus = (unus != 0xFFFF && unus < (int)dv) ? tot0 + unus : -1;  // the target cell breaks before that check
     } else {
@@ -566,15 +569,11 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
 }
 
 // children of a node (treeobs.cpp:583-608 / observations.py:464-489): child k (k = 0 left, 1 forward, 2 right, 3 back)
-// -> start state or -1 (null cell)
-__device__ __forceinline__ int child_state(const ObsCtx &X, const NodeDesc &nd, int k) {
+// -> start state or -1 (null cell); tabulated with the segment (fl_dmap.hip k_segments)
+__device__ __forceinline__ int child_state(const NodeDesc &nd, int k) {
     if (!(nd.flags & (ND_SWITCH | ND_DEAD_END))) return -1;
-    const int ecell = nd.end >> 2;
-    const uint32_t edir = nd.end & 3;
-    const uint32_t pbits = nibble(cw_bits(X, ecell), edir);
-    const uint32_t bd = (edir + (uint32_t)(k + 3)) & 3u, rev = (bd + 2u) & 3u;
-    if (nd.flags & ND_DEAD_END) return ((pbits >> (3 - rev)) & 1) ? state_towards(X, ecell, rev) : -1;
-    return ((pbits >> (3 - bd)) & 1) ? state_towards(X, ecell, bd) : -1;
+    const uint32_t c = ((k < 2 ? nd.kids01 : nd.kids23) >> (16 * (k & 1))) & 0xFFFFu;
+    return c == FL_R_NONE ? -1 : (int)c;
 }
 
 // scale_node (treeobs.cpp:111-152), float32 arithmetic
@@ -597,29 +596,6 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
     for (int i = 0; i < k; i++) m &= m - 1;
     return __ffsll((long long)m) - 1;
 }
-
-// RailEnvTransitions.transition_list (core/grid/rail_env_grid.py:28-38)
-__constant__ uint16_t c_transition_list[11] = {0x0000, 0x8020, 0x9220, 0x8421, 0x9621, 0xCC33,
-                                               0x5202, 0x2000, 0x4002, 0x1200, 0xC022};
-// rotate_transition (tool.h:300-335): each nibble rotated right by k, then the word by 4k
-__device__ __forceinline__ uint32_t rotate_transition(uint32_t cell, int k) {
-    uint32_t v = 0;
-    for (int i = 0; i < 4; i++) {
-        uint32_t nib = (cell >> ((3 - i) * 4)) & 15u;
-        nib = ((nib >> k) | (nib << (4 - k))) & 15u;
-        v |= nib << ((3 - i) * 4);
-    }
-    return ((v >> (4 * k)) | (v << (16 - 4 * k))) & 0xFFFFu;
-}
-__device__ __forceinline__ int road_type_of(uint32_t cell) {  // loader.cpp:122-161
-    for (int rot = 0; rot < 4; rot++) {
-        const uint32_t t = rot == 0 ? cell : rotate_transition(cell, rot);
-        for (int k = 0; k < 11; k++)
-            if (c_transition_list[k] == t) return k;
-    }
-    return 0;
-}
-
 
 // LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
 enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
@@ -698,18 +674,20 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
             c_index = 1 + tl * sz[1];
             if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
         }
+        const uint16_t *dm_t = X.dm + a_tslot[ia] * X.SS;  // per-agent constants of the level loop
+        const int tgt_r = X.a_target[ia];
         int width = 4;
         for (int level = 1; level <= D; level++) {
             int ch[4] = {-1, -1, -1, -1};
             int ch_tot = 0;
             if (have && tl < width && c_index >= 0 && c_state >= 0) {
-                const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
                 scr[F_START * CAP + c_index] = nd.start; scr[F_TOT * CAP + c_index] = nd.tot0;
                 scr[F_VIS * CAP + c_index] = nd.nvis; scr[F_END * CAP + c_index] = nd.end;
                 scr[F_FLAGS * CAP + c_index] = (int)nd.flags; scr[F_UNUS * CAP + c_index] = nd.unus;
                 ch_tot = nd.tot0 + nd.nvis;
 #pragma unroll
-                for (int k = 0; k < 4; k++) ch[k] = child_state(X, nd, k);
+                for (int k = 0; k < 4; k++) ch[k] = child_state(nd, k);
             } else if (tl < width) {
                 c_index = -1;  // missing node: its whole subtree stays -inf
             }
@@ -793,6 +771,8 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         const uint32_t bd = (orientation + (uint32_t)(c_act + 4)) & 3u;
         if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
     }
+    const uint16_t *dm_t = X.dm + a_tslot[ia] * X.SS;  // per-agent constants of the level loop
+    const int tgt_r = X.a_target[ia];
     int n_cur = 3, node_base = 1, levels = 0;
     if (gl == 0) scr[F_HGT * CAP + 0] = (1 << 2) | 1;  // root: first child = node 1
     while (true) {  // pass A
@@ -806,10 +786,10 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         bool explored = false;
         if (mine) {
             if (c_state >= 0) {
-                const NodeDesc nd = node_topology(X, i, c_state >> 2, (uint32_t)(c_state & 3), c_tot);
+                const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
                 explored = true;
                 ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
-                ch0 = child_state(X, nd, 0); ch1 = child_state(X, nd, 1); ch2 = child_state(X, nd, 2);
+                ch0 = child_state(nd, 0); ch1 = child_state(nd, 1); ch2 = child_state(nd, 2);
                 scr[F_START * CAP + idx_node] = nd.start; scr[F_TOT * CAP + idx_node] = nd.tot0;
                 scr[F_VIS * CAP + idx_node] = nd.nvis; scr[F_END * CAP + idx_node] = nd.end;
                 scr[F_FLAGS * CAP + idx_node] = (int)nd.flags; scr[F_UNUS * CAP + idx_node] = nd.unus;
@@ -996,10 +976,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint16_t *a_lp2 = LDS_OPT(uint16_t, L_A_LP2);
     uint16_t *a_tpc2 = LDS_OPT(uint16_t, L_A_TPC2);
     // static tables of the env: LDS copies (TAB_LDS) or HBM
-    uint2 *seg_lds = TAB_LDS ? LDS_AT(uint2, L_SEG) : nullptr;
+    uint4 *seg_lds = TAB_LDS ? LDS_AT(uint4, L_SEG) : nullptr;
     uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
     uint16_t *hop8_lds = TAB_LDS ? LDS_AT(uint16_t, L_HOP8) : nullptr;
-    const uint2 *gseg = d.seg + (size_t)b * Scap;
+    const uint4 *gseg = d.seg + (size_t)b * Scap;
     const uint16_t *gdm = d.dm + (size_t)b * d.Ucap * Scap;
     const uint16_t *ghop8 = d.hop8 + (size_t)b * d.Ucap * Scap;
     const uint16_t *gnh = d.nh + (size_t)b * d.Ucap * Rcap;
@@ -1221,7 +1201,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             // AgentAttrParser::get_features (feature_parser.cpp:3-98)
             float *o = P.attr + (size_t)g * FL_CUTILS_ATTR;
             int n = 0;
-            const int road_type = pos >= 0 ? road_type_of(cell) : 0;
+            const int road_type = pos >= 0 ? (int)d.rtype[(size_t)b * Rcap + pos] : 0;  // static per rail cell (fl_host.hip)
             const uint32_t malfw = d.malf[g];
             const int malf01 = (malfw & 0xFFFFu) != 0, nmalf01 = (malfw >> 16) != 0;
             for (int k = 0; k < 7; k++) o[n++] = (k == (int)state) ? 1.0f : 0.0f;
@@ -1639,7 +1619,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
         put(L_ITEMS2, (size_t)OBS_ITEMS2_CAP * 4);
         put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2);
     }
-    if (o.tab) { put(L_SEG, NS * 8); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
+    if (o.tab) { put(L_SEG, NS * 16); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
     L.total = (unsigned)off;
     L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
     return L;

@@ -80,6 +80,39 @@ def test_single_agent_env():
     env.check()
 
 
+def test_largest_supported_agent_count_matches_oracle():
+    """A = 1024 (the cap of one lane per agent): more than 64 KiB of dynamic LDS in the step kernel.  A synthetic
+    env: the 30x30 map of cfg2 with 1024 agents cycling through its agents' lines and staggered departures."""
+    from oracle import orc
+    from flatland_marl_amd import synth
+    fx = util.load("cfg2_spfollow")
+    st = util.static_of(fx)
+    A0, A = len(st["init_dir"]), 1024
+    idx = np.arange(A) % A0
+    big = dict(st)
+    for k in ("init_pos", "init_dir", "target", "speed", "latest"):
+        big[k] = np.ascontiguousarray(np.asarray(st[k])[idx])
+    big["earliest"] = (np.arange(A) // 4).astype(np.int32)
+    big["malf_rate"] = 1 / 300.0
+    env = _env([big], pred_depth=60)
+    o = orc.OracleEnv(big)
+    for t in range(150):
+        rew, done, done_all = env.step_synth(77, 0, 1, auto_reset=True)
+        r_o, d_o, da = o.step(synth.forward_biased_actions(77, 0, t, A))
+        _same(env.state()[0][0], o.state(), f"t={t} state")
+        _same(rew.cpu().numpy()[0], r_o, f"t={t} rewards")
+        if t % 25 == 0:
+            got = {k: v.cpu().numpy() for k, v in env.obs_cutils().items()}
+            exp = o.obs_cutils(31, 60)
+            for g, e in (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("valid_actions", "valid"), ("props", "props")):
+                _same(got[g][0], exp[e], f"t={t} {g}")
+            _same(env.obs_tree(2, 30).cpu().numpy()[0], o.obs_pytree(2, 30), f"t={t} tree")
+    env.check()
+    key, pos = env.rng_state()
+    k_o, p_o = o.get_rng()
+    assert pos[0] == p_o and np.array_equal(key[0], k_o)
+
+
 def test_masked_and_non_fresh_reset():
     """fl_reset(mask, fresh=0) follows EnvAgent.reset() literally: arrival_time survives (agent_utils.py:90-105)."""
     import torch
