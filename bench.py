@@ -238,6 +238,8 @@ def main():
     rank, world, local_rank = dist_utils.init_from_env()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if os.environ.get("FL_DIST_BACKEND") == "gloo":      # rehearsal: several ranks share the GPUs that exist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
 
     head = run_workload(args.workload, args.tree_depth, args.tree_pred, args.envs, args.steps, args.warmup, rank, world, local_rank,

@@ -279,10 +279,11 @@ __device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool w
     const unsigned long long m = __ballot(want);
     if (m == 0) return true;
     const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)m) - 1;
+    // the first ACTIVE lane reserves the slots for the wavefront; its result is broadcast with v_readfirstlane (a shuffle
+    // would be another LDS round trip)
     int base = 0;
-    if (lane == leader) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, leader);
+    if (lane == __ffsll((long long)__ballot(1)) - 1) base = atomicAdd(count, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
     const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
     if (want && idx < cap) list[idx] = e;
     if (idx_out) *idx_out = idx;

@@ -16,8 +16,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # FL_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+            backend = os.environ.get("FL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,

@@ -176,6 +176,7 @@ class ObservationBuilder:
 
 class TreeObsForRailEnv(ObservationBuilder):
     """Drop-in for flatland_cutils.TreeObsForRailEnv(max_nodes, max_pred_depth) (treeobs.h:133-169)."""
+    checks_errors = True
 
     def __init__(self, max_nodes=31, max_pred_depth=500):
         super().__init__()
@@ -191,7 +192,7 @@ class TreeObsForRailEnv(ObservationBuilder):
         """-> (agent_attr [A][83], (nodes [A][N][12], adjacency [A][N-1][3], node_order [A][N], edge_order [A][N-1]))
         as nested lists, like the pybind11 STL casters return them (treeobs.h:160-161)."""
         o = self.env._batch.obs_cutils()
-        self.env._batch.check()
+        self.env._batch.check()       # the one synchronising error check of a step (RailEnv.step leaves it to the builder)
         self._last = {k: v[0].cpu().numpy() for k, v in o.items()}
         h = list(handles)
         L = self._last
@@ -221,6 +222,7 @@ class TreeObsUpstream(ObservationBuilder):
     float64 array per agent: [N(max_depth), 12] in DFS pre-order (node, L, F, R, B), missing subtree = -inf
     (observations.py:20-32 gives the 12 field names, in this order)."""
 
+    checks_errors = True
     FIELDS = ("dist_own_target_encountered", "dist_other_target_encountered", "dist_other_agent_encountered",
               "dist_potential_conflict", "dist_unusable_switch", "dist_to_next_branch", "dist_min_to_target",
               "num_agents_same_direction", "num_agents_opposite_direction", "num_agents_malfunctioning",
@@ -380,7 +382,9 @@ class RailEnv:
                 acts[0, int(i)] = v if 0 <= v <= 4 else 7   # illegal values become DO_NOTHING inside the kernel
         rew, done, done_all = self._batch.step(acts)
         try:
-            self._batch.check()
+            if not getattr(self.obs_builder, "checks_errors", False):
+                self._batch.check()
+            obs = self._get_observations()      # the builders call fl_check themselves: one sync + read-back per step
         except EpisodeDoneError as e:
             raise Exception("Episode is done, cannot call step()") from e
         except FlatlandHipError as e:
@@ -393,7 +397,8 @@ class RailEnv:
             self.dones[i] = bool(done[i])
         self.dones["__all__"] = bool(done_all[0].item())
         self._refresh()
-        return self._get_observations(), self.rewards_dict, self.dones, self.get_info_dict()
+        self.obs_dict = obs
+        return obs, self.rewards_dict, self.dones, self.get_info_dict()
 
 
 class LocalTestEnvWrapper:
