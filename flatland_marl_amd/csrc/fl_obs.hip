@@ -633,81 +633,105 @@ struct ObsArgs {
 // upstream dense tree (observations.py:196-254, 464-494): DFS pre-order layout, one TEAM of lanes per agent
 // (TEAM = 32: two agents per wavefront, depth <= 2; TEAM = 64: depth 3).  Level L of pass A is handled by 4^L lanes;
 // every row that is not a real node is -inf.
-template <int TEAM, int CAP, bool ITL>
-__device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                              int nwaves, int *wave_scr0, int *team_meta,
-                                              const uint16_t *a_vpos, const uint8_t *a_dir, const uint16_t *a_malf,
-                                              const double *a_speed, const uint16_t *a_tslot) {
-    constexpr int TPW = 64 / TEAM;  // teams per wavefront
+//
+// pass A of one upstream tree: root row, node topology into the team's table scr (wave-level synchronisation only)
+template <int TEAM, int CAP>
+__device__ __forceinline__ void upstream_pass_a(const ObsCtx &X, const ObsArgs &P, int b, int i, bool have, int tl, int *scr) {
     const int A = X.A;
-    const int team = lane / TEAM, tl = lane % TEAM;
     const int D = P.max_depth, NN = P.n_tree_nodes;
     int sz[5];  // sz[l] = nodes of a subtree rooted at depth l
     { int n = 0; for (int l = D; l >= 0; l--) { n = n * 4 + 1; sz[l] = n; } }
+    const int ia = have ? i : 0;
+    const int g = b * A + ia;
+    const int vpos = X.a_vpos[ia];
+    const uint32_t dir = X.a_dir[ia];
+    const uint32_t rbits = nibble(cw_bits(X, vpos), dir);
+    uint32_t orientation = dir;
+    if (__popc(rbits) == 1) orientation = first_dir(rbits);
+    double *out = P.tree_out + (size_t)g * NN * 12;
+    if (have && tl == 0) {
+        const uint16_t dv = X.dm[X.a_tslot[i] * X.SS + vpos * 4 + (int)dir];
+        double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
+        root[9] = (double)X.a_malf[i];
+        root[10] = X.a_speed[i];
+        for (int k = 0; k < 12; k++) out[k] = root[k];
+    }
+    for (int k = tl; k < CAP; k += TEAM) { scr[F_START * CAP + k] = -1; scr[F_VIS * CAP + k] = 0; }
+    team_sync();
+    int c_state = -1, c_tot = 1, c_index = -1;
+    if (tl < 4) {
+        const uint32_t bd = (orientation + (uint32_t)(tl + 3)) & 3u;
+        c_index = 1 + tl * sz[1];
+        if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
+    }
+    const uint16_t *dm_t = X.dm + X.a_tslot[ia] * X.SS;  // per-agent constants of the level loop
+    const int tgt_r = X.a_target[ia];
+    int width = 4;
+    for (int level = 1; level <= D; level++) {
+        int ch[4] = {-1, -1, -1, -1};
+        int ch_tot = 0;
+        if (have && tl < width && c_index >= 0 && c_state >= 0) {
+            const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
+            scr[F_START * CAP + c_index] = nd.start; scr[F_TOT * CAP + c_index] = nd.tot0;
+            scr[F_VIS * CAP + c_index] = nd.nvis; scr[F_END * CAP + c_index] = nd.end;
+            scr[F_FLAGS * CAP + c_index] = (int)nd.flags; scr[F_UNUS * CAP + c_index] = nd.unus;
+            ch_tot = nd.tot0 + nd.nvis;
+#pragma unroll
+            for (int k = 0; k < 4; k++) ch[k] = child_state(nd, k);
+        } else if (tl < width) {
+            c_index = -1;  // missing node: its whole subtree stays -inf
+        }
+        if (level == D) break;
+        // children of lane p go to lanes 4p .. 4p+3 of the next level (all lanes take part in the shuffles)
+        const int src = tl >> 2, which = tl & 3;
+        const int p_index = __shfl(c_index, src, TEAM);
+        const int s0 = __shfl(ch[0], src, TEAM), s1 = __shfl(ch[1], src, TEAM), s2 = __shfl(ch[2], src, TEAM), s3 = __shfl(ch[3], src, TEAM);
+        const int s_tot = __shfl(ch_tot, src, TEAM);
+        width *= 4;
+        c_index = -1;
+        c_state = -1;
+        if (tl < width && p_index >= 0) {
+            c_state = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
+            c_tot = s_tot;
+            c_index = p_index + 1 + which * sz[level + 1];
+        }
+    }
+    team_sync();
+}
+
+// rows 1 .. NN-1 of one upstream tree from its node table (the root row was written by pass A)
+template <int TEAM, int CAP>
+__device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P, int b, int i, bool have, int tl, const int *scr) {
+    if (!have) return;
+    const int NN = P.n_tree_nodes;
+    double *out = P.tree_out + (size_t)(b * X.A + i) * NN * 12;
+    for (int idx = 1 + tl; idx < NN; idx += TEAM) {
+        double *row = out + (size_t)idx * 12;
+        if (scr[F_START * CAP + idx] < 0) {
+            for (int k = 0; k < 12; k++) row[k] = -INFINITY;
+        } else {
+            double f[12];
+            node_row<CAP>(X, i, scr, idx, f);
+            for (int k = 0; k < 12; k++) row[k] = f[k];
+        }
+    }
+}
+
+template <int TEAM, int CAP, bool ITL>
+__device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
+                                              int nwaves, int *wave_scr0, int *team_meta) {
+    constexpr int TPW = 64 / TEAM;  // teams per wavefront
+    const int A = X.A;
+    const int team = lane / TEAM, tl = lane % TEAM;
+    const int NN = P.n_tree_nodes;
     // team t's node table is slot t; teams that can never hold an agent share the dummy slot behind the real ones
     const int n_slots = min(nwaves * TPW, A);
     int *scr = wave_scr0 + min(wave * TPW + team, n_slots) * (F_WORDS * CAP);
     for (int base = 0; base < A; base += nwaves * TPW) {
         const int i = base + wave * TPW + team;
         const bool have = i < A;
-        const int ia = have ? i : 0;
-        const int g = b * A + ia;
-        const int vpos = a_vpos[ia];
-        const uint32_t dir = a_dir[ia];
-        const uint32_t rbits = nibble(cw_bits(X, vpos), dir);
-        uint32_t orientation = dir;
-        if (__popc(rbits) == 1) orientation = first_dir(rbits);
-        double *out = P.tree_out + (size_t)g * NN * 12;
-        if (have && tl == 0) {
-            const uint16_t dv = X.dm[a_tslot[i] * X.SS + vpos * 4 + (int)dir];
-            double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
-            root[9] = (double)a_malf[i];
-            root[10] = a_speed[i];
-            for (int k = 0; k < 12; k++) out[k] = root[k];
-        }
-        for (int k = tl; k < CAP; k += TEAM) { scr[F_START * CAP + k] = -1; scr[F_VIS * CAP + k] = 0; }
-        team_sync();
-        // pass A
-        int c_state = -1, c_tot = 1, c_index = -1;
-        if (tl < 4) {
-            const uint32_t bd = (orientation + (uint32_t)(tl + 3)) & 3u;
-            c_index = 1 + tl * sz[1];
-            if ((rbits >> (3 - bd)) & 1) c_state = state_towards(X, vpos, bd);
-        }
-        const uint16_t *dm_t = X.dm + a_tslot[ia] * X.SS;  // per-agent constants of the level loop
-        const int tgt_r = X.a_target[ia];
-        int width = 4;
-        for (int level = 1; level <= D; level++) {
-            int ch[4] = {-1, -1, -1, -1};
-            int ch_tot = 0;
-            if (have && tl < width && c_index >= 0 && c_state >= 0) {
-                const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
-                scr[F_START * CAP + c_index] = nd.start; scr[F_TOT * CAP + c_index] = nd.tot0;
-                scr[F_VIS * CAP + c_index] = nd.nvis; scr[F_END * CAP + c_index] = nd.end;
-                scr[F_FLAGS * CAP + c_index] = (int)nd.flags; scr[F_UNUS * CAP + c_index] = nd.unus;
-                ch_tot = nd.tot0 + nd.nvis;
-#pragma unroll
-                for (int k = 0; k < 4; k++) ch[k] = child_state(nd, k);
-            } else if (tl < width) {
-                c_index = -1;  // missing node: its whole subtree stays -inf
-            }
-            if (level == D) break;
-            // children of lane p go to lanes 4p .. 4p+3 of the next level (all lanes take part in the shuffles)
-            const int src = tl >> 2, which = tl & 3;
-            const int p_index = __shfl(c_index, src, TEAM);
-            const int s0 = __shfl(ch[0], src, TEAM), s1 = __shfl(ch[1], src, TEAM), s2 = __shfl(ch[2], src, TEAM), s3 = __shfl(ch[3], src, TEAM);
-            const int s_tot = __shfl(ch_tot, src, TEAM);
-            width *= 4;
-            c_index = -1;
-            c_state = -1;
-            if (tl < width && p_index >= 0) {
-                c_state = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
-                c_tot = s_tot;
-                c_index = p_index + 1 + which * sz[level + 1];
-            }
-        }
-        team_sync();
+        upstream_pass_a<TEAM, CAP>(X, P, b, i, have, tl, scr);
         TREE_STAMP(X, 6);
         {
             const int tot_cells = team_prepare<TEAM, CAP>(have, tl, have ? NN : 1, scr);
@@ -716,19 +740,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         }
         wg_pass_b<false, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr0, F_WORDS * CAP, team_meta);
         TREE_STAMP(X, 7);
-        if (have) {  // rows
-            const int *vs = scr;
-            for (int idx = 1 + tl; idx < NN; idx += TEAM) {
-                double *row = out + (size_t)idx * 12;
-                if (vs[F_START * CAP + idx] < 0) {
-                    for (int k = 0; k < 12; k++) row[k] = -INFINITY;
-                } else {
-                    double f[12];
-                    node_row<CAP>(X, i, scr, idx, f);
-                    for (int k = 0; k < 12; k++) row[k] = f[k];
-                }
-            }
-        }
+        upstream_rows<TEAM, CAP>(X, P, b, i, have, tl, scr);
         team_sync();
         TREE_STAMP(X, 8);
     }
@@ -825,6 +837,63 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
     levels_out = levels;
 }
 
+// rows, adjacency and evaluation orders of one flatland_cutils tree from its node table (after pass B); lane gl of the team
+__device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int gl,
+                                                   const int *scr, int node_base, int levels, float max_dist) {
+    constexpr int CAP = 32;
+    const int A = X.A, N = P.max_nodes;
+    const int g = b * A + (have ? i : 0);
+    float *F = P.forest + (size_t)g * N * 12;
+    int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
+    if (have) {  // rows: lane gl writes node gl + 1
+        const int *vs = scr;
+        for (int idx = gl + 1; idx < N; idx += 32) {
+            int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+            if (idx < node_base) {
+                adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = (vs[F_HGT * CAP + idx] & 3) - 1;
+                if (vs[F_START * CAP + idx] < 0) {
+                    const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                    scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                } else {
+                    double f[12];
+                    node_row<CAP>(X, i, scr, idx, f);
+                    if (vs[F_FLAGS * CAP + idx] & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
+                    scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
+                }
+            } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
+                const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
+                scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
+                adj[0] = adj[1] = adj[2] = -2;
+            }
+        }
+    }
+    // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
+    // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
+    {
+        const int packed = gl < node_base ? scr[F_HGT * CAP + gl] : 0;
+        const int fc = packed >> 2;          // 0 = no children pushed
+        const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
+        const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
+        const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
+        int h = 0;
+        for (int it = 0; it < max_levels; it++) {
+            const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
+            int hn = 0;
+            if (nchild > 0) hn = h0 + 1;
+            if (nchild > 1) hn = max(hn, h1 + 1);
+            if (nchild > 2) hn = max(hn, h2 + 1);
+            h = hn;
+        }
+        const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
+        if (have) {
+            int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
+            if (gl < N) {
+                NO[gl] = gl < node_base ? h : -2;
+                if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
+            }
+        }
+    }}
+
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
 template <bool ITL>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
@@ -867,55 +936,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
             }
             wg_pass_b<true, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, F_WORDS * CAP, team_meta);
             TREE_STAMP(X, 7);
-            if (have) {  // rows: lane gl writes node gl + 1
-                const int *vs = scr;
-                for (int idx = gl + 1; idx < N; idx += 32) {
-                    int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
-                    if (idx < node_base) {
-                        adj[0] = vs[F_PAR * CAP + idx]; adj[1] = idx; adj[2] = (vs[F_HGT * CAP + idx] & 3) - 1;
-                        if (vs[F_START * CAP + idx] < 0) {
-                            const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                            scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                        } else {
-                            double f[12];
-                            node_row<CAP>(X, i, scr, idx, f);
-                            if (vs[F_FLAGS * CAP + idx] & ND_ZERO) atomicCAS(&d.err[b], 0, FL_ERR_ZERO_TRANSITION);  // treeobs.cpp:529-535 throws
-                            scale_and_store(f, max_dist, A, F + (size_t)idx * 12);
-                        }
-                    } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
-                        const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
-                        scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                        adj[0] = adj[1] = adj[2] = -2;
-                    }
-                }
-            }
-            TREE_STAMP(X, 8);
-            // calculate_evaluation_orders (tool.h:468-524): order = height above the leaves.  Lane k holds node k; a node's
-            // children are consecutive nodes, so heights settle after as many shuffle rounds as the tree has levels.
-            {
-                const int packed = gl < node_base ? scr[F_HGT * CAP + gl] : 0;
-                const int fc = packed >> 2;          // 0 = no children pushed
-                const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
-                const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
-                const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
-                int h = 0;
-                for (int it = 0; it < max_levels; it++) {
-                    const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
-                    int hn = 0;
-                    if (nchild > 0) hn = h0 + 1;
-                    if (nchild > 1) hn = max(hn, h1 + 1);
-                    if (nchild > 2) hn = max(hn, h2 + 1);
-                    h = hn;
-                }
-                const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
-                if (have) {
-                    int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-                    if (gl < N) {
-                        NO[gl] = gl < node_base ? h : -2;
-                        if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
-                    }
-                }
-            }
+            cutils_rows_orders(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
             team_sync();
             TREE_STAMP(X, 16);
         }
@@ -1536,11 +1557,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
     } else if (P.max_depth <= 2) {
-        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<32, 32, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        else tree_upstream<32, 32, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
     } else {
-        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
-        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_dir, a_malf, a_speed, a_tslot);
+        if (items_in_lds) tree_upstream<64, 88, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        else tree_upstream<64, 88, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
     }
     OBS_STAMP(5);
 #undef LDS_AT
