@@ -80,6 +80,8 @@ struct ObsCtx {
     const uint16_t *a_malf;       // real down counter
     const double *a_speed;
     const uint16_t *a_tpc;        // times per cell of the predictor
+    const double *a_tq;           // time per cell of the tree walk: float 1.0 / speed of cutils (treeobs.cpp:304, held exactly
+                                  // in a double) or np.reciprocal(speed) of the upstream builder (observations.py:277)
     const uint16_t *a_tslot;
     const uint16_t *a_target;     // rail index
     const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
@@ -97,6 +99,21 @@ struct ObsCtx {
     int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
     const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
     int tshift;
+    // pass B over the trees of BOTH builders at once (PB = 2): teams below n_cu are flatland_cutils trees and use the members
+    // above, the others are upstream trees and use the upstream predictor's index:
+    int n_cu;
+    const int *u_csr_end;
+    const uint32_t *u_items;
+    const unsigned long long *u_tmask;
+    int u_Tn, u_tshift;
+    const double *a_tq2;          // np.reciprocal(speed)
+    // Own-path filter of the classify loop (small envs): a cell that is waypoint tot of the walking agent's own predicted
+    // path always has that agent's own item around the queried time.  tmask_m2 / u_tmask_m2 = buckets covered by at least
+    // TWO items of the key, so the own item's buckets can be taken out of the test exactly; nullptr = no filter.
+    const unsigned long long *tmask_m2, *u_tmask_m2;
+    const uint16_t *path;         // HBM [A][pred_cap] predicted paths of the env (state per waypoint)
+    int pred_cap;
+    const uint16_t *a_lp, *a_lp2, *a_tpc2;  // last waypoint in the first / second index, times per cell of the second
     long long *dbg;               // diagnostic builds
     int dbg_base;
 };
@@ -106,9 +123,25 @@ __device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int r) { return X.c
 __device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int r) { return X.cellw[r] >> 16; }
 __device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int r) { return X.cellw[r]; }
 __device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? (int)X.rkey[r] : r; }
+// Pass B serves one builder (PB 0 = upstream, 1 = flatland_cutils) or both in one pass (PB 2): cu says which builder's
+// rules apply to a team
+template <int PB>
+__device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 2 ? team < X.n_cu : PB == 1; }
+// predicted time at which the walking agent reaches a cell tot steps away (treeobs.cpp:378 / observations.py:329)
+template <int PB>
+__device__ __forceinline__ int pt_of(const ObsCtx &X, bool cu, int handle, int tot) {
+    if (PB == 2 && !cu) return (int)((double)tot * X.a_tq2[handle]);
+    return cu ? (int)((float)tot * (float)X.a_tq[handle]) : (int)((double)tot * X.a_tq[handle]);
+}
 // items of rail cell r's key a conflict query at predicted time pt has to look at: [lo, hi)
-__device__ __forceinline__ void list_range(const ObsCtx &X, int r, int pt, int &lo, int &hi) {
+template <int PB>
+__device__ __forceinline__ void list_range(const ObsCtx &X, bool cu, int r, int pt, int &lo, int &hi) {
     const int key = key_of(X, r);
+    if (PB == 2 && !cu) {
+        lo = key > 0 ? X.u_csr_end[key - 1] : 0;
+        hi = X.u_csr_end[key];
+        return;
+    }
     const int base = key > 0 ? X.csr_end[key - 1] : 0;
     if (X.bk_rel) {
         const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_BK_NB - 1);
@@ -193,8 +226,8 @@ __host__ __device__ inline int obs_scr_words(int nwaves, int A, int tw_c, int tw
 // min / sum / max are associative and tot_dist grows along a walk, so "first hit" = minimum.
 //
 // occupant of the cell (treeobs.cpp:322-357 / observations.py:296-327)
-template <bool CUTILS, int CAP>
-__device__ __forceinline__ void occ_event(const ObsCtx &X, int *sc, int node, uint32_t sl, uint32_t d, int tot) {
+template <int PB, int CAP>
+__device__ __forceinline__ void occ_event(const ObsCtx &X, bool CUTILS, int *sc, int node, uint32_t sl, uint32_t d, int tot) {
     const int ag = X.slot_agent[sl];
     if (ag < 0) return;
     atomicMin(&sc[F_OA * CAP + node], tot);
@@ -217,15 +250,16 @@ __device__ __forceinline__ void occ_event(const ObsCtx &X, int *sc, int node, ui
 // Tn > 0, tot < Tn and pt < Tn.  conflict_flags scans items [lo, hi) of the cell's key and returns six bits:
 // bit k (k = 0, 1, 2 for the times pt, pt - 1, pt + 1): some OTHER agent is predicted there then; bit 3 + k: some agent
 // predicted there then (self included) satisfies the conflict condition.  Flags of sub-ranges of a list simply OR.
-template <bool CUTILS, bool ITL>
-__device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, int cell, uint32_t d, int pt, int lo, int hi) {
+template <int PB, bool ITL>
+__device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS, int handle, int cell, uint32_t d, int pt, int lo, int hi) {
     const uint32_t bits = nibble(cw_bits(X, cell), d);
-    const uint32_t tlast = (uint32_t)(X.Tn - 1);
-    const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, X.Tn - 1);
+    const bool second = PB == 2 && !CUTILS;  // the upstream predictor's index
+    const int Tn = second ? X.u_Tn : X.Tn;
+    const uint32_t tlast = (uint32_t)(Tn - 1);
+    const uint32_t t0 = (uint32_t)pt, t1 = (uint32_t)max(pt - 1, 0), t2 = (uint32_t)min(pt + 1, Tn - 1);
     uint32_t flags = 0;
-    auto test_item = [&](uint32_t it) {
+    auto test_item = [&](uint32_t it) __attribute__((always_inline)) {
         const uint32_t tl = IT_TLO(it), th = IT_THI(it, tlast);
-        if (th < t1 || tl > t2) return;
         const uint32_t in = (uint32_t)(tl <= t0 && t0 <= th) | ((uint32_t)(tl <= t1 && t1 <= th) << 1) | ((uint32_t)(tl <= t2 && t2 <= th) << 2);
         const int a = IT_AGENT(it);
         // direction the conflict test uses: upstream takes the one at the matching time step
@@ -236,23 +270,47 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, 
         if (CUTILS && !(in & 1u)) cd = t0 > th ? IT_DNEXT(it) : IT_DPREV(it);
         const bool cnd = (d != cd && ((bits >> (3u - ((cd + 2u) & 3u))) & 1u)) || X.a_state[a] == ST_DONE;
         flags |= (a != handle ? in : 0u) | (cnd ? in << 3 : 0u);
+#ifdef FL_OBS_COUNTS
+        if (a == handle && in) flags |= 64u;  // the walking agent itself is predicted there then
+#endif
     };
-    // the key's list is short and unsorted: scan it with NB independent loads in flight, most items fall out at the
-    // interval test (sorting the lists costs more than it saves)
+    // The key's list is short and unsorted and nearly all of its items are about other times.  In lock step the full test
+    // would run for every item slot in which ANY lane has a match, so the scan takes two steps: a cheap interval test of all
+    // items (NB independent loads in flight) that leaves a bit mask of the matching ones, then the full test of only those
+    // (fetched again, two at a time).  Windows of 32 items; a slot past the end repeats the last item, which is harmless.
     auto scan = [&](const uint32_t *items, auto nb) __attribute__((always_inline)) {
         constexpr int NB = decltype(nb)::value;
-        for (int e0 = lo; e0 < hi; e0 += NB) {
-            uint32_t itv[NB];
+        for (int w0 = lo; w0 < hi; w0 += 32) {
+            const int wend = min(hi, w0 + 32);
+            uint32_t hits = 0;
+            for (int e0 = w0; e0 < wend; e0 += NB) {
+                uint32_t itv[NB];
 #pragma unroll
-            for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, hi - 1)];
+                for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, wend - 1)];
 #pragma unroll
-            for (int q = 0; q < NB; q++)
-                if (e0 + q < hi) test_item(itv[q]);
+                for (int q = 0; q < NB; q++) {
+                    const uint32_t tl = IT_TLO(itv[q]), th = IT_THI(itv[q], tlast);
+                    hits |= (uint32_t)(th >= t1 && tl <= t2) << ((e0 - w0 + q) & 31);
+                }
+            }
+#ifdef FL_SCAN_ONE_STEP
+            for (int e0 = w0; e0 < wend; e0++) if ((hits >> (e0 - w0)) & 1u) test_item(items[e0]);
+            hits = 0;
+#endif
+            while (hits) {
+                const int q0 = __ffs((int)hits) - 1;
+                hits &= hits - 1u;
+                const int q1 = hits ? __ffs((int)hits) - 1 : q0;
+                hits &= hits - 1u;
+                const uint32_t it0 = items[min(w0 + q0, wend - 1)], it1 = items[min(w0 + q1, wend - 1)];
+                test_item(it0);
+                if (q1 != q0) test_item(it1);
+            }
         }
     };
     // separate call sites so that each keeps a static address space; whole lists in HBM scratch (large maps without time
     // masks) are fetched in bigger batches: their round trips are what the scan costs
-    if (ITL) scan(X.items_lds, std::integral_constant<int, 4>());
+    if (ITL) scan(second ? X.u_items : X.items_lds, std::integral_constant<int, 8>());
     else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK>());  // chunked work-list entries: the whole chunk in flight at once
     else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
     return flags;
@@ -260,12 +318,12 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, int handle, 
 // the other-agent test takes the first time (pt, pt - 1, pt + 1) at which somebody else is predicted on the cell
 __device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f >> 3) & 1u : ((f & 2u) ? (f >> 4) & 1u : ((f & 4u) ? (f >> 5) & 1u : false)); }
 
-template <bool CUTILS, int CAP, bool ITL>
-__device__ __forceinline__ void conflict_event(const ObsCtx &X, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
+template <int PB, int CAP, bool ITL>
+__device__ __forceinline__ void conflict_event(const ObsCtx &X, bool cu, int *sc, int node, int handle, int cell, uint32_t d, int tot, int pt) {
     int lo, hi;
-    list_range(X, cell, pt, lo, hi);
+    list_range<PB>(X, cu, cell, pt, lo, hi);
     if (hi <= lo) return;
-    if (conflict_hit(conflict_flags<CUTILS, ITL>(X, handle, cell, d, pt, lo, hi))) atomicMin(&sc[F_PC * CAP + node], tot);
+    if (conflict_hit(conflict_flags<PB, ITL>(X, cu, handle, cell, d, pt, lo, hi))) atomicMin(&sc[F_PC * CAP + node], tot);
 }
 
 // flag word of a conflict work-list entry (other lanes OR their bits into it)
@@ -290,6 +348,33 @@ __device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool w
     return !want || idx < cap;
 }
 
+// Slots in BOTH work lists with one LDS atomic per wavefront (the two counters are the halves of one 64-bit word), split in
+// two so that the caller can issue the next cell's loads while the atomic is in flight.
+__device__ __forceinline__ unsigned long long wl_reserve2_issue(int *cnt, unsigned long long m0, unsigned long long m1) {
+    unsigned long long old = 0;
+    // one lane adds for the wavefront.  The address goes through a register the compiler cannot see through: for an address it
+    // knows to be uniform it rewrites the atomic into its own wave reduction and waits for the result on the spot
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    if ((m0 | m1) != 0ull && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1)
+        old = atomicAdd(reinterpret_cast<unsigned long long *>(cnt) + zero, (unsigned long long)__popcll(m0) | ((unsigned long long)__popcll(m1) << 32));
+    return old;
+}
+__device__ __forceinline__ void wl_reserve2_finish(unsigned long long old, unsigned long long m0, unsigned long long m1, int &i0, int &i1) {
+    const int b0 = __builtin_amdgcn_readfirstlane((int)(uint32_t)old), b1 = __builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
+    const unsigned long long lt = (1ull << __lane_id()) - 1ull;
+    i0 = b0 + __popcll(m0 & lt);
+    i1 = b1 + __popcll(m1 & lt);
+}
+
+#ifdef FL_OBS_TIMING
+// per-wavefront marks inside a phase (absolute clock): slot k = latest wavefront, slot k2 = 2^40 - earliest wavefront
+#define WAVE_MARK(X, k, k2) do { if ((X).dbg && (threadIdx.x & 63) == 0) { const long long now_ = (long long)wall_clock64() & 0xFFFFFFFFFFll; \
+    atomicMax((unsigned long long *)&(X).dbg[(X).dbg_base + (k)], (unsigned long long)now_); \
+    if ((k2) >= 0) atomicMax((unsigned long long *)&(X).dbg[(X).dbg_base + ((k2) < 0 ? 0 : (k2))], (unsigned long long)((1ll << 40) - now_)); } } while (0)
+#else
+#define WAVE_MARK(X, k, k2) do {} while (0)
+#endif
 #ifdef FL_OBS_TIMING
 // accumulates the time since the previous stamp of this stage in slot k (summed over the rounds of trees)
 #define TREE_STAMP(X, k) do { __syncthreads(); if (threadIdx.x == 0 && (X).dbg) { const long long now_ = (long long)wall_clock64(); (X).dbg[(X).dbg_base + (k)] += now_ - (X).dbg[(X).dbg_base + 15]; (X).dbg[(X).dbg_base + 15] = now_; } } while (0)
@@ -303,39 +388,67 @@ __device__ __forceinline__ void team_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Pass B of the trees.  team_prepare: per team (= one agent's tree), inclusive prefix of the nodes' visit counts and
-// reset of the node accumulators.  wg_pass_b: the visited cells of ALL nodes of ALL trees of the batch are split evenly
-// over ALL lanes of the workgroup; every lane walks its slice (binary search for its first team / node, a cheap skip
-// to the slice start, then ONE lock-step loop over its cells).
+// Pass B of the trees.  team_prepare: per team (= one agent's tree), inclusive prefix of the nodes' visit counts, a link
+// from every node to the next node that has cells, and reset of the node accumulators.  wg_pass_b: the visited cells of ALL
+// nodes of ALL trees of the batch are split evenly over ALL lanes of the workgroup; every lane walks its slice (search
+// for its first team / node, a skip to the slice start, then ONE lock-step loop over its cells).
+//
+// F_INCL word of node k: inclusive prefix (24 bits) | index of the next node with cells << 24 (0xFF = none).
+// Returns the team's number of cells; first_real = its first node with cells (0xFF = none).
 template <int TEAM, int CAP>
-__device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int *scr) {
+__device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int *scr, int &first_real) {
+    constexpr int NCH = (CAP + TEAM - 1) / TEAM;
     unsigned long long *ms = reinterpret_cast<unsigned long long *>(scr + F_MS * CAP);
+    const int tbase = ((int)__lane_id() / TEAM) * TEAM;
+    const unsigned long long tbits = TEAM == 64 ? ~0ull : ((1ull << (TEAM & 63)) - 1ull);
+    int v[NCH];
+    unsigned long long real[NCH];  // bit j: node c * TEAM + j has cells
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int k = c * TEAM + tl;
+        v[c] = (have && k < n_nodes && k < CAP && scr[F_START * CAP + k] >= 0) ? scr[F_VIS * CAP + k] : 0;
+        real[c] = (__ballot(v[c] > 0) >> tbase) & tbits;
+    }
     int run_base = 0;
-    for (int k0 = 0; k0 < CAP; k0 += TEAM) {
-        const int k = k0 + tl;
-        int v = (have && k < n_nodes && k < CAP && scr[F_START * CAP + k] >= 0) ? scr[F_VIS * CAP + k] : 0;
-        int incl = v;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int k = c * TEAM + tl;
+        int incl = v[c];
 #pragma unroll
         for (int off = 1; off < TEAM; off <<= 1) { const int u = __shfl_up(incl, off, TEAM); if (tl >= off) incl += u; }
         incl += run_base;
+        int nxt = 0xFF;
+#pragma unroll
+        for (int c2 = NCH - 1; c2 > c; c2--)
+            if (real[c2]) nxt = c2 * TEAM + __ffsll((long long)real[c2]) - 1;
+        const unsigned long long above = tl + 1 < TEAM ? real[c] >> ((tl + 1) & 63) : 0ull;
+        if (above) nxt = k + __ffsll((long long)above);
         if (k < CAP) {
-            scr[F_INCL * CAP + k] = incl;
+            scr[F_INCL * CAP + k] = incl | (nxt << 24);
             scr[F_OA * CAP + k] = 0x7fffffff; scr[F_PC * CAP + k] = 0x7fffffff; scr[F_OT * CAP + k] = 0x7fffffff;
             scr[F_SAME * CAP + k] = 0; scr[F_OPP * CAP + k] = 0; scr[F_MALF * CAP + k] = 0; scr[F_READY * CAP + k] = 0;
             ms[k] = 0x3FF0000000000000ull;  // 1.0; positive doubles order like their bit patterns
         }
         run_base = __shfl(incl, TEAM - 1, TEAM);
     }
+    first_real = 0xFF;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--)
+        if (real[c]) first_real = c * TEAM + __ffsll((long long)real[c]) - 1;
     return run_base;
 }
 
-// team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1), [192,256) BFS levels (cutils)
+// team_meta: [0,64) cells per team, [64,128) nodes per team, [128,192) agent of the team (or -1), [192,256) BFS levels (cutils),
+// [256,320) first node with cells
 //
 // Step 1: every lane walks its slice of the visited cells and only CLASSIFIES them (three cheap tests per cell: has the
 // cell an occupant; does the time-bucket mask of its key say that somebody is predicted there around the queried time;
 // is it somebody's target) -- cells that need work go to two LDS work lists.  Step 2: the lists are processed one entry
 // per lane, so the expensive handlers run on densely packed wavefronts instead of as rare side branches of a lock-step loop.
-template <bool CUTILS, int CAP, bool ITL>
+// The loop of step 1 is a chain of LDS round trips, so it is software-pipelined by hand: everything the NEXT cell needs
+// (rail word, successor, time mask, the next node's descriptor when the walk ends here) is requested while the work-list
+// reservation of the current cell is in flight -- about one round trip per cell.
+template <int PB, int CAP, bool ITL>
 __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int n_teams, int *scr0, int team_words,
                                           const int *team_meta) {
     if (tid == 0) { X.wl_cnt[0] = 0; X.wl_cnt[1] = 0; X.wl_cnt[2] = 0; }
@@ -346,20 +459,30 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     int tincl = tv;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(tincl, off); if (lane >= off) tincl += u; }
-    const int total = __shfl(tincl, 63);
+    const int total = __builtin_amdgcn_readlane(tincl, 63);
     const int q = (total + nt - 1) / nt;
     int pos = tid * q;
     const int end = min(pos + q, total);
-    // first team whose inclusive prefix exceeds pos (all lanes take part in the shuffles)
-    int tlo = 0, thi = n_teams - 1;
-    const int ppos = min(pos, max(total - 1, 0));
-    for (int it = 0; it < 6; it++) {
-        const int mid = (tlo + thi) >> 1;
-        const int v = __shfl(tincl, mid);
-        if (tlo < thi) { if (v > ppos) thi = mid; else tlo = mid + 1; }
+    // first team whose inclusive prefix exceeds pos: the wavefront's first cell by a scalar binary search (v_readlane, no LDS),
+    // then every lane counts the few team boundaries inside the wavefront's range
+    const int wpos0 = __builtin_amdgcn_readfirstlane(tid >> 6) * 64 * q;
+    int team = 0, t_excl = 0;
+    if (wpos0 < total) {
+        const int wlast = min(wpos0 + 64 * q, total) - 1;
+        int ulo = 0, uhi = n_teams - 1;
+        while (ulo < uhi) {
+            const int mid = (ulo + uhi) >> 1;
+            if (__builtin_amdgcn_readlane(tincl, mid) > wpos0) uhi = mid; else ulo = mid + 1;
+        }
+        team = ulo;
+        t_excl = ulo > 0 ? __builtin_amdgcn_readlane(tincl, ulo - 1) : 0;
+        const int ppos = min(pos, total - 1);
+        for (int t = ulo; t < n_teams - 1; t++) {
+            const int v = __builtin_amdgcn_readlane(tincl, t);
+            if (v > wlast) break;
+            if (ppos >= v) { team = t + 1; t_excl = v; }
+        }
     }
-    int team = tlo;
-    const int t_excl = __shfl(tincl, team) - __shfl(tv, team);
 #ifdef FL_OBS_TIMING
     const long long dbg_t1 = (long long)wall_clock64();
     int dbg_skip = 0;
@@ -368,22 +491,49 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int *vs = scr0 + team * team_words;
         int nn = team_meta[64 + team];
         int handle = team_meta[128 + team];
-        // first node of the team whose inclusive prefix exceeds the team-local position
+        // first node of the team whose inclusive prefix exceeds the team-local position: three pivots per round trip
         const int lpos = pos - t_excl;
         int lo = 0, hi = nn - 1;
         while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (vs[F_INCL * CAP + mid] > lpos) hi = mid; else lo = mid + 1;
+            const int m2 = (lo + hi) >> 1, m1 = (lo + m2) >> 1, m3 = (m2 + 1 + hi) >> 1;
+            const int i1 = vs[F_INCL * CAP + m1] & 0xFFFFFF, i2 = vs[F_INCL * CAP + m2] & 0xFFFFFF, i3 = vs[F_INCL * CAP + m3] & 0xFFFFFF;
+            if (i1 > lpos) hi = m1;
+            else if (i2 > lpos) { lo = m1 + 1; hi = m2; }
+            else if (i3 > lpos) { lo = m2 + 1; hi = m3; }
+            else lo = min(m3 + 1, hi);
         }
         int node = lo;
-        int target = X.a_target[handle];
-        float tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);  // float time_per_cell = 1.0 / agent.speed (treeobs.cpp:304)
-        double tpc_d = 1.0 / X.a_speed[handle];                          // np.reciprocal(speed) (observations.py:277)
+        // what changes with the team: the walking agent's target and time per cell (pt_of) and, with the trees of both builders
+        // in one pass, whose rules and whose prediction index apply
+        int target;
+        double tq;
+        bool cu;
+        const unsigned long long *tmask_t = X.tmask, *tmask2_t = X.tmask_m2;
+        int Tn_t = X.Tn, tshift_t = X.tshift;
+        const bool self_filter = PB == 2 && X.tmask_m2 != nullptr;
+        const uint16_t *path_t = X.path;
+        int lp_t = 0, tpc_t = 1;
+        auto enter_team = [&]() __attribute__((always_inline)) {
+            target = X.a_target[handle];
+            cu = pb_cu<PB>(X, team);
+            tq = (PB == 2 && !cu) ? X.a_tq2[handle] : X.a_tq[handle];
+            if (PB == 2) {
+                tmask_t = cu ? X.tmask : X.u_tmask; Tn_t = cu ? X.Tn : X.u_Tn; tshift_t = cu ? X.tshift : X.u_tshift;
+                if (self_filter) {
+                    tmask2_t = cu ? X.tmask_m2 : X.u_tmask_m2;
+                    path_t = X.path + (size_t)handle * X.pred_cap;
+                    lp_t = cu ? X.a_lp[handle] : X.a_lp2[handle];
+                    tpc_t = cu ? X.a_tpc[handle] : X.a_tpc2[handle];
+                }
+            }
+        };
+        enter_team();
         // state of the piece being walked
-        int left, cell, tot;
+        int left, cell, tot, nxt;
         uint32_t dd;
         {
-            const int nvis = vs[F_VIS * CAP + node], incl = vs[F_INCL * CAP + node];
+            const uint32_t inw = (uint32_t)vs[F_INCL * CAP + node];
+            const int nvis = vs[F_VIS * CAP + node], incl = (int)(inw & 0xFFFFFFu);
             const int k = lpos - (incl - nvis);  // offset inside the node's walk
             const uint32_t st = skip_cells(X, (uint32_t)vs[F_START * CAP + node], k);
             cell = (int)(st >> 2); dd = st & 3u;
@@ -392,75 +542,124 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #endif
             tot = vs[F_TOT * CAP + node] + k;
             left = nvis - k;
+            nxt = (int)(inw >> 24);
         }
 #ifdef FL_OBS_TIMING
         if (X.dbg && lane == 0) atomicMax((unsigned long long *)&X.dbg[24], (unsigned long long)((long long)wall_clock64() - dbg_t1));
 #endif
-        // ONE loop over the lane's cells (lanes of a wave run it in lock step); node / team boundaries are side branches
-        for (; pos < end; pos++) {
-            if (left == 0) {
-                while (true) {  // next node with cells, possibly in the next team(s)
-                    node++;
-                    if (node >= nn) {
-                        team++;
-                        if (team >= n_teams) { team = n_teams - 1; node = nn - 1; pos = end; break; }  // cannot happen: the prefix says cells remain
-                        vs = scr0 + team * team_words;
-                        nn = team_meta[64 + team];
-                        handle = team_meta[128 + team];
-                        node = 0;
-                        if (handle >= 0) {
-                            target = X.a_target[handle];
-                            tpc_f = (float)(1.0 / (double)(float)X.a_speed[handle]);
-                            tpc_d = 1.0 / X.a_speed[handle];
-                        }
-                        continue;
-                    }
-                    if (vs[F_START * CAP + node] >= 0 && vs[F_VIS * CAP + node] > 0) break;
-                }
-                if (pos >= end) break;
-                const int st = vs[F_START * CAP + node];
-                cell = st >> 2; dd = st & 3;
-                tot = vs[F_TOT * CAP + node];
-                left = vs[F_VIS * CAP + node];
+        // The common case -- time masks, successor table, keys = rail indices -- gets its own copy of the loop, without the
+        // tests for what is there
+        auto walk = [&](auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const bool has_snext = FAST || X.snext != nullptr, has_tmask = FAST || X.tmask != nullptr;
+        // what the loop body needs of the current cell, requested one iteration ahead
+        uint32_t cw = 0, sn = 0, ct = 0, n_inw = 0, own_w = 0;
+        unsigned long long tm = 0, tm2 = 0;
+        int c_hi = 0, c_lo = 0, n_start = 0, n_tot = 0, n_vis = 0;
+        auto request = [&]() __attribute__((always_inline)) {
+            if (FAST && self_filter) own_w = path_t[min(tot, lp_t)];  // HBM (L2): the longest latency first
+            cw = cw_load(X, cell);
+            if (has_snext) sn = X.snext[((uint32_t)cell << 2) | dd];
+            if (FAST || X.Tn > 0) {
+                const int key = FAST ? cell : key_of(X, cell);
+                if (has_tmask) { tm = tmask_t[key]; if (FAST && self_filter) tm2 = tmask2_t[key]; }
+                else { c_hi = X.csr_end[key]; c_lo = key > 0 ? X.csr_end[key - 1] : 0; }
             }
-            const uint32_t cw = cw_load(X, cell);
+            if (PB != 1) ct = X.cell_target[cell >> 5];
+            if (left == 1 && nxt < nn) {  // the walk ends on this cell: descriptor of the team's next node with cells
+                n_start = vs[F_START * CAP + nxt]; n_tot = vs[F_TOT * CAP + nxt]; n_vis = vs[F_VIS * CAP + nxt];
+                n_inw = (uint32_t)vs[F_INCL * CAP + nxt];
+            }
+        };
+        request();
+        // ONE loop over the lane's cells (lanes of a wave run it in lock step)
+        while (true) {
+            const int e_cell = cell, e_tot = tot, e_node = node, e_handle = handle;
+            const uint32_t e_dd = dd;
+            const bool e_cu = cu;
             int *sc = scr0 + team * team_words;
             const uint2 entry = make_uint2(((uint32_t)cell << 2) | dd | ((uint32_t)team << 24), (uint32_t)tot | ((uint32_t)node << 24));
             // occupant?
             const uint32_t sl = cw >> 16;
             const bool occ = sl != 0xFFFFu;
-            if (!wl_push(X.wl_occ, X.wl_occ_cap, &X.wl_cnt[0], occ, entry)) occ_event<CUTILS, CAP>(X, sc, node, sl, dd, tot);
             // somebody predicted on this key around the queried time?
             bool cand = false;
             int pt = 0;
-            if (X.Tn > 0 && tot < X.Tn) {
-                pt = CUTILS ? (int)((float)tot * tpc_f) : (int)((double)tot * tpc_d);
-                if (pt < X.Tn) {
-                    const int key = key_of(X, cell);
-                    if (X.tmask) {
-                        const int b1 = min(max(pt - 1, 0) >> X.tshift, 63), b2 = min(min(pt + 1, X.Tn - 1) >> X.tshift, 63);
-                        const unsigned long long qm = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
-                        cand = (X.tmask[key] & qm) != 0ull;
+            if ((FAST || X.Tn > 0) && tot < Tn_t) {
+                pt = cu ? (int)((float)tot * (float)tq) : (int)((double)tot * tq);
+                if (pt < Tn_t) {
+                    if (has_tmask) {  // buckets of the times pt - 1 .. pt + 1: at most three consecutive bits from b1 on
+                        const int b1 = min(max(pt - 1, 0) >> tshift_t, 63), b2 = min(min(pt + 1, Tn_t - 1) >> tshift_t, 63);
+                        unsigned long long others = tm;
+                        if (FAST && self_filter && tot >= 1 && tot <= lp_t && (int)(own_w >> 2) == cell) {
+                            // this cell is waypoint tot of the walking agent's own path: the buckets of that item (same formulas as
+                            // the fill of the index) count only where a second item covers them too
+                            const int tlast = Tn_t - 1;
+                            const int tlo = cu ? (tot - 1) * tpc_t + 1 : tot * tpc_t, te = tlo + tpc_t - 1;
+                            const int thi = (tot == lp_t || te >= tlast) ? tlast : te;
+                            const int o1 = min(tlo >> tshift_t, 63), o2 = min(thi >> tshift_t, 63);
+                            others = (tm & ~(((2ull << o2) - 1ull) & ~((1ull << o1) - 1ull))) | tm2;
+                        }
+                        cand = ((uint32_t)(others >> b1) & ((2u << (b2 - b1)) - 1u)) != 0u;
                     } else {
-                        cand = X.csr_end[key] > (key > 0 ? X.csr_end[key - 1] : 0);
+                        cand = c_hi > c_lo;
                     }
                 }
             }
-            if (X.tmask) {
-                if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], cand, make_uint2(entry.x, (uint32_t)tot | ((uint32_t)node << 24))))
-                    conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);  // list full
-            } else if (cand) {
-                conflict_event<CUTILS, CAP, ITL>(X, sc, node, handle, cell, dd, tot, pt);
-            }
             // somebody's target (upstream only: cutils never fills the map, treeobs.cpp:72)
-            if (!CUTILS && ((X.cell_target[cell >> 5] >> (cell & 31)) & 1u) && cell != target) atomicMin(&sc[F_OT * CAP + node], tot);
+            const bool tgt_hit = !cu && ((ct >> (cell & 31)) & 1u) && cell != target;
+            // reserve the work-list slots of the wavefront (without time masks the conflicts are handled in place)
+            const bool to_cf = cand && has_tmask;
+            const unsigned long long m_occ = __ballot(occ), m_cf = __ballot(to_cf);
+            const unsigned long long resv = wl_reserve2_issue(X.wl_cnt, m_occ, m_cf);
+            // advance to the next cell and request its data
+            pos++;
             left--;
-            if (left > 0) {  // keep walking along the only transition
-                const uint32_t sn = chain_next(X, ((uint32_t)cell << 2) | dd, cw & 0xFFFFu);
-                cell = (int)(sn >> 2); dd = sn & 3u;
-                tot += 1;
+            const bool more = pos < end;
+            if (more) {
+                if (left > 0) {  // keep walking along the only transition
+                    const uint32_t s2 = has_snext ? sn : chain_next(X, ((uint32_t)cell << 2) | dd, cw & 0xFFFFu);
+                    cell = (int)(s2 >> 2); dd = s2 & 3u;
+                    tot += 1;
+                } else {
+                    if (nxt < nn) {
+                        node = nxt;
+                    } else {  // next team with cells (the prefix says cells remain)
+                        do { team++; } while (team < n_teams - 1 && team_meta[team] == 0);
+                        vs = scr0 + team * team_words;
+                        nn = team_meta[64 + team];
+                        handle = team_meta[128 + team];
+                        node = team_meta[256 + team];
+                        enter_team();
+                        n_start = vs[F_START * CAP + node]; n_tot = vs[F_TOT * CAP + node]; n_vis = vs[F_VIS * CAP + node];
+                        n_inw = (uint32_t)vs[F_INCL * CAP + node];
+                    }
+                    cell = n_start >> 2; dd = (uint32_t)n_start & 3u;
+                    tot = n_tot;
+                    left = n_vis;
+                    nxt = (int)(n_inw >> 24);
+                }
+                request();
             }
+            // file the current cell
+            int i_occ, i_cf;
+            wl_reserve2_finish(resv, m_occ, m_cf, i_occ, i_cf);
+            if (occ) {
+                if (i_occ < X.wl_occ_cap) X.wl_occ[i_occ] = entry;
+                else occ_event<PB, CAP>(X, e_cu, sc, e_node, sl, e_dd, e_tot);  // list full
+            }
+            if (to_cf) {
+                if (i_cf < X.wl_cf_cap) X.wl_cf[i_cf] = entry;
+                else conflict_event<PB, CAP, ITL>(X, e_cu, sc, e_node, e_handle, e_cell, e_dd, e_tot, pt);  // list full
+            } else if (cand) {
+                conflict_event<PB, CAP, ITL>(X, e_cu, sc, e_node, e_handle, e_cell, e_dd, e_tot, pt);
+            }
+            if (tgt_hit) atomicMin(&sc[F_OT * CAP + e_node], e_tot);
+            if (!more) break;
         }
+        };
+        if (PB == 2 || (X.tmask != nullptr && X.snext != nullptr && X.rkey == nullptr)) walk(std::true_type());  // PB 2: the launcher saw to it
+        else walk(std::false_type());
     }
 #ifdef FL_OBS_TIMING
     if (X.dbg && lane == 0) {
@@ -472,6 +671,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #endif
     __syncthreads();
     TREE_STAMP(X, 11);
+    WAVE_MARK(X, 18, -1);
     // step 2: one list entry per lane
     const int n_occ = min(X.wl_cnt[0], X.wl_occ_cap), n_cf = min(X.wl_cnt[1], X.wl_cf_cap);
 #ifdef FL_OBS_TIMING
@@ -480,67 +680,85 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     for (int e = tid; e < n_occ; e += nt) {
         const uint2 w = X.wl_occ[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        occ_event<CUTILS, CAP>(X, scr0 + team * team_words, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
+        occ_event<PB, CAP>(X, pb_cu<PB>(X, team), scr0 + team * team_words, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
-    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes
-    // further entries for the rest of its list.  First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) |
-    // node << 24; the others: chunk | index of the first entry << 6 (17 bits) | CF_MORE.
+    WAVE_MARK(X, 12, -1);
+    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone.  The first chunk is scanned
+    // right here, which settles a list of one chunk (nearly all of them).  A longer one: its entry becomes the FIRST entry,
+    // tot | chunks << 9 | flags << 15 (OR-ed together below) | node << 24, and pushes further entries chunk | index of the
+    // first entry << 6 (17 bits) | CF_MORE for the rest of its list; those are scanned after a barrier.
+    bool any_multi = false;
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
-        int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0;
+        int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0, pt = 0;
+        bool cu = PB == 1;
         uint2 w = make_uint2(0u, 0u);
         if (e < n_cf) {
             w = X.wl_cf[e];
             cell = (int)((w.x & 0xFFFFFFu) >> 2);
-            handle = team_meta[128 + (int)(w.x >> 24)];
+            const int team = (int)(w.x >> 24);
+            handle = team_meta[128 + team];
             tot = (int)(w.y & 511u);
-            const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
-            list_range(X, cell, pt, lo, hi);
+            cu = pb_cu<PB>(X, team);
+            pt = pt_of<PB>(X, cu, handle, tot);
+            list_range<PB>(X, cu, cell, pt, lo, hi);
             nch = max(min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
-            X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
+            // the first chunk is scanned right here: every lane of the wavefront scans one
+            const uint32_t f = hi > lo ? conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo, min(hi, lo + CF_CHUNK)) : 0u;
+#ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down)
+            if (X.dbg) {
+                atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)(hi - lo));
+                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+                if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
+                if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
+                if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
+            }
+#endif
+            if (nch == 1) {
+                if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(w.y >> 24)], tot);
+            } else {
+                X.wl_cf[e].y = w.y | ((uint32_t)nch << 9) | (f << 15);
+                any_multi = true;
+            }
         }
         for (int j = 1; __any(j < nch); j++) {
             if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
                 // list full: this chunk is scanned here
-                const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
-                const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + j * CF_CHUNK, j == 62 ? hi : min(hi, lo + (j + 1) * CF_CHUNK));
+                const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + j * CF_CHUNK, j == 62 ? hi : min(hi, lo + (j + 1) * CF_CHUNK));
                 if (f) atomicOr(&X.wl_cf[e].y, f << 15);
             }
         }
     }
-    __syncthreads();
-    const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
-    bool any_multi = false;
-    for (int e = tid; e < n_cf2; e += nt) {
-        const uint2 w = X.wl_cf[e];
-        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        const bool more = (w.y & CF_MORE) != 0;
-        const int first = more ? (int)((w.y >> 6) & 0x1FFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
-        const uint32_t fy = more ? wl_flags(X, &X.wl_cf[first]) : w.y;
-        const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
-        const int handle = team_meta[128 + team];
-        const int pt = CUTILS ? (int)((float)tot * (float)(1.0 / (double)(float)X.a_speed[handle])) : (int)((double)tot * (1.0 / X.a_speed[handle]));
-        int lo, hi;
-        list_range(X, cell, pt, lo, hi);
-        const uint32_t f = conflict_flags<CUTILS, ITL>(X, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
-        if (nch == 1) {
-            if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(fy >> 24)], tot);
-        } else {
-            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
-            any_multi = true;
-        }
-    }
     if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
+    WAVE_MARK(X, 13, 17);
     __syncthreads();
-    if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
+    WAVE_MARK(X, 14, -1);
+    if (X.wl_cnt[2]) {  // some keys have more than one chunk
+        const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
         for (int e = tid; e < n_cf2; e += nt) {
+            const uint2 w = X.wl_cf[e];
+            if (!(w.y & CF_MORE)) continue;  // first chunks: done above
+            const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
+            const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u);
+            const uint32_t fy = wl_flags(X, &X.wl_cf[first]);
+            const int tot = (int)(fy & 511u);
+            const int handle = team_meta[128 + team];
+            const bool cu = pb_cu<PB>(X, team);
+            const int pt = pt_of<PB>(X, cu, handle, tot);
+            int lo, hi;
+            list_range<PB>(X, cu, cell, pt, lo, hi);
+            const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
+            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
+        }
+        __syncthreads();
+        for (int e = tid; e < n_cf2; e += nt) {  // the first entries have collected all flags
             uint2 w = X.wl_cf[e];
             w.y = wl_flags(X, &X.wl_cf[e]);
-            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
+            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 0u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) atomicMin(&(scr0 + (int)(w.x >> 24) * team_words)[F_PC * CAP + (int)(w.y >> 24)], (int)(w.y & 511u));
         }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // the 12 features of node k from its descriptor and accumulators (treeobs.cpp:546-573 / observations.py:433-461)
@@ -600,8 +818,8 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
 
 // LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
 enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
-       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_LP, L_A_N, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
-       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_NH, L_CSR2, L_TMASKB, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
+       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_TQ, L_A_TQ2, L_A_LP, L_A_N, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
+       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_TMASK2, L_NH, L_CSR2, L_TMASKB, L_TMASKB2, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
 #define L_ABSENT 0xFFFFFFFFu
 struct ObsLayout {
     unsigned off[L_COUNT];  // byte offset into the dynamic LDS, L_ABSENT = not in this launch
@@ -609,6 +827,8 @@ struct ObsLayout {
     int nt;                 // threads per workgroup
     int wl_bytes;           // size of the pass B work lists
     int tab_lds;            // the env's dm / seg / nh / hop8 tables are staged in LDS (kernel template TAB_LDS)
+    int items_cap, items2_cap;  // entries of the LDS copies of the prediction items (first / second index); an env with more
+                                // falls back to the items in HBM scratch / to the two stages
 };
 
 // ---------------------------------------------------------------------------------------------- kernel
@@ -627,6 +847,7 @@ struct ObsArgs {
     int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
     int bk;            // large maps: the cutils index is grouped by time bucket (OBS_BK_NB); built in the node tables' LDS
+    int merged;        // fused launch on small envs: ONE pass B over the trees of both builders (trees_merged)
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
 };
 
@@ -734,9 +955,10 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         upstream_pass_a<TEAM, CAP>(X, P, b, i, have, tl, scr);
         TREE_STAMP(X, 6);
         {
-            const int tot_cells = team_prepare<TEAM, CAP>(have, tl, have ? NN : 1, scr);
+            int first;
+            const int tot_cells = team_prepare<TEAM, CAP>(have, tl, have ? NN : 1, scr, first);
             const int team_id = wave * TPW + team;
-            if (tl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? NN : 1; team_meta[128 + team_id] = have ? i : -1; }
+            if (tl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? NN : 1; team_meta[128 + team_id] = have ? i : -1; team_meta[256 + team_id] = first; }
         }
         wg_pass_b<false, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr0, F_WORDS * CAP, team_meta);
         TREE_STAMP(X, 7);
@@ -752,7 +974,8 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
                                               int gl, int *scr, const uint16_t *a_vpos, const int *a_pos,
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
-                                              const uint16_t *a_tslot, float max_dist, int &node_base_out, int &levels_out) {
+                                              const uint16_t *a_tslot, float max_dist, uint32_t spk, uint32_t malfw,
+                                              int &node_base_out, int &levels_out) {
     constexpr int CAP = 32;
     const int A = X.A, N = P.max_nodes;
     const int ia = have ? i : 0;
@@ -763,18 +986,6 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
     uint32_t orientation = dir;
     if (__popc(rbits) == 1) orientation = first_dir(rbits);
     float *F = P.forest + (size_t)g * N * 12;
-    if (have && gl == 0) {  // root (treeobs.cpp:171-186)
-        const uint32_t state = a_state[i];
-        double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint16_t dv = FL_INF16;
-        if (state == ST_DONE) dv = 0;
-        else dv = X.dm[a_tslot[i] * X.SS + (is_off_map(state) ? vpos : a_pos[i]) * 4 +  // off the map: vpos = initial position
-                       (int)(is_off_map(state) ? SPK_INIT_DIR(d.spk[g]) : dir)];
-        root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
-        root[9] = (double)((d.malf[g] >> 16) != 0);
-        root[10] = (double)(float)a_speed[i];
-        scale_and_store(root, max_dist, A, F);
-    }
     scr[F_START * CAP + gl] = -1; scr[F_VIS * CAP + gl] = 0;
     scr[F_PAR * CAP + gl] = -2;
     // level 1: three cells from the root (treeobs.cpp:205-222)
@@ -831,6 +1042,19 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
                 c_act = which - 1;
             }
         }
+    }
+    // the root row last: its HBM operands (spk, malfunction word) were requested before the level loop
+    if (have && gl == 0) {  // root (treeobs.cpp:171-186)
+        const uint32_t state = a_state[i];
+        double root[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint16_t dv = FL_INF16;
+        if (state == ST_DONE) dv = 0;
+        else dv = X.dm[a_tslot[i] * X.SS + (is_off_map(state) ? vpos : a_pos[i]) * 4 +  // off the map: vpos = initial position
+                       (int)(is_off_map(state) ? SPK_INIT_DIR(spk) : dir)];
+        root[6] = dv == FL_INF16 ? INFINITY : (double)dv;
+        root[9] = (double)((malfw >> 16) != 0);
+        root[10] = (double)(float)a_speed[i];
+        scale_and_store(root, max_dist, A, F);
     }
     team_sync();
     node_base_out = node_base;
@@ -926,13 +1150,15 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
                 node_base = team_meta[64 + wave * 2 + grp];
                 levels = team_meta[192 + wave * 2 + grp];
             } else {
-                cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, node_base, levels);
+                cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist,
+                              d.spk[b * A + (have ? i : 0)], d.malf[b * A + (have ? i : 0)], node_base, levels);
             }
             TREE_STAMP(X, 6);
             {
-                const int tot_cells = team_prepare<32, CAP>(have, gl, have ? node_base : 1, scr);
+                int first;
+                const int tot_cells = team_prepare<32, CAP>(have, gl, have ? node_base : 1, scr, first);
                 const int team_id = wave * 2 + grp;
-                if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; }
+                if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; team_meta[256 + team_id] = first; }
             }
             wg_pass_b<true, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, F_WORDS * CAP, team_meta);
             TREE_STAMP(X, 7);
@@ -941,6 +1167,45 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
             TREE_STAMP(X, 16);
         }
     }
+}
+
+// Fused launch on a small env (at most 31 agents, upstream depth <= 2): the trees of BOTH builders go through ONE pass B.
+// Node-table slot = pass B team: 0 .. A-1 flatland_cutils trees (team of 32 lanes, wavefront w holds agents 2w, 2w + 1),
+// A the shared dummy, A + 1 + u the upstream tree of agent u (team of 16 lanes, wavefront w holds agents 4w .. 4w + 3).
+// Pass A of all of them ran beside the path walk (obs_body).
+__device__ __forceinline__ int merged_slot_upstream(int A, int u) { return A + 1 + u; }
+
+template <bool ITL>
+__device__ __forceinline__ void trees_merged(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane, int nwaves,
+                                             int *wave_scr, int *team_meta, float max_dist) {
+    constexpr int CAP = 32, TW = F_WORDS * CAP;
+    const int A = X.A, NN = P.n_tree_nodes;
+    const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;
+    const bool have_c = ct < A;
+    int *scr_c = wave_scr + min(ct, A) * TW;
+    const int node_base = have_c ? team_meta[64 + ct] : 1, levels = have_c ? team_meta[192 + ct] : 0;
+    const int u = wave * 4 + (lane >> 4), tl = lane & 15;
+    const bool have_u = u < A;
+    int *scr_u = wave_scr + (have_u ? merged_slot_upstream(A, u) : A) * TW;
+    TREE_STAMP(X, 6);
+    {
+        int first;
+        const int cells = team_prepare<32, CAP>(have_c, gl, node_base, scr_c, first);
+        if (have_c && gl == 0) { team_meta[ct] = cells; team_meta[64 + ct] = node_base; team_meta[128 + ct] = ct; team_meta[256 + ct] = first; }
+        if (wave == 0 && lane == 0) { team_meta[A] = 0; team_meta[64 + A] = 1; team_meta[128 + A] = -1; team_meta[256 + A] = 0xFF; }
+    }
+    if (wave * 4 < A) {  // wave-uniform
+        int first;
+        const int cells = team_prepare<16, CAP>(have_u, tl, NN, scr_u, first);
+        const int id = merged_slot_upstream(A, u);
+        if (have_u && tl == 0) { team_meta[id] = cells; team_meta[64 + id] = NN; team_meta[128 + id] = u; team_meta[256 + id] = first; }
+    }
+    wg_pass_b<2, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, 2 * A + 1, wave_scr, TW, team_meta);
+    TREE_STAMP(X, 7);
+    cutils_rows_orders(X, d, P, b, ct, have_c, gl, scr_c, node_base, levels, max_dist);
+    if (wave * 4 < A) upstream_rows<16, CAP>(X, P, b, u, have_u, tl, scr_u);
+    team_sync();
+    TREE_STAMP(X, 16);
 }
 
 // One observation build for the workgroup's env.  STAGE 0: stand-alone; the fused launch (both builders) runs STAGE 1
@@ -975,6 +1240,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint16_t *a_target = LDS_AT(uint16_t, L_A_TARGET);
     uint16_t *a_malf = LDS_AT(uint16_t, L_A_MALF);
     uint16_t *a_tpc = LDS_AT(uint16_t, L_A_TPC);
+    double *a_tq = LDS_AT(double, L_A_TQ);
     uint16_t *a_lp = LDS_AT(uint16_t, L_A_LP);
     uint16_t *a_n = LDS_AT(uint16_t, L_A_N);  // waypoints of the agent's predicted path
     uint8_t *a_dir = LDS_AT(uint8_t, L_A_DIR);
@@ -994,9 +1260,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
     int *csr2 = LDS_OPT(int, L_CSR2);
     unsigned long long *tmaskb = LDS_OPT(unsigned long long, L_TMASKB);
+    unsigned long long *tmask_m2 = LDS_OPT(unsigned long long, L_TMASK2), *tmaskb_m2 = LDS_OPT(unsigned long long, L_TMASKB2);  // own-path filter
     uint32_t *items2 = LDS_OPT(uint32_t, L_ITEMS2);
     uint16_t *a_lp2 = LDS_OPT(uint16_t, L_A_LP2);
     uint16_t *a_tpc2 = LDS_OPT(uint16_t, L_A_TPC2);
+    double *a_tq2 = LDS_OPT(double, L_A_TQ2);
     // static tables of the env: LDS copies (TAB_LDS) or HBM
     uint4 *seg_lds = TAB_LDS ? LDS_AT(uint4, L_SEG) : nullptr;
     uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
@@ -1016,6 +1284,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (tid < 64 && STAGE != 2) P.dbg[(size_t)b * 64 + tid] = 0;
     __syncthreads();
 #endif
+    if (STAGE == 2 && P.merged && misc[5]) {  // stage 1 built the upstream trees too (trees_merged)
+#ifdef FL_OBS_TIMING
+        if (tid == 0) { const long long now_ = (long long)wall_clock64(); for (int k = 32; k <= 37; k++) P.dbg[(size_t)b * 64 + k] = now_; }
+#endif
+        return;
+    }
     OBS_STAMP(0);
 
     const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
@@ -1074,7 +1348,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             a_tslot[i] = (uint16_t)d.tslot[g];
             a_target[i] = (uint16_t)target_r;
             a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
-            if (CUTILS && STAGE == 1 && P.dual_index) a_tpc2[i] = (uint16_t)(int)(1.0 / speed);  // the upstream predictor's (predictions.py:139)
+            a_tq[i] = CUTILS ? (double)(float)(1.0 / (double)(float)speed) : 1.0 / speed;
+            if (CUTILS && STAGE == 1 && P.dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
         }
         __syncthreads();
         // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
@@ -1101,7 +1376,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
     } else {
         // second stage: only the predictor's times-per-cell differ (int(np.reciprocal(speed)), predictions.py:139)
-        for (int i = tid; i < A; i += nt) a_tpc[i] = (uint16_t)(int)(1.0 / a_speed[i]);
+        for (int i = tid; i < A; i += nt) { a_tpc[i] = (uint16_t)(int)(1.0 / a_speed[i]); a_tq[i] = 1.0 / a_speed[i]; }
     }
     __syncthreads();
 
@@ -1114,7 +1389,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.dbg = P.dbg ? P.dbg + (size_t)b * 64 : nullptr;
     X.dbg_base = STAGE == 2 ? 32 : 0;
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
-    X.a_tpc = a_tpc; X.a_tslot = a_tslot; X.a_target = a_target;
+    X.a_tpc = a_tpc; X.a_tq = a_tq; X.a_tslot = a_tslot; X.a_target = a_target;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
@@ -1126,11 +1401,20 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
     X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = min(t >> tshift, 63)
+    // one pass B over the trees of both builders (stage 1 of the fused launch): the upstream builder's side of the context
+    const bool merged = CUTILS && STAGE == 1 && P.merged != 0;
+    X.n_cu = A + 1;
+    X.u_csr_end = csr2; X.u_items = items2; X.u_tmask = tmaskb; X.a_tq2 = a_tq2;
+    X.tmask_m2 = merged ? tmask_m2 : nullptr; X.u_tmask_m2 = tmaskb_m2;
+    X.path = S.path + (size_t)b * A * S.pred_cap; X.pred_cap = S.pred_cap;
+    X.a_lp = a_lp; X.a_lp2 = a_lp2; X.a_tpc2 = a_tpc2;
+    X.u_Tn = P.tree_pred + 1; X.u_tshift = X.u_Tn <= 64 ? 0 : P.tshift;
 
     OBS_STAMP(1);
-    // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  ONE wavefront does all of it (wave-level
-    // synchronisation only), so it can run beside the path walkers of phase 2, which occupy the first wavefronts.
-    auto phase1 = [&]() __attribute__((always_inline)) {
+    // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  The deadlock check is the work of ONE
+    // wavefront (wave-level synchronisation only) and runs beside the path walkers of phase 2; the per-agent rest is spread
+    // over all wavefronts (phase1b).
+    auto phase1a = [&]() __attribute__((always_inline)) {
         // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
         // its exits leads to an empty cell or to a free, not yet deadlocked agent (or it has no exit at all);
         // every other active agent becomes (and stays) deadlocked.  Equivalent to the reference's DFS + _fix_deps.
@@ -1169,99 +1453,110 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             team_sync();
             if (!__any(changed)) break;
         }
-        for (int i = lane; i < A; i += 64) {
+        for (int i = lane; i < A; i += 64) {  // commit the new deadlocks; the deadlock flag of the attribute row and of props
             const int g = b * A + i;
-            const uint32_t state = a_state[i];
-            if (is_on_map(state) && !a_dead[i] && !a_free[i]) {
+            if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
                 a_dead[i] = 1;
                 d.pk[g] |= (1u << 18);
             }
-            const uint32_t pk = d.pk[g], spk = d.spk[g];
-            const int pos = a_pos[i];
-            const uint32_t dir = a_dir[i];
-            const uint32_t scount = PK_SCOUNT(pk), max_count = SPK_MAX_COUNT(spk), init_dir = SPK_INIT_DIR(spk);
-            const uint32_t old_dir = PK_OLD_DIR(pk) == 4 ? dir : PK_OLD_DIR(pk);
-            // update_dist_target (loader.cpp:163-179)
-            const int dmb = a_tslot[i] * X.SS;
-            const uint16_t dv_init = X.dm[dmb + (int)d.init_r[g] * 4 + (int)init_dir];
-            const float init_dist = dv_init == FL_INF16 ? INFINITY : (float)dv_init;
-            float dist_target;
-            if (state == ST_DONE) dist_target = 0;
-            else if (is_off_map(state)) dist_target = init_dist;
-            else {
-                const uint16_t dv = X.dm[dmb + pos * 4 + (int)dir];
-                dist_target = dv == FL_INF16 ? INFINITY : (float)dv;
-            }
-            // valid-action mask (loader.cpp:273-312)
-            uint32_t va = 0;
-            const uint32_t cell = pos >= 0 ? cw_bits(X, pos) : 0;
-            if (state == ST_MOVING || state == ST_STOPPED) {
-                if (scount == 0) {
-                    const uint32_t bits = nibble(cell, dir);
-                    int cnt = 0;
-                    bool has_branch = false;
-                    for (uint32_t a = ACT_LEFT; a <= ACT_RIGHT; a++) {
-                        const uint32_t nd = (dir + a + 2u) & 3u;
-                        if ((bits >> (3 - nd)) & 1) {
-                            va |= 1u << a;
-                            cnt++;
-                            const uint32_t nr = nbr[pos * 4 + (int)nd];
-                            if (nr != FL_R_NONE && __popc(cw_bits(X, (int)nr)) > 2) has_branch = true;
-                        }
-                    }
-                    if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
-                } else va |= 1u << ACT_NOTHING;
-            } else if (state == ST_READY) va = (1u << ACT_FORWARD) | (1u << ACT_STOP);
-            else va = 1u << ACT_NOTHING;
-            uint8_t *vout = P.valid + (size_t)g * 5;
-            for (int a = 0; a < 5; a++) vout[a] = (va >> a) & 1;
-            if (P.props) {
-                P.props[(size_t)g * 3 + 0] = (double)dist_target;
-                P.props[(size_t)g * 3 + 1] = (double)a_dead[i];
-                P.props[(size_t)g * 3 + 2] = (double)(state == ST_READY);
-            }
-            // AgentAttrParser::get_features (feature_parser.cpp:3-98)
-            float *o = P.attr + (size_t)g * FL_CUTILS_ATTR;
-            int n = 0;
-            const int road_type = pos >= 0 ? (int)d.rtype[(size_t)b * Rcap + pos] : 0;  // static per rail cell (fl_host.hip)
-            const uint32_t malfw = d.malf[g];
-            const int malf01 = (malfw & 0xFFFFu) != 0, nmalf01 = (malfw >> 16) != 0;
-            for (int k = 0; k < 7; k++) o[n++] = (k == (int)state) ? 1.0f : 0.0f;
-            for (int k = 0; k < 11; k++) o[n++] = (k == road_type) ? 1.0f : 0.0f;
-            for (int k = 0; k < 10; k++) o[n++] = (k == nmalf01) ? 1.0f : 0.0f;
-            for (int k = 0; k < 4; k++) o[n++] = (k == (int)init_dir) ? 1.0f : 0.0f;
-            for (int k = 0; k < 4; k++) o[n++] = (k == (int)dir) ? 1.0f : 0.0f;
-            for (int k = 0; k < 4; k++) o[n++] = (k == (int)old_dir) ? 1.0f : 0.0f;
-            o[n++] = (float)(state == ST_MOVING);
-            o[n++] = (float)a_dead[i];
-            o[n++] = (float)PK_SIGMALF(pk);
-            o[n++] = (float)(!malf01);
-            o[n++] = (float)(scount == 0);
-            o[n++] = (float)(scount == max_count);
-            o[n++] = (float)(state == ST_MALF || state == ST_MALF_OFF);
-            o[n++] = (float)is_off_map(state);
-            o[n++] = (float)is_on_map(state);
-            for (int k = 15; k >= 0; k--) o[n++] = (float)((cell >> k) & 1u);
-            for (int a = 0; a < 5; a++) o[n++] = (float)((va >> a) & 1u);
-            const float max_t = (float)T, max_dist_target = (float)((d.H + d.W) * 8);
-            const float f_step = (float)tnow / max_t;
-            const float f_latest = (float)d.latest[g] / max_t;
-            const float f_before = f_latest - f_step;
-            const float f_dist = isinf(dist_target) ? 8.0f : dist_target / max_dist_target;
-            o[n++] = (float)i / (float)A;
-            o[n++] = f_step;
-            o[n++] = (float)d.earliest[g] / max_t;
-            o[n++] = f_latest;
-            o[n++] = (float)d.arrival[g] / max_t;
-            o[n++] = f_before;
-            o[n++] = f_dist;
-            o[n++] = f_before < f_dist ? f_before : f_dist;
-            o[n++] = (float)max_count / 10;
-            o[n++] = (float)a_speed[i] / 1.0f;
-            o[n++] = (float)scount / 10;
-            o[n++] = (float)malf01 / 10;
-            o[n++] = isinf(init_dist) ? 8.0f : init_dist / max_dist_target;
+            P.attr[(size_t)g * FL_CUTILS_ATTR + 41] = (float)a_dead[i];
+            if (P.props) P.props[(size_t)g * 3 + 1] = (double)a_dead[i];
         }
+    };
+    // Rest of phase 1, per agent: valid actions, props, attribute row (everything but the deadlock flag).  A team of 32
+    // lanes per agent: every lane derives the agent's scalars (broadcast loads) and writes elements gl, gl + 32, gl + 64 of
+    // the row, so it can run on any wavefront beside the deadlock check.
+    // what phase1b reads from HBM: requested ahead of the hoisted pass A so that the two latencies overlap
+    struct AgentRaw { uint32_t pk, spk, malfw; int latest, earliest, arrival, init_r, road_type; };
+    auto phase1b_load = [&](int i) __attribute__((always_inline)) {
+        const int g = b * A + i, pos = a_pos[i];
+        AgentRaw r;
+        r.pk = d.pk[g]; r.spk = d.spk[g]; r.malfw = d.malf[g];
+        r.latest = d.latest[g]; r.earliest = d.earliest[g]; r.arrival = d.arrival[g];
+        r.init_r = d.init_r[g];
+        r.road_type = pos >= 0 ? (int)d.rtype[(size_t)b * Rcap + pos] : 0;  // static per rail cell (fl_host.hip)
+        return r;
+    };
+    auto phase1b = [&](int i, int gl, const AgentRaw &raw) __attribute__((always_inline)) {
+        const int g = b * A + i;
+        const uint32_t state = a_state[i];
+        const uint32_t pk = raw.pk, spk = raw.spk;
+        const int pos = a_pos[i];
+        const uint32_t dir = a_dir[i];
+        const uint32_t scount = PK_SCOUNT(pk), max_count = SPK_MAX_COUNT(spk), init_dir = SPK_INIT_DIR(spk);
+        const uint32_t old_dir = PK_OLD_DIR(pk) == 4 ? dir : PK_OLD_DIR(pk);
+        // update_dist_target (loader.cpp:163-179)
+        const int dmb = a_tslot[i] * X.SS;
+        const uint16_t dv_init = X.dm[dmb + raw.init_r * 4 + (int)init_dir];
+        const float init_dist = dv_init == FL_INF16 ? INFINITY : (float)dv_init;
+        float dist_target;
+        if (state == ST_DONE) dist_target = 0;
+        else if (is_off_map(state)) dist_target = init_dist;
+        else {
+            const uint16_t dv = X.dm[dmb + pos * 4 + (int)dir];
+            dist_target = dv == FL_INF16 ? INFINITY : (float)dv;
+        }
+        // valid-action mask (loader.cpp:273-312)
+        uint32_t va = 0;
+        const uint32_t cell = pos >= 0 ? cw_bits(X, pos) : 0;
+        if (state == ST_MOVING || state == ST_STOPPED) {
+            if (scount == 0) {
+                const uint32_t bits = nibble(cell, dir);
+                int cnt = 0;
+                bool has_branch = false;
+                for (uint32_t a = ACT_LEFT; a <= ACT_RIGHT; a++) {
+                    const uint32_t nd = (dir + a + 2u) & 3u;
+                    if ((bits >> (3 - nd)) & 1) {
+                        va |= 1u << a;
+                        cnt++;
+                        const uint32_t nr = nbr[pos * 4 + (int)nd];
+                        if (nr != FL_R_NONE && __popc(cw_bits(X, (int)nr)) > 2) has_branch = true;
+                    }
+                }
+                if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
+            } else va |= 1u << ACT_NOTHING;
+        } else if (state == ST_READY) va = (1u << ACT_FORWARD) | (1u << ACT_STOP);
+        else va = 1u << ACT_NOTHING;
+        if (gl < 5) P.valid[(size_t)g * 5 + gl] = (va >> gl) & 1;
+        if (P.props && gl == 5) {
+            P.props[(size_t)g * 3 + 0] = (double)dist_target;
+            P.props[(size_t)g * 3 + 2] = (double)(state == ST_READY);
+        }
+        // AgentAttrParser::get_features (feature_parser.cpp:3-98): elements 0 .. 69 are 0 / 1 -- bit j of (m_lo, m_hi)
+        const int road_type = raw.road_type;
+        const uint32_t malfw = raw.malfw;
+        const uint32_t malf01 = (malfw & 0xFFFFu) != 0, nmalf01 = (malfw >> 16) != 0;
+        const uint32_t rev = __brev(cell) >> 16;  // element 49 + k = bit 15 - k of the rail word
+        unsigned long long m_lo = (state < 7u ? 1ull << state : 0ull) | (road_type < 11 ? 1ull << (7 + road_type) : 0ull) | (1ull << (18 + nmalf01)) |
+                                  (1ull << (28 + init_dir)) | (1ull << (32 + dir)) | (1ull << (36 + old_dir)) |
+                                  ((unsigned long long)(state == ST_MOVING) << 40) | ((unsigned long long)PK_SIGMALF(pk) << 42) |
+                                  ((unsigned long long)(!malf01) << 43) | ((unsigned long long)(scount == 0) << 44) |
+                                  ((unsigned long long)(scount == max_count) << 45) | ((unsigned long long)(state == ST_MALF || state == ST_MALF_OFF) << 46) |
+                                  ((unsigned long long)is_off_map(state) << 47) | ((unsigned long long)is_on_map(state) << 48) |
+                                  ((unsigned long long)(rev & 0x7FFFu) << 49);
+        const uint32_t m_hi = (rev >> 15) | (va << 1);
+        // elements 70 .. 82
+        const float max_t = (float)T, max_dist_target = (float)((d.H + d.W) * 8);
+        const float f_step = (float)tnow / max_t;
+        const float f_latest = (float)raw.latest / max_t;
+        const float f_before = f_latest - f_step;
+        const float f_dist = isinf(dist_target) ? 8.0f : dist_target / max_dist_target;
+        const float fv[13] = {(float)i / (float)A, f_step, (float)raw.earliest / max_t, f_latest, (float)raw.arrival / max_t, f_before, f_dist,
+                              f_before < f_dist ? f_before : f_dist, (float)max_count / 10, (float)a_speed[i] / 1.0f, (float)scount / 10,
+                              (float)malf01 / 10, isinf(init_dist) ? 8.0f : init_dist / max_dist_target};
+        float *o = P.attr + (size_t)g * FL_CUTILS_ATTR;
+        o[gl] = (float)((m_lo >> gl) & 1ull);
+        if (gl + 32 != 41) o[gl + 32] = (float)((m_lo >> (gl + 32)) & 1ull);  // element 41: the deadlock flag (phase 1a)
+        if (gl + 64 < FL_CUTILS_ATTR) {
+            float v = (float)((m_hi >> gl) & 1u);
+#pragma unroll
+            for (int k = 0; k < 13; k++) v = gl == 6 + k ? fv[k] : v;
+            o[gl + 64] = v;
+        }
+    };
+    // all agents of the env, one team of 32 lanes each
+    auto phase1b_all = [&]() __attribute__((always_inline)) {
+        for (int i = wave * 2 + (lane >> 5); i < A; i += 2 * (nt >> 6)) phase1b(i, lane & 31, phase1b_load(i));
     };
 
     // eight walker lanes per agent, on at least four wavefronts (consecutive wavefronts of a workgroup land on different
@@ -1271,7 +1566,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(4, (A + 7) / 8)) : 0;
     const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
-        if (wave == 0) phase1();
+        if (wave == 0) phase1a();
+        phase1b_all();
         __syncthreads();
     }
     OBS_STAMP(2);
@@ -1288,10 +1584,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         uint32_t *bkc = reinterpret_cast<uint32_t *>(wave_scr);
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
-            if (X.tmask) for (int k = tid; k <= K; k += nt) tmask[k] = 0ull;
+            if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
             if (bk) for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) bkc[k] = 0u;
         }
-        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; }
+        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
@@ -1300,7 +1596,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // of the first round of cutils trees for its two agents -- none of that needs the prediction index.
         const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
         if (do_p1 && p1_beside_walk && wave == w_first - 1) {
-            phase1();
+            phase1a();
 #ifdef FL_OBS_TIMING
             if (lane == 0) atomicMax((unsigned long long *)&X.dbg[20], (unsigned long long)wall_clock64());
 #endif
@@ -1369,12 +1665,43 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (wsel >= 0 && lane == 0) atomicMax((unsigned long long *)&X.dbg[21], (unsigned long long)wall_clock64());
 #endif
-        if (CUTILS && !bk) {
+        {
             const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
-            int node_base, levels;
-            cutils_pass_a(X, d, P, b, team_id, team_id < A, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32),
-                          a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T, node_base, levels);
-            if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
+#ifdef FL_OBS_TIMING
+            const long long t_pa0 = (long long)wall_clock64();
+#endif
+            if (CUTILS && !bk) {  // pass A of the team's first tree
+                int node_base, levels;
+                const bool have = team_id < A;
+                cutils_pass_a(X, d, P, b, team_id, have, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32),
+                              a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
+                              d.spk[b * A + (have ? team_id : 0)], d.malf[b * A + (have ? team_id : 0)], node_base, levels);
+                if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
+            }
+#ifdef FL_OBS_TIMING
+            if (lane == 0) {
+                atomicMax((unsigned long long *)&X.dbg[19], (unsigned long long)wall_clock64());
+                atomicMax((unsigned long long *)&X.dbg[23], (unsigned long long)((long long)wall_clock64() - t_pa0));
+                if (wave == 0) X.dbg[27] = (long long)wall_clock64() - t_pa0;  // wavefront 0 alone
+            }
+#endif
+            // The wavefronts are done with their roles at very different times (no tree to build, a short walk, a deep
+            // tree): what is left of this phase is a queue of jobs that whoever is free takes -- the rest of phase 1, two agents a job
+            // (longest first: pass A of four upstream trees when both builders share one pass B, see trees_merged)
+            const int n_up = merged ? (A + 3) / 4 : 0, n_p1 = (do_p1 && p1_beside_walk) ? (A + 1) / 2 : 0;
+            while (n_up + n_p1 > 0) {
+                int j = 0;
+                if (lane == 0) j = atomicAdd(&misc[6], 1);
+                j = __builtin_amdgcn_readfirstlane(j);
+                if (j >= n_up + n_p1) break;
+                if (j < n_up) {
+                    const int u = 4 * j + (lane >> 4);
+                    upstream_pass_a<16, 32>(X, P, b, u, u < A, lane & 15, wave_scr + (u < A ? merged_slot_upstream(A, u) : A) * (F_WORDS * 32));
+                } else {
+                    const int i = 2 * (j - n_up) + grp;
+                    if (i < A) phase1b(i, gl, phase1b_load(i));
+                }
+            }
         }
 #ifdef FL_OBS_TIMING
         if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
@@ -1480,9 +1807,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             __syncthreads();
         }
-        const bool fit = items_lds != nullptr && misc[2] <= OBS_ITEMS_LDS_CAP;
-        const bool dual_fill = dual && misc[3] <= OBS_ITEMS2_CAP;
+        const bool fit = items_lds != nullptr && misc[2] <= L.items_cap;
+        const bool dual_fill = dual && misc[3] <= L.items2_cap;
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
+        if (merged && tid == 0) misc[5] = (fit && dual_fill) ? 1 : 0;  // else: the two stages as usual
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
@@ -1506,7 +1834,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const int key = key_of(X, (int)(w >> 2));
                 if (X.tmask) {  // time buckets this item covers
                     const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
-                    atomicOr(&tmask[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
+                    const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
+                    const unsigned long long seen = atomicOr(&tmask[key], bits);
+                    if (X.tmask_m2 && (seen & bits)) atomicOr(&tmask_m2[key], seen & bits);  // covered by a second item
                 }
                 const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                       ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
@@ -1528,7 +1858,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const uint32_t dnext2 = k < lp2 ? dnext : (w & 3u);
                     if (P.use_tmask) {
                         const int b1 = min(tlo2 >> tshift2, 63), b2 = min((to_end2 ? tlast2 : tlo2 + tpc2 - 1) >> tshift2, 63);
-                        atomicOr(&tmaskb[key], ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull));
+                        const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
+                        const unsigned long long seen = atomicOr(&tmaskb[key], bits);
+                        if (X.tmask_m2 && (seen & bits)) atomicOr(&tmaskb_m2[key], seen & bits);
                     }
                     const int slot2 = atomicAdd(&csr2[key], 1);
                     items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
@@ -1553,7 +1885,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const float max_dist = (float)T;
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
-    if (CUTILS) {
+    if (merged && items_in_lds && misc[5]) {  // (misc[5] was written before the barriers of the index build)
+        trees_merged<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, max_dist);
+    } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
     } else if (P.max_depth <= 2) {
@@ -1623,23 +1957,29 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     if (d.rkey) put(L_RKEY, R * 2);
     put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
     put(L_CELL_TARGET, ((R + 31) / 32) * 4);
-    put(L_A_SPEED, A * 8);
+    put(L_A_SPEED, A * 8); put(L_A_TQ, A * 8);
     put(L_A_VPOS, A * 2); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 2); put(L_A_TARGET, A * 2);
     put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2);
     put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
-    put(L_MISC, 64 * 4); put(L_TEAM_META, 256 * 4);
-    put(L_WAVE_SCR, (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4);
+    put(L_MISC, 64 * 4); put(L_TEAM_META, 320 * 4);
+    if (P.merged) put(L_WAVE_SCR, (size_t)(2 * d.A + 1) * (F_WORDS * 32) * 4);  // trees_merged: a slot per tree of either builder + the dummy
+    else put(L_WAVE_SCR, (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4);
     put(L_CSR, K1 * 4);
-    if (o.items) put(L_ITEMS, (size_t)OBS_ITEMS_LDS_CAP * 4);
+    // one pass B for both builders needs the room for twice the node tables: a tighter first-index copy (128 waypoints an agent)
+    L.items_cap = P.merged ? (int)std::min<size_t>(OBS_ITEMS_LDS_CAP, std::max<size_t>(1024, A * 128)) : OBS_ITEMS_LDS_CAP;
+    L.items2_cap = (int)std::min<size_t>(OBS_ITEMS2_CAP, A * (size_t)(P.tree_pred + 2));  // an agent has at most tree_pred + 1 of them
+    if (o.items) put(L_ITEMS, (size_t)L.items_cap * 4);
     if (o.wl_bytes) put(L_WL, (size_t)o.wl_bytes);       // 0: the work lists live in HBM scratch
     if (o.partial || !o.wl_bytes) put(L_PARTIAL, (size_t)o.nt * 4);
     if (o.tmask) put(L_TMASK, K1 * 8);
+    if (o.tmask && P.merged) put(L_TMASK2, K1 * 8);
     if (o.nh || o.tab) put(L_NH, U * R * 2);
     if (o.dual) {
         put(L_CSR2, K1 * 4);
         if (o.tmask) put(L_TMASKB, K1 * 8);
-        put(L_ITEMS2, (size_t)OBS_ITEMS2_CAP * 4);
-        put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2);
+        if (o.tmask && P.merged) put(L_TMASKB2, K1 * 8);
+        put(L_ITEMS2, (size_t)std::max(L.items2_cap, 4) * 4);
+        put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2); put(L_A_TQ2, A * 8);
     }
     if (o.tab) { put(L_SEG, NS * 16); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
     L.total = (unsigned)off;
@@ -1679,6 +2019,29 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // difference in time (their gathers hit L2 and hide behind the rest) but replace narrow HBM gathers with one coalesced read.
     ObsOptions o;
     o.tab = 0;
+    // Small envs, both builders: one pass B over the trees of both (trees_merged).  It needs a wavefront per two agents, the
+    // second index, the items and the time masks in LDS, the successor table and keys = rail indices (the fast classify loop).
+    static const bool no_merge = getenv("FL_OBS_NO_MERGE") != nullptr;
+    P.merged = 0;
+    if (!no_merge && dual_ok && P.max_depth <= 2 && d.A <= 31 && d.rkey == nullptr && (!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT) &&
+        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.items, 1) && ok(force.snext, 1) && force.tab != 1) {
+        P.merged = 1;
+        o.nt = OBS_NT; o.tmask = 1; o.dual = 1; o.items = 1; o.snext = 1; o.partial = 1;
+        for (int wk = 0; wk < 2 && P.merged; wk++) {
+            o.wl_bytes = wk == 0 ? 24 * 1024 : 16 * 1024;
+            if (!ok(force.wl, o.wl_bytes)) continue;
+            for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
+                if (!ok(force.nh, o.nh)) continue;
+                const ObsLayout L = obs_layout(d, P, o);
+                if (L.total > lds_limit) continue;
+                P.L = L; P.use_tmask = 1; P.dual_index = 1; P.bk = 0;
+                static const int force_tshift_m = getenv("FL_OBS_TSHIFT") ? atoi(getenv("FL_OBS_TSHIFT")) : -1;
+                P.tshift = force_tshift_m >= 0 ? force_tshift_m : OBS_TSHIFT;
+                return true;
+            }
+        }
+        P.merged = 0;
+    }
     for (int k = 0; k < 3; k++) {
         o.nt = nts[k];
         if ((force_nt && o.nt != force_nt) || !ok(force.nt, o.nt)) continue;
@@ -1727,8 +2090,8 @@ static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const
     const ObsLayout &L = P.L;
     if (verbose && printed < 4) {
         printed++;
-        fprintf(stderr, "[fl_obs] %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d\n",
-                L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT);
+        fprintf(stderr, "[fl_obs] %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d, one pass B for both builders %d\n",
+                L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT, P.merged);
     }
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(d.B), dim3(L.nt), L.total, s, d, o, P);

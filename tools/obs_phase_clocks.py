@@ -45,19 +45,41 @@ def dur(k):
     return (c[:, :, k] / 100.0).mean()
 
 
-print("%s, upstream depth %d: on-map agents %.1f of %d" % (workload, depth, (env.state()[0][:, :, 0] >= 0).sum(1).mean(), env.A))
-print("stage 1 (cutils):")
-print("  p0 stage %.1f  p1 %.1f  p2a walk|phase1|passA + count %.1f  p2b scan/fill %.1f" % (seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4)))
-print("     since p2a start: phase-1 wavefront done %.1f, walkers done %.1f, hoisted pass A done %.1f" % (seg(2, 20), seg(2, 21), seg(2, 22)))
-print("  trees (sum over rounds): passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f  orders %.1f   stage total %.1f" %
-      (dur(6), dur(11), dur(7), dur(8), dur(16), seg(0, 5)))
-print("stage 2 (upstream tree):")
-print("  prep %.1f  count %.1f  scan/fill %.1f" % (seg(32, 34), seg(34, 35), seg(35, 36)))
-print("  trees: passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f   stage total %.1f" % (dur(38), dur(43), dur(39), dur(40), seg(32, 37)))
-print("kernel total %.1f us (slowest env %.1f)" % (seg(0, 37), ((c[:, :, 37] - c[:, :, 0]) / 100.0).max(1).mean()))
-pb = c[:, :, 25].astype(np.uint64)
-print("pass B (max over rounds / stages): slowest-lane loop %.1f us, cells/lane %.1f, cells per round %.0f; slowest-lane setup %.1f us (skipped %.1f cells)" %
-      (((pb >> np.uint64(40)).astype(np.float64) / 100.0).mean(), ((pb >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(np.float64).mean(),
-       c[:, :, 26].mean(), (c[:, :, 24] / 100.0).mean(), (pb & np.uint64(0xFFFFF)).astype(np.float64).mean()))
-print("work-list entries (sum over rounds): occupant %.0f / %.0f, conflict %.0f / %.0f  (cutils / upstream)" %
-      (c[:, :, 9].mean(), c[:, :, 41].mean(), c[:, :, 10].mean(), c[:, :, 42].mean()))
+def report():
+
+    print("%s, upstream depth %d: on-map agents %.1f of %d" % (workload, depth, (env.state()[0][:, :, 0] >= 0).sum(1).mean(), env.A))
+    print("stage 1 (cutils):")
+    print("  p0 stage %.1f  p1 %.1f  p2a walk|phase1|passA + count %.1f  p2b scan/fill %.1f" % (seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4)))
+    print("     since p2a start: deadlock wavefront done %.1f, walkers done %.1f, hoisted pass A done %.1f, rest of phase 1 done %.1f" % (seg(2, 20), seg(2, 21), seg(2, 19), seg(2, 22)))
+    print("     hoisted pass A alone: slowest wavefront %.1f, wavefront 0 %.1f" % (dur(23), dur(27)))
+    print("  trees (sum over rounds): passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f  orders %.1f   stage total %.1f" %
+          (dur(6), dur(11), dur(7), dur(8), dur(16), seg(0, 5)))
+    print("stage 2 (upstream tree):")
+    print("  prep %.1f  count %.1f  scan/fill %.1f" % (seg(32, 34), seg(34, 35), seg(35, 36)))
+    print("  trees: passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f   stage total %.1f" % (dur(38), dur(43), dur(39), dur(40), seg(32, 37)))
+    print("kernel total %.1f us (slowest env %.1f)" % (seg(0, 37), ((c[:, :, 37] - c[:, :, 0]) / 100.0).max(1).mean()))
+    pb = c[:, :, 25].astype(np.uint64)
+    print("pass B (max over rounds / stages): slowest-lane loop %.1f us, cells/lane %.1f, cells per round %.0f; slowest-lane setup %.1f us (skipped %.1f cells)" %
+          (((pb >> np.uint64(40)).astype(np.float64) / 100.0).mean(), ((pb >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(np.float64).mean(),
+           c[:, :, 26].mean(), (c[:, :, 24] / 100.0).mean(), (pb & np.uint64(0xFFFFF)).astype(np.float64).mean()))
+    def rel(k, k0):  # absolute 40-bit marks of the timing build
+        return ((c[:, :, k] - c[:, :, k0]) / 100.0).mean()
+
+    def rel_min(k, k0):
+        return (((1 << 40) - c[:, :, k] - c[:, :, k0]) / 100.0).mean()
+
+    print("work-list step, since its start (cutils | upstream): occupants done %.1f | %.1f, first scan done: earliest wavefront %.1f | %.1f, latest %.1f | %.1f, after the barrier %.1f | %.1f" %
+          (rel(12, 18), rel(44, 50), rel_min(17, 18), rel_min(49, 50), rel(13, 18), rel(45, 50), rel(14, 18), rel(46, 50)))
+    print("conflict entries (cutils | upstream): items in their lists %.0f | %.0f, queried beyond the fine buckets %.0f | %.0f, somebody else there %.0f | %.0f, conflicts %.0f | %.0f, only the walking agent itself there %.0f | %.0f" %
+          (c[:, :, 27].mean(), c[:, :, 59].mean(), c[:, :, 28].mean(), c[:, :, 60].mean(), c[:, :, 29].mean(), c[:, :, 61].mean(), c[:, :, 30].mean(), c[:, :, 62].mean(), c[:, :, 31].mean(), c[:, :, 63].mean()))
+    print("work-list entries (sum over rounds): occupant %.0f / %.0f, conflict %.0f / %.0f  (cutils / upstream)" %
+          (c[:, :, 9].mean(), c[:, :, 41].mean(), c[:, :, 10].mean(), c[:, :, 42].mean()))
+
+
+report()
+# the same for the slowest env of every step (it sets the launch time)
+full = c
+slow = ((full[:, :, 37] - full[:, :, 0])).argmax(1)
+c = np.stack([full[t, slow[t]] for t in range(full.shape[0])])[:, None, :]
+print("---- slowest env of each step:")
+report()
