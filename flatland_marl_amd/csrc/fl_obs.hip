@@ -274,37 +274,19 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
         if (a == handle && in) flags |= 64u;  // the walking agent itself is predicted there then
 #endif
     };
-    // The key's list is short and unsorted and nearly all of its items are about other times.  In lock step the full test
-    // would run for every item slot in which ANY lane has a match, so the scan takes two steps: a cheap interval test of all
-    // items (NB independent loads in flight) that leaves a bit mask of the matching ones, then the full test of only those
-    // (fetched again, two at a time).  Windows of 32 items; a slot past the end repeats the last item, which is harmless.
+    // the key's list is short and unsorted: scan it with NB independent loads in flight, most items fall out at the
+    // interval test (sorting the lists costs more than it saves; so did a separate pass that first collects the matching
+    // items of a chunk and then tests only those -- 1 to 2 % slower on every workload)
     auto scan = [&](const uint32_t *items, auto nb) __attribute__((always_inline)) {
         constexpr int NB = decltype(nb)::value;
-        for (int w0 = lo; w0 < hi; w0 += 32) {
-            const int wend = min(hi, w0 + 32);
-            uint32_t hits = 0;
-            for (int e0 = w0; e0 < wend; e0 += NB) {
-                uint32_t itv[NB];
+        for (int e0 = lo; e0 < hi; e0 += NB) {
+            uint32_t itv[NB];
 #pragma unroll
-                for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, wend - 1)];
+            for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, hi - 1)];
 #pragma unroll
-                for (int q = 0; q < NB; q++) {
-                    const uint32_t tl = IT_TLO(itv[q]), th = IT_THI(itv[q], tlast);
-                    hits |= (uint32_t)(th >= t1 && tl <= t2) << ((e0 - w0 + q) & 31);
-                }
-            }
-#ifdef FL_SCAN_ONE_STEP
-            for (int e0 = w0; e0 < wend; e0++) if ((hits >> (e0 - w0)) & 1u) test_item(items[e0]);
-            hits = 0;
-#endif
-            while (hits) {
-                const int q0 = __ffs((int)hits) - 1;
-                hits &= hits - 1u;
-                const int q1 = hits ? __ffs((int)hits) - 1 : q0;
-                hits &= hits - 1u;
-                const uint32_t it0 = items[min(w0 + q0, wend - 1)], it1 = items[min(w0 + q1, wend - 1)];
-                test_item(it0);
-                if (q1 != q0) test_item(it1);
+            for (int q = 0; q < NB; q++) {
+                const uint32_t tl = IT_TLO(itv[q]), th = IT_THI(itv[q], tlast);
+                if (e0 + q < hi && th >= t1 && tl <= t2) test_item(itv[q]);
             }
         }
     };
@@ -683,11 +665,11 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         occ_event<PB, CAP>(X, pb_cu<PB>(X, team), scr0 + team * team_words, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
     WAVE_MARK(X, 12, -1);
-    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone.  The first chunk is scanned
-    // right here, which settles a list of one chunk (nearly all of them).  A longer one: its entry becomes the FIRST entry,
-    // tot | chunks << 9 | flags << 15 (OR-ed together below) | node << 24, and pushes further entries chunk | index of the
-    // first entry << 6 (17 bits) | CF_MORE for the rest of its list; those are scanned after a barrier.
-    bool any_multi = false;
+    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes further
+    // entries for the rest of its list, and ALL chunks are scanned after a barrier, one per lane on densely packed wavefronts
+    // (scanning the first chunk right away measured 4 % slower on 80 agents, where many lists have several chunks).
+    // First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) | node << 24; the others: chunk | index of the
+    // first entry << 6 (17 bits) | CF_MORE.
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
         int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0, pt = 0;
@@ -703,23 +685,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             pt = pt_of<PB>(X, cu, handle, tot);
             list_range<PB>(X, cu, cell, pt, lo, hi);
             nch = max(min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
-            // the first chunk is scanned right here: every lane of the wavefront scans one
-            const uint32_t f = hi > lo ? conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo, min(hi, lo + CF_CHUNK)) : 0u;
-#ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down)
-            if (X.dbg) {
-                atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)(hi - lo));
-                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
-                if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
-                if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
-                if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
-            }
-#endif
-            if (nch == 1) {
-                if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(w.y >> 24)], tot);
-            } else {
-                X.wl_cf[e].y = w.y | ((uint32_t)nch << 9) | (f << 15);
-                any_multi = true;
-            }
+            X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
         }
         for (int j = 1; __any(j < nch); j++) {
             if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
@@ -729,32 +695,47 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             }
         }
     }
-    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
     WAVE_MARK(X, 13, 17);
     __syncthreads();
     WAVE_MARK(X, 14, -1);
-    if (X.wl_cnt[2]) {  // some keys have more than one chunk
-        const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
-        for (int e = tid; e < n_cf2; e += nt) {
-            const uint2 w = X.wl_cf[e];
-            if (!(w.y & CF_MORE)) continue;  // first chunks: done above
-            const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-            const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u);
-            const uint32_t fy = wl_flags(X, &X.wl_cf[first]);
-            const int tot = (int)(fy & 511u);
-            const int handle = team_meta[128 + team];
-            const bool cu = pb_cu<PB>(X, team);
-            const int pt = pt_of<PB>(X, cu, handle, tot);
-            int lo, hi;
-            list_range<PB>(X, cu, cell, pt, lo, hi);
-            const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
-            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
+    const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
+    bool any_multi = false;
+    for (int e = tid; e < n_cf2; e += nt) {
+        const uint2 w = X.wl_cf[e];
+        const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
+        const bool more = (w.y & CF_MORE) != 0;
+        const int first = more ? (int)((w.y >> 6) & 0x1FFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
+        const uint32_t fy = more ? wl_flags(X, &X.wl_cf[first]) : w.y;
+        const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
+        const int handle = team_meta[128 + team];
+        const bool cu = pb_cu<PB>(X, team);
+        const int pt = pt_of<PB>(X, cu, handle, tot);
+        int lo, hi;
+        list_range<PB>(X, cu, cell, pt, lo, hi);
+        const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
+#ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down)
+        if (X.dbg && !more) {
+            atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)(hi - lo));
+            if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+            if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
+            if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
+            if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
         }
-        __syncthreads();
-        for (int e = tid; e < n_cf2; e += nt) {  // the first entries have collected all flags
+#endif
+        if (nch == 1) {
+            if (conflict_hit(f)) atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(fy >> 24)], tot);
+        } else {
+            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
+            any_multi = true;
+        }
+    }
+    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
+    __syncthreads();
+    if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
+        for (int e = tid; e < n_cf2; e += nt) {
             uint2 w = X.wl_cf[e];
             w.y = wl_flags(X, &X.wl_cf[e]);
-            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 0u) continue;
+            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) atomicMin(&(scr0 + (int)(w.x >> 24) * team_words)[F_PC * CAP + (int)(w.y >> 24)], (int)(w.y & 511u));
         }
         __syncthreads();
@@ -818,7 +799,7 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
 
 // LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
 enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
-       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_TQ, L_A_TQ2, L_A_LP, L_A_N, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
+       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_TQ, L_A_TQ2, L_A_RAW, L_RTYPE, L_A_LP, L_A_N, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
        L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_TMASK2, L_NH, L_CSR2, L_TMASKB, L_TMASKB2, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
 #define L_ABSENT 0xFFFFFFFFu
 struct ObsLayout {
@@ -1171,7 +1152,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
 
 // Fused launch on a small env (at most 31 agents, upstream depth <= 2): the trees of BOTH builders go through ONE pass B.
 // Node-table slot = pass B team: 0 .. A-1 flatland_cutils trees (team of 32 lanes, wavefront w holds agents 2w, 2w + 1),
-// A the shared dummy, A + 1 + u the upstream tree of agent u (team of 16 lanes, wavefront w holds agents 4w .. 4w + 3).
+// A the shared dummy, A + 1 + u the upstream tree of agent u (team of 16 lanes, four trees a wavefront).
 // Pass A of all of them ran beside the path walk (obs_body).
 __device__ __forceinline__ int merged_slot_upstream(int A, int u) { return A + 1 + u; }
 
@@ -1184,7 +1165,9 @@ __device__ __forceinline__ void trees_merged(const ObsCtx &X, const FlDev &d, co
     const bool have_c = ct < A;
     int *scr_c = wave_scr + min(ct, A) * TW;
     const int node_base = have_c ? team_meta[64 + ct] : 1, levels = have_c ? team_meta[192 + ct] : 0;
-    const int u = wave * 4 + (lane >> 4), tl = lane & 15;
+    // (the upstream trees from the last wavefront down, the cutils trees from the first up: their rows are written side by side)
+    const int wu = nwaves - 1 - wave;
+    const int u = wu * 4 + (lane >> 4), tl = lane & 15;
     const bool have_u = u < A;
     int *scr_u = wave_scr + (have_u ? merged_slot_upstream(A, u) : A) * TW;
     TREE_STAMP(X, 6);
@@ -1194,7 +1177,7 @@ __device__ __forceinline__ void trees_merged(const ObsCtx &X, const FlDev &d, co
         if (have_c && gl == 0) { team_meta[ct] = cells; team_meta[64 + ct] = node_base; team_meta[128 + ct] = ct; team_meta[256 + ct] = first; }
         if (wave == 0 && lane == 0) { team_meta[A] = 0; team_meta[64 + A] = 1; team_meta[128 + A] = -1; team_meta[256 + A] = 0xFF; }
     }
-    if (wave * 4 < A) {  // wave-uniform
+    if (wu * 4 < A) {  // wave-uniform
         int first;
         const int cells = team_prepare<16, CAP>(have_u, tl, NN, scr_u, first);
         const int id = merged_slot_upstream(A, u);
@@ -1203,7 +1186,7 @@ __device__ __forceinline__ void trees_merged(const ObsCtx &X, const FlDev &d, co
     wg_pass_b<2, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, 2 * A + 1, wave_scr, TW, team_meta);
     TREE_STAMP(X, 7);
     cutils_rows_orders(X, d, P, b, ct, have_c, gl, scr_c, node_base, levels, max_dist);
-    if (wave * 4 < A) upstream_rows<16, CAP>(X, P, b, u, have_u, tl, scr_u);
+    if (wu * 4 < A) upstream_rows<16, CAP>(X, P, b, u, have_u, tl, scr_u);
     team_sync();
     TREE_STAMP(X, 16);
 }
@@ -1216,7 +1199,7 @@ __device__ __forceinline__ void trees_merged(const ObsCtx &X, const FlDev &d, co
 // the pass B work lists live in HBM scratch, which leaves the LDS to the time masks and lifts the cap on their entries.
 template <bool CUTILS, int VAR, int STAGE>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
-    constexpr bool TAB_LDS = VAR == 1, WL_HBM = VAR == 2;
+    constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
@@ -1265,6 +1248,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint16_t *a_lp2 = LDS_OPT(uint16_t, L_A_LP2);
     uint16_t *a_tpc2 = LDS_OPT(uint16_t, L_A_TPC2);
     double *a_tq2 = LDS_OPT(double, L_A_TQ2);
+    // what phase 1 and the root rows read per agent (pk, spk, malfunction word, latest, earliest, arrival, initial rail cell) and the
+    // road types of the rail cells: LDS copies when there is room (small envs), else HBM
+    uint32_t *a_raw = LDS_OPT(uint32_t, L_A_RAW);
+    uint8_t *rtype_lds = LDS_OPT(uint8_t, L_RTYPE);
     // static tables of the env: LDS copies (TAB_LDS) or HBM
     uint4 *seg_lds = TAB_LDS ? LDS_AT(uint4, L_SEG) : nullptr;
     uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
@@ -1325,6 +1312,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             if (nh_in_lds)
                 for (int c = tid; c < U * Rcap; c += nt) nh_lds[c] = gnh[c];
+            if (rtype_lds) {
+                const uint8_t *grt = d.rtype + (size_t)b * Rcap;
+                for (int r = tid; r < R; r += nt) rtype_lds[r] = grt[r];
+            }
         }
         for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
         for (int c = tid; c < (R + 31) / 32; c += nt) cell_target[c] = 0;
@@ -1343,7 +1334,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             a_dir[i] = (uint8_t)PK_DIR(pk);
             a_state[i] = (uint8_t)state;
             a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
-            a_malf[i] = (uint16_t)(d.malf[g] & 0xFFFFu);
+            const uint32_t malfw = d.malf[g];
+            a_malf[i] = (uint16_t)(malfw & 0xFFFFu);
+            if (a_raw) {
+                uint32_t *r8 = a_raw + i * 8;
+                r8[0] = pk; r8[1] = d.spk[g]; r8[2] = malfw; r8[3] = (uint32_t)d.latest[g]; r8[4] = (uint32_t)d.earliest[g];
+                r8[5] = (uint32_t)d.arrival[g]; r8[6] = (uint32_t)init_r;
+            }
             a_speed[i] = speed;
             a_tslot[i] = (uint16_t)d.tslot[g];
             a_target[i] = (uint16_t)target_r;
@@ -1471,10 +1468,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     auto phase1b_load = [&](int i) __attribute__((always_inline)) {
         const int g = b * A + i, pos = a_pos[i];
         AgentRaw r;
-        r.pk = d.pk[g]; r.spk = d.spk[g]; r.malfw = d.malf[g];
-        r.latest = d.latest[g]; r.earliest = d.earliest[g]; r.arrival = d.arrival[g];
-        r.init_r = d.init_r[g];
-        r.road_type = pos >= 0 ? (int)d.rtype[(size_t)b * Rcap + pos] : 0;  // static per rail cell (fl_host.hip)
+        if (a_raw) {
+            const uint32_t *r8 = a_raw + i * 8;
+            r.pk = r8[0]; r.spk = r8[1]; r.malfw = r8[2]; r.latest = (int)r8[3]; r.earliest = (int)r8[4]; r.arrival = (int)r8[5]; r.init_r = (int)r8[6];
+        } else {
+            r.pk = d.pk[g]; r.spk = d.spk[g]; r.malfw = d.malf[g];
+            r.latest = d.latest[g]; r.earliest = d.earliest[g]; r.arrival = d.arrival[g];
+            r.init_r = d.init_r[g];
+        }
+        // static per rail cell (fl_host.hip)
+        r.road_type = pos < 0 ? 0 : rtype_lds ? (int)rtype_lds[pos] : (int)d.rtype[(size_t)b * Rcap + pos];
         return r;
     };
     auto phase1b = [&](int i, int gl, const AgentRaw &raw) __attribute__((always_inline)) {
@@ -1563,7 +1566,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // SIMDs): a lone wavefront issues at the full rate of its SIMD
     const bool do_p1 = CUTILS && STAGE != 2;
     // (with hundreds of agents every wavefront would walk: one of them is kept back for phase 1, which then runs beside the walk)
-    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(4, (A + 7) / 8)) : 0;
+    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(2, (A + 7) / 8)) : 0;
     const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
         if (wave == 0) phase1a();
@@ -1629,12 +1632,21 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     }
                 }
             };
+            // waypoints that can be occupied within the horizon enter the per-key index: they are counted as they are recorded
+            // (bucketed lists count per bucket, below)
+            const int hz1 = bk ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
+            const int hz2 = dual ? max(0, min(P.tree_pred - 1, (Tn2 - 1) / (int)a_tpc2[ia])) : -1;
             auto walk8 = [&](const uint16_t *h8) __attribute__((always_inline)) {
                 int idx = j, last = -1;
                 while (__any(alive)) {
                     if (alive) {
                         path[idx] = (uint16_t)st;
                         last = idx;
+                        if (idx <= hz1) {
+                            const int key = key_of(X, (int)(st >> 2));
+                            atomicAdd(&csr[key], 1);
+                            if (idx <= hz2) atomicAdd(&csr2[key], 1);
+                        }
                         const uint32_t s8 = idx + 8 < n_max ? (uint32_t)h8[st] : (uint32_t)FL_R_NONE;
                         if (s8 == FL_R_NONE) alive = false;
                         else { st = s8; idx += 8; }
@@ -1675,7 +1687,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const bool have = team_id < A;
                 cutils_pass_a(X, d, P, b, team_id, have, grp, gl, wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (F_WORDS * 32),
                               a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
-                              d.spk[b * A + (have ? team_id : 0)], d.malf[b * A + (have ? team_id : 0)], node_base, levels);
+                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 1] : d.spk[b * A + (have ? team_id : 0)],
+                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 2] : d.malf[b * A + (have ? team_id : 0)], node_base, levels);
                 if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
             }
 #ifdef FL_OBS_TIMING
@@ -1706,13 +1719,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
 #endif
-        __syncthreads();
-        // waypoints per key: only those that can be occupied within the horizon enter the index
-        for (int i = wave; i < A; i += (nt >> 6)) {
-            const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
-            const int lp = a_lp[i];
-            const int lp2 = dual ? (int)a_lp2[i] : -1;
-            if (bk) {  // one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+        if (bk) {  // bucketed lists: one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+            __syncthreads();
+            for (int i = wave; i < A; i += (nt >> 6)) {
+                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const int lp = a_lp[i];
                 const int tpc = a_tpc[i], tlast = X.Tn - 1;
                 for (int k = lane; k <= lp; k += 64) {
                     const int key = key_of(X, (int)(path[k] >> 2));
@@ -1725,12 +1736,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     }
                     atomicAdd(&csr[key], b2 - b1 + 1);
                 }
-                continue;
-            }
-            for (int k = lane; k <= lp; k += 64) {
-                const int key = key_of(X, (int)(path[k] >> 2));
-                atomicAdd(&csr[key], 1);
-                if (k <= lp2) atomicAdd(&csr2[key], 1);
             }
         }
         } else if (!reuse) {
@@ -1835,8 +1840,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 if (X.tmask) {  // time buckets this item covers
                     const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
                     const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
-                    const unsigned long long seen = atomicOr(&tmask[key], bits);
-                    if (X.tmask_m2 && (seen & bits)) atomicOr(&tmask_m2[key], seen & bits);  // covered by a second item
+                    if (X.tmask_m2) {
+                        const unsigned long long seen = atomicOr(&tmask[key], bits);
+                        if (seen & bits) atomicOr(&tmask_m2[key], seen & bits);  // covered by a second item
+                    } else {
+                        atomicOr(&tmask[key], bits);
+                    }
                 }
                 const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
                                       ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
@@ -1859,8 +1868,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     if (P.use_tmask) {
                         const int b1 = min(tlo2 >> tshift2, 63), b2 = min((to_end2 ? tlast2 : tlo2 + tpc2 - 1) >> tshift2, 63);
                         const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
-                        const unsigned long long seen = atomicOr(&tmaskb[key], bits);
-                        if (X.tmask_m2 && (seen & bits)) atomicOr(&tmaskb_m2[key], seen & bits);
+                        if (X.tmask_m2) {
+                            const unsigned long long seen = atomicOr(&tmaskb[key], bits);
+                            if (seen & bits) atomicOr(&tmaskb_m2[key], seen & bits);
+                        } else {
+                            atomicOr(&tmaskb[key], bits);
+                        }
                     }
                     const int slot2 = atomicAdd(&csr2[key], 1);
                     items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
@@ -1958,6 +1971,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
     put(L_CELL_TARGET, ((R + 31) / 32) * 4);
     put(L_A_SPEED, A * 8); put(L_A_TQ, A * 8);
+    if (P.merged) { put(L_A_RAW, A * 32); put(L_RTYPE, R); }
     put(L_A_VPOS, A * 2); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 2); put(L_A_TARGET, A * 2);
     put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2);
     put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
@@ -2024,23 +2038,26 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     static const bool no_merge = getenv("FL_OBS_NO_MERGE") != nullptr;
     P.merged = 0;
     if (!no_merge && dual_ok && P.max_depth <= 2 && d.A <= 31 && d.rkey == nullptr && (!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT) &&
-        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.items, 1) && ok(force.snext, 1) && force.tab != 1) {
+        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.items, 1) && ok(force.snext, 1)) {
         P.merged = 1;
         o.nt = OBS_NT; o.tmask = 1; o.dual = 1; o.items = 1; o.snext = 1; o.partial = 1;
+        // (the static tables in LDS with the work lists in HBM scratch instead measured 1.2 us slower on cfg2: longer staging)
+        static const int merged_variants[2][2] = {{24 * 1024, 0}, {16 * 1024, 0}};
         for (int wk = 0; wk < 2 && P.merged; wk++) {
-            o.wl_bytes = wk == 0 ? 24 * 1024 : 16 * 1024;
-            if (!ok(force.wl, o.wl_bytes)) continue;
+            o.wl_bytes = merged_variants[wk][0]; o.tab = merged_variants[wk][1];
+            if (!ok(force.wl, o.wl_bytes) || !ok(force.tab, o.tab) || (o.tab && (no_tab || !nh_fit))) continue;
             for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
-                if (!ok(force.nh, o.nh)) continue;
+                if (!ok(force.nh, o.nh) || (o.tab && !o.nh)) continue;
                 const ObsLayout L = obs_layout(d, P, o);
                 if (L.total > lds_limit) continue;
                 P.L = L; P.use_tmask = 1; P.dual_index = 1; P.bk = 0;
                 static const int force_tshift_m = getenv("FL_OBS_TSHIFT") ? atoi(getenv("FL_OBS_TSHIFT")) : -1;
-                P.tshift = force_tshift_m >= 0 ? force_tshift_m : OBS_TSHIFT;
+                P.tshift = force_tshift_m >= 0 ? force_tshift_m : 2;  // 4-step buckets: same-box A/B on cfg2, 54.8 us against 55.1 (2-step) and 56.9 (8-step)
                 return true;
             }
         }
         P.merged = 0;
+        o.tab = 0;
     }
     for (int k = 0; k < 3; k++) {
         o.nt = nts[k];
