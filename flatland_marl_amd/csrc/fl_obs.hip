@@ -1284,6 +1284,36 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const bool nh_in_lds = nh_lds != nullptr && any_pred;
     // ---- phase 0: stage the rail words and the static tables, clear the per-cell maps, per-agent snapshot into LDS
     if (STAGE != 2) {
+        // per-agent snapshot first, on the LAST lanes: its two dependent HBM reads (state, then the rail index of the position)
+        // overlap with the staging of the tables by everybody else
+        const uint16_t *gridx = d.ridx + (size_t)b * d.H * d.W;
+        for (int i = nt - 1 - tid; i < A; i += nt) {
+            const int g = b * A + i;
+            const uint32_t pk = d.pk[g];
+            const uint32_t state = PK_STATE(pk);
+            const int pos = d.pos[g];
+            const int init_r = d.init_r[g], target_r = d.target_r[g];
+            const double speed = d.speed[g];
+            const int pos_r = pos < 0 ? -1 : (int)gridx[pos];  // the dynamic state keeps cell ids (C-ABI, step kernel)
+            a_pos[i] = pos_r;
+            a_vpos[i] = (uint16_t)(is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r));  // loader.cpp:74-82
+            a_dir[i] = (uint8_t)PK_DIR(pk);
+            a_state[i] = (uint8_t)state;
+            a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
+            const uint32_t malfw = d.malf[g];
+            a_malf[i] = (uint16_t)(malfw & 0xFFFFu);
+            if (a_raw) {
+                uint32_t *r8 = a_raw + i * 8;
+                r8[0] = pk; r8[1] = d.spk[g]; r8[2] = malfw; r8[3] = (uint32_t)d.latest[g]; r8[4] = (uint32_t)d.earliest[g];
+                r8[5] = (uint32_t)d.arrival[g]; r8[6] = (uint32_t)init_r;
+            }
+            a_speed[i] = speed;
+            a_tslot[i] = (uint16_t)d.tslot[g];
+            a_target[i] = (uint16_t)target_r;
+            a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
+            a_tq[i] = CUTILS ? (double)(float)(1.0 / (double)(float)speed) : 1.0 / speed;
+            if (CUTILS && STAGE == 1 && P.dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
+        }
         {
             const uint16_t *grg = d.rgrid + (size_t)b * Rcap;
             for (int r = tid; r < R; r += nt) cellw[r] = (uint32_t)grg[r] | 0xFFFF0000u;
@@ -1320,34 +1350,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
         for (int c = tid; c < (R + 31) / 32; c += nt) cell_target[c] = 0;
         if (tid < 64) misc[tid] = 0;
-        const uint16_t *gridx = d.ridx + (size_t)b * d.H * d.W;
-        for (int i = tid; i < A; i += nt) {
-            const int g = b * A + i;
-            const uint32_t pk = d.pk[g];
-            const uint32_t state = PK_STATE(pk);
-            const int pos = d.pos[g];
-            const int init_r = d.init_r[g], target_r = d.target_r[g];
-            const double speed = d.speed[g];
-            const int pos_r = pos < 0 ? -1 : (int)gridx[pos];  // the dynamic state keeps cell ids (C-ABI, step kernel)
-            a_pos[i] = pos_r;
-            a_vpos[i] = (uint16_t)(is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r));  // loader.cpp:74-82
-            a_dir[i] = (uint8_t)PK_DIR(pk);
-            a_state[i] = (uint8_t)state;
-            a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
-            const uint32_t malfw = d.malf[g];
-            a_malf[i] = (uint16_t)(malfw & 0xFFFFu);
-            if (a_raw) {
-                uint32_t *r8 = a_raw + i * 8;
-                r8[0] = pk; r8[1] = d.spk[g]; r8[2] = malfw; r8[3] = (uint32_t)d.latest[g]; r8[4] = (uint32_t)d.earliest[g];
-                r8[5] = (uint32_t)d.arrival[g]; r8[6] = (uint32_t)init_r;
-            }
-            a_speed[i] = speed;
-            a_tslot[i] = (uint16_t)d.tslot[g];
-            a_target[i] = (uint16_t)target_r;
-            a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
-            a_tq[i] = CUTILS ? (double)(float)(1.0 / (double)(float)speed) : 1.0 / speed;
-            if (CUTILS && STAGE == 1 && P.dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
-        }
         __syncthreads();
         // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
         // Occupied cells get an entry in a small table; the per-cell word only holds the entry index.
@@ -1415,40 +1417,71 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
         // its exits leads to an empty cell or to a free, not yet deadlocked agent (or it has no exit at all);
         // every other active agent becomes (and stays) deadlocked.  Equivalent to the reference's DFS + _fix_deps.
-        for (int i = lane; i < A; i += 64) {
-            bool fr = false;
-            if (is_on_map(a_state[i]) && !a_dead[i]) {
+        if (A <= 64) {
+            // one agent a lane: who blocks whom is looked up once (a bit mask of the agents on the exits), the fixpoint
+            // itself runs on ballots, without a memory access
+            const int i = lane;
+            bool active = false, fr = false;
+            unsigned long long blockers = 0;
+            if (i < A && is_on_map(a_state[i]) && !a_dead[i]) {
+                active = true;
                 const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
                 if (bits == 0) fr = true;
-                for (uint32_t m = 0; m < 4 && !fr; m++) {
+                for (uint32_t m = 0; m < 4; m++) {
                     if (!((bits >> (3 - m)) & 1)) continue;
                     const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
                     if (nr == FL_R_NONE) { fr = true; continue; }  // leaves the grid / the rail: nobody can be there
                     const uint32_t sl = cw_slot(X, (int)nr);
-                    if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
+                    const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
+                    if (opp < 0) fr = true;
+                    else if (!a_dead[opp]) blockers |= 1ull << opp;
                 }
             }
-            a_free[i] = fr;
-        }
-        team_sync();
-        while (true) {  // monotone: any evaluation order reaches the same least fixpoint
-            bool changed = false;
+            unsigned long long free_set = __ballot(fr);
+            while (true) {  // monotone: any evaluation order reaches the same least fixpoint
+                if (active && !fr && (free_set & blockers)) fr = true;
+                const unsigned long long next = __ballot(fr);
+                if (next == free_set) break;
+                free_set = next;
+            }
+            if (i < A) a_free[i] = fr;
+            team_sync();
+        } else {
             for (int i = lane; i < A; i += 64) {
-                if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
+                bool fr = false;
+                if (is_on_map(a_state[i]) && !a_dead[i]) {
                     const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
-                    bool fr = false;
+                    if (bits == 0) fr = true;
                     for (uint32_t m = 0; m < 4 && !fr; m++) {
                         if (!((bits >> (3 - m)) & 1)) continue;
                         const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
-                        const uint32_t sl = nr != FL_R_NONE ? cw_slot(X, (int)nr) : 0xFFFFu;
-                        const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
-                        if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
+                        if (nr == FL_R_NONE) { fr = true; continue; }  // leaves the grid / the rail: nobody can be there
+                        const uint32_t sl = cw_slot(X, (int)nr);
+                        if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
                     }
-                    if (fr) { a_free[i] = 1; changed = true; }
                 }
+                a_free[i] = fr;
             }
             team_sync();
-            if (!__any(changed)) break;
+            while (true) {  // monotone: any evaluation order reaches the same least fixpoint
+                bool changed = false;
+                for (int i = lane; i < A; i += 64) {
+                    if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
+                        const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
+                        bool fr = false;
+                        for (uint32_t m = 0; m < 4 && !fr; m++) {
+                            if (!((bits >> (3 - m)) & 1)) continue;
+                            const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                            const uint32_t sl = nr != FL_R_NONE ? cw_slot(X, (int)nr) : 0xFFFFu;
+                            const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
+                            if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
+                        }
+                        if (fr) { a_free[i] = 1; changed = true; }
+                    }
+                }
+                team_sync();
+                if (!__any(changed)) break;
+            }
         }
         for (int i = lane; i < A; i += 64) {  // commit the new deadlocks; the deadlock flag of the attribute row and of props
             const int g = b * A + i;
@@ -1568,6 +1601,25 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // (with hundreds of agents every wavefront would walk: one of them is kept back for phase 1, which then runs beside the walk)
     const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(2, (A + 7) / 8)) : 0;
     const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
+    // job queue of phase 2: pass A of four upstream trees (one pass B for both builders, see trees_merged; longest first), the
+    // rest of phase 1 of two agents.  (Ending the phase with the last pass A of a cutils tree and taking the rest of the queue
+    // beside the fill of the index measured 0.8 us slower: a job is a chain of HBM reads and takes as long as the fill.)
+    const int n_up_jobs = merged ? (A + 3) / 4 : 0, n_p1_jobs = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
+    auto drain_jobs = [&]() __attribute__((always_inline)) {
+        while (n_up_jobs + n_p1_jobs > 0) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&misc[6], 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= n_up_jobs + n_p1_jobs) break;
+            if (j < n_up_jobs) {
+                const int u = 4 * j + (lane >> 4);
+                upstream_pass_a<16, 32>(X, P, b, u, u < A, lane & 15, wave_scr + (u < A ? merged_slot_upstream(A, u) : A) * (F_WORDS * 32));
+            } else {
+                const int i = 2 * (j - n_up_jobs) + (lane >> 5);
+                if (i < A) phase1b(i, lane & 31, phase1b_load(i));
+            }
+        }
+    };
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
         if (wave == 0) phase1a();
         phase1b_all();
@@ -1701,20 +1753,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             // The wavefronts are done with their roles at very different times (no tree to build, a short walk, a deep
             // tree): what is left of this phase is a queue of jobs that whoever is free takes -- the rest of phase 1, two agents a job
             // (longest first: pass A of four upstream trees when both builders share one pass B, see trees_merged)
-            const int n_up = merged ? (A + 3) / 4 : 0, n_p1 = (do_p1 && p1_beside_walk) ? (A + 1) / 2 : 0;
-            while (n_up + n_p1 > 0) {
-                int j = 0;
-                if (lane == 0) j = atomicAdd(&misc[6], 1);
-                j = __builtin_amdgcn_readfirstlane(j);
-                if (j >= n_up + n_p1) break;
-                if (j < n_up) {
-                    const int u = 4 * j + (lane >> 4);
-                    upstream_pass_a<16, 32>(X, P, b, u, u < A, lane & 15, wave_scr + (u < A ? merged_slot_upstream(A, u) : A) * (F_WORDS * 32));
-                } else {
-                    const int i = 2 * (j - n_up) + grp;
-                    if (i < A) phase1b(i, gl, phase1b_load(i));
-                }
-            }
+            drain_jobs();
         }
 #ifdef FL_OBS_TIMING
         if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
@@ -2046,6 +2085,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         for (int wk = 0; wk < 2 && P.merged; wk++) {
             o.wl_bytes = merged_variants[wk][0]; o.tab = merged_variants[wk][1];
             if (!ok(force.wl, o.wl_bytes) || !ok(force.tab, o.tab) || (o.tab && (no_tab || !nh_fit))) continue;
+            // (the eight-hop table or the distance maps in LDS as well: no difference in time, same-box A/B)
             for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
                 if (!ok(force.nh, o.nh) || (o.tab && !o.nh)) continue;
                 const ObsLayout L = obs_layout(d, P, o);
