@@ -44,6 +44,7 @@
 #define OBS_TSHIFT 1                 // time-bucket width of the per-key masks for long horizons: 1 << OBS_TSHIFT steps
 #endif
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
+#define CF_DIRECT 32                 // when no list of the env is longer, every conflict entry is scanned by its lane alone, in one pass
 #define OBS_ITEMS2_CAP 2048          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
@@ -97,6 +98,7 @@ struct ObsCtx {
     int wl_occ_cap, wl_cf_cap;
     bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
     int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
+    const int *long_lists;        // LDS flag: some key's list has more than CF_DIRECT items (else no conflict query needs chunks)
     const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
     int tshift;
     // pass B over the trees of BOTH builders at once (PB = 2): teams below n_cu are flatland_cutils trees and use the members
@@ -539,7 +541,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         unsigned long long tm = 0, tm2 = 0;
         int c_hi = 0, c_lo = 0, n_start = 0, n_tot = 0, n_vis = 0;
         auto request = [&]() __attribute__((always_inline)) {
-            if (FAST && self_filter) own_w = path_t[min(tot, lp_t)];  // HBM (L2): the longest latency first
+            if (FAST && self_filter) own_w = path_t[min(tot, lp_t)];  // HBM (L2): the longest latency first (an LDS copy of the paths made no difference)
             cw = cw_load(X, cell);
             if (has_snext) sn = X.snext[((uint32_t)cell << 2) | dd];
             if (FAST || X.Tn > 0) {
@@ -665,6 +667,22 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         occ_event<PB, CAP>(X, pb_cu<PB>(X, team), scr0 + team * team_words, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
     WAVE_MARK(X, 12, -1);
+    if (*X.long_lists == 0) {  // every list is short: one pass, every lane scans the list of its entry
+        for (int e = tid; e < n_cf; e += nt) {
+            const uint2 w = X.wl_cf[e];
+            const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
+            const int handle = team_meta[128 + team], tot = (int)(w.y & 511u);
+            const bool cu = pb_cu<PB>(X, team);
+            const int pt = pt_of<PB>(X, cu, handle, tot);
+            int lo, hi;
+            list_range<PB>(X, cu, cell, pt, lo, hi);
+            if (hi > lo && conflict_hit(conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo, hi)))
+                atomicMin(&(scr0 + team * team_words)[F_PC * CAP + (int)(w.y >> 24)], tot);
+        }
+        WAVE_MARK(X, 13, 17);
+        __syncthreads();
+        return;
+    }
     // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes further
     // entries for the rest of its list, and ALL chunks are scanned after a barrier, one per lane on densely packed wavefronts
     // (scanning the first chunk right away measured 4 % slower on 80 agents, where many lists have several chunks).
@@ -1399,6 +1417,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.wl_occ_cap = X.tmask ? wl_entries / OBS_WL_OCC_DIV : wl_entries;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
+    X.long_lists = misc + 11;
     X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = min(t >> tshift, 63)
     // one pass B over the trees of both builders (stage 1 of the fused launch): the upstream builder's side of the context
     const bool merged = CUTILS && STAGE == 1 && P.merged != 0;
@@ -1639,6 +1658,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         uint32_t *bkc = reinterpret_cast<uint32_t *>(wave_scr);
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
+            if (tid == 0) misc[11] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
             if (bk) for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) bkc[k] = 0u;
         }
@@ -1801,7 +1821,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int chunk = (K + 1 + nt - 1) / nt;
             const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
             int sum = 0;
-            for (int k = lo; k < hi; k++) sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
+            int longest = 0;
+            for (int k = lo; k < hi; k++) {
+                sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
+                longest = max(longest, dual ? max(csr[k], csr2[k]) : csr[k]);
+            }
+            if (longest > CF_DIRECT) misc[11] = 1;  // (lists of the bucketed index count an item once per bucket: they only look longer)
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
