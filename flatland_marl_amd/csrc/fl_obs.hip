@@ -1767,7 +1767,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (lane == 0) {
                 atomicMax((unsigned long long *)&X.dbg[19], (unsigned long long)wall_clock64());
                 atomicMax((unsigned long long *)&X.dbg[23], (unsigned long long)((long long)wall_clock64() - t_pa0));
-                if (wave == 0) X.dbg[27] = (long long)wall_clock64() - t_pa0;  // wavefront 0 alone
             }
 #endif
             // The wavefronts are done with their roles at very different times (no tree to build, a short walk, a deep

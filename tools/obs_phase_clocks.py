@@ -51,7 +51,7 @@ def report():
     print("stage 1 (cutils):")
     print("  p0 stage %.1f  p1 %.1f  p2a walk|phase1|passA + count %.1f  p2b scan/fill %.1f" % (seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4)))
     print("     since p2a start: deadlock wavefront done %.1f, walkers done %.1f, hoisted pass A done %.1f, rest of phase 1 done %.1f" % (seg(2, 20), seg(2, 21), seg(2, 19), seg(2, 22)))
-    print("     hoisted pass A alone: slowest wavefront %.1f, wavefront 0 %.1f" % (dur(23), dur(27)))
+    print("     hoisted pass A alone: slowest wavefront %.1f" % dur(23))
     print("  trees (sum over rounds): passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f  orders %.1f   stage total %.1f" %
           (dur(6), dur(11), dur(7), dur(8), dur(16), seg(0, 5)))
     print("stage 2 (upstream tree):")
@@ -68,10 +68,12 @@ def report():
     def rel_min(k, k0):
         return (((1 << 40) - c[:, :, k] - c[:, :, k0]) / 100.0).mean()
 
-    print("work-list step, since its start (cutils | upstream): occupants done %.1f | %.1f, first scan done: earliest wavefront %.1f | %.1f, latest %.1f | %.1f, after the barrier %.1f | %.1f" %
-          (rel(12, 18), rel(44, 50), rel_min(17, 18), rel_min(49, 50), rel(13, 18), rel(45, 50), rel(14, 18), rel(46, 50)))
-    print("conflict entries (cutils | upstream): items in their lists %.0f | %.0f, queried beyond the fine buckets %.0f | %.0f, somebody else there %.0f | %.0f, conflicts %.0f | %.0f, only the walking agent itself there %.0f | %.0f" %
-          (c[:, :, 27].mean(), c[:, :, 59].mean(), c[:, :, 28].mean(), c[:, :, 60].mean(), c[:, :, 29].mean(), c[:, :, 61].mean(), c[:, :, 30].mean(), c[:, :, 62].mean(), c[:, :, 31].mean(), c[:, :, 63].mean()))
+    if env.A <= 31 and c[:, :, 50].max() == 0:  # marks of the last round only; meaningful for one round and one pass B
+        print("work-list step, since its start: occupants done %.1f, conflict scan done: earliest wavefront %.1f, latest %.1f" %
+              (rel(12, 18), rel_min(17, 18), rel(13, 18)))
+    if c[:, :, 27].max() > 0:  # a -DFL_OBS_COUNTS build
+      print("conflict entries (cutils | upstream): items in their lists %.0f | %.0f, queried beyond the fine buckets %.0f | %.0f, somebody else there %.0f | %.0f, conflicts %.0f | %.0f, only the walking agent itself there %.0f | %.0f" %
+            (c[:, :, 27].mean(), c[:, :, 59].mean(), c[:, :, 28].mean(), c[:, :, 60].mean(), c[:, :, 29].mean(), c[:, :, 61].mean(), c[:, :, 30].mean(), c[:, :, 62].mean(), c[:, :, 31].mean(), c[:, :, 63].mean()))
     print("work-list entries (sum over rounds): occupant %.0f / %.0f, conflict %.0f / %.0f  (cutils / upstream)" %
           (c[:, :, 9].mean(), c[:, :, 41].mean(), c[:, :, 10].mean(), c[:, :, 42].mean()))
 
