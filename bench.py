@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KERNEL_SOURCES = ("fl_obs.hip", "fl_obs.h", "fl_step.hip", "fl_step_body.h", "fl_dmap.hip", "fl_internal.h")
+KERNEL_SOURCES = ("fl_obs.hip", "fl_obs.h", "fl_step.hip", "fl_step_body.h", "fl_dmap.hip", "fl_internal.h", "build.sh")  # sources + compile flags
 EXTRA_WORKLOADS = (  # (workload, tree depth, distance-map rebuild at auto-reset, timed steps)
     ("cfg3", 3, False, 150), ("cfg4", 2, False, 150), ("cfg5", 3, True, 100))
 
