@@ -113,6 +113,40 @@ def test_largest_supported_agent_count_matches_oracle():
     assert pos[0] == p_o and np.array_equal(key[0], k_o)
 
 
+@pytest.mark.parametrize("A,max_nodes,depth", [(1, 31, 2), (2, 31, 1), (31, 31, 2), (32, 31, 2), (31, 13, 2), (31, 12, 2), (24, 20, 1)])
+def test_fused_observations_at_the_limits_of_the_one_pass_mode(A, max_nodes, depth):
+    """The fused launch builds the trees of both builders with ONE pass B on envs of at most 31 agents (upstream depth <= 2,
+    max_nodes >= 13) and in two stages beyond (fl_obs.hip: trees_merged): the agent counts either side of the limit, the
+    smallest counts, the smallest node budget, dense traffic on the 30x30 map of cfg2 (agents cycling through its lines,
+    staggered departures, malfunctions)."""
+    from oracle import orc
+    from flatland_marl_amd import synth
+    fx = util.load("cfg2_spfollow")
+    st = util.static_of(fx)
+    A0 = len(st["init_dir"])
+    idx = np.arange(A) % A0
+    big = dict(st)
+    for k in ("init_pos", "init_dir", "target", "speed", "latest"):
+        big[k] = np.ascontiguousarray(np.asarray(st[k])[idx])
+    big["earliest"] = (np.arange(A) // 3).astype(np.int32)
+    big["malf_rate"] = 1 / 200.0
+    env = _env([big, big], max_nodes=max_nodes, pred_depth=120)
+    o = orc.OracleEnv(big)
+    keys = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("node_order", "node_order"),
+            ("edge_order", "edge_order"), ("valid_actions", "valid"), ("props", "props"))
+    for t in range(140):
+        env.step_synth(91, 0, 1, auto_reset=True)
+        o.step(synth.forward_biased_actions(91, 0, t, A))
+        _same(env.state()[0][0], o.state(), f"t={t} state")
+        if t % 7 == 0:
+            got, tree = env.obs_both(depth, 30)
+            exp = o.obs_cutils(max_nodes, 120)
+            for g, e in keys:
+                _same(got[g].cpu().numpy()[0], exp[e], f"t={t} {g}")
+            _same(tree.cpu().numpy()[0], o.obs_pytree(depth, 30), f"t={t} tree")
+    env.check()
+
+
 def test_masked_and_non_fresh_reset():
     """fl_reset(mask, fresh=0) follows EnvAgent.reset() literally: arrival_time survives (agent_utils.py:90-105)."""
     import torch
