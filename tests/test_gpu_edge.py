@@ -147,6 +147,38 @@ def test_fused_observations_at_the_limits_of_the_one_pass_mode(A, max_nodes, dep
     env.check()
 
 
+@pytest.mark.parametrize("name,A", [("cfg4_fwd_head", 24), ("cfg5_fwd_head", 20), ("cfg3_uniform", 31), ("cfg0_tall_spfollow", 3)])
+def test_fused_observations_of_few_agents_on_other_maps(name, A):
+    """The one-pass mode of the fused launch (fl_obs.hip: trees_merged) on other maps than cfg2's: the first agents of the
+    60x60 / 150x150 / 35x30 envs (long paths, next-hop tables that do not fit the LDS, hundreds of keys) and a map that is
+    taller than wide (its prediction keys collide, so it takes the two stages)."""
+    from oracle import orc
+    from flatland_marl_amd import synth
+    st = util.static_of(util.load(name))
+    sub = dict(st)
+    A = min(A, len(st["init_dir"]))
+    for k in ("init_pos", "init_dir", "target", "speed", "latest"):
+        sub[k] = np.ascontiguousarray(np.asarray(st[k])[:A])
+    sub["earliest"] = (np.arange(A) // 3).astype(np.int32)  # everybody on the map soon
+    sub["malf_rate"] = 1 / 150.0
+    env = _env([sub], pred_depth=300)
+    o = orc.OracleEnv(sub)
+    keys = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("node_order", "node_order"),
+            ("edge_order", "edge_order"), ("valid_actions", "valid"), ("props", "props"))
+    for t in range(120):
+        env.step_synth(5, 0, 1, auto_reset=True)
+        o.step(synth.forward_biased_actions(5, 0, t, A))
+        _same(env.state()[0][0], o.state(), f"t={t} state")
+        if t % 10 == 0:
+            got, tree = env.obs_both(2, 30)
+            exp = o.obs_cutils(31, 300)
+            for g, e in keys:
+                _same(got[g].cpu().numpy()[0], exp[e], f"t={t} {g}")
+            _same(tree.cpu().numpy()[0], o.obs_pytree(2, 30), f"t={t} tree")
+    assert (env.state()[0][0][:, 0] >= 0).sum() >= min(A, 3) // 2      # agents are on the map at the end
+    env.check()
+
+
 def test_masked_and_non_fresh_reset():
     """fl_reset(mask, fresh=0) follows EnvAgent.reset() literally: arrival_time survives (agent_utils.py:90-105)."""
     import torch
