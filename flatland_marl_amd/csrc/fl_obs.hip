@@ -129,6 +129,11 @@ __device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? 
 // rules apply to a team
 template <int PB>
 __device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 2 ? team < X.n_cu : PB == 1; }
+// the agent of a team: from the team table, or -- both builders in one pass -- from the numbering of trees_merged (no memory access)
+template <int PB>
+__device__ __forceinline__ int pb_handle(const ObsCtx &X, const int *team_meta, int team) {
+    return PB == 2 ? (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
+}
 // predicted time at which the walking agent reaches a cell tot steps away (treeobs.cpp:378 / observations.py:329)
 template <int PB>
 __device__ __forceinline__ int pt_of(const ObsCtx &X, bool cu, int handle, int tot) {
@@ -474,7 +479,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     if (pos < end) {
         const int *vs = scr0 + team * team_words;
         int nn = team_meta[64 + team];
-        int handle = team_meta[128 + team];
+        int handle = pb_handle<PB>(X, team_meta, team);
         // first node of the team whose inclusive prefix exceeds the team-local position: three pivots per round trip
         const int lpos = pos - t_excl;
         int lo = 0, hi = nn - 1;
@@ -612,7 +617,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                         do { team++; } while (team < n_teams - 1 && team_meta[team] == 0);
                         vs = scr0 + team * team_words;
                         nn = team_meta[64 + team];
-                        handle = team_meta[128 + team];
+                        handle = pb_handle<PB>(X, team_meta, team);
                         node = team_meta[256 + team];
                         enter_team();
                         n_start = vs[F_START * CAP + node]; n_tot = vs[F_TOT * CAP + node]; n_vis = vs[F_VIS * CAP + node];
@@ -671,7 +676,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         for (int e = tid; e < n_cf; e += nt) {
             const uint2 w = X.wl_cf[e];
             const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-            const int handle = team_meta[128 + team], tot = (int)(w.y & 511u);
+            const int handle = pb_handle<PB>(X, team_meta, team), tot = (int)(w.y & 511u);
             const bool cu = pb_cu<PB>(X, team);
             const int pt = pt_of<PB>(X, cu, handle, tot);
             int lo, hi;
@@ -697,7 +702,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             w = X.wl_cf[e];
             cell = (int)((w.x & 0xFFFFFFu) >> 2);
             const int team = (int)(w.x >> 24);
-            handle = team_meta[128 + team];
+            handle = pb_handle<PB>(X, team_meta, team);
             tot = (int)(w.y & 511u);
             cu = pb_cu<PB>(X, team);
             pt = pt_of<PB>(X, cu, handle, tot);
@@ -725,7 +730,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int first = more ? (int)((w.y >> 6) & 0x1FFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
         const uint32_t fy = more ? wl_flags(X, &X.wl_cf[first]) : w.y;
         const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
-        const int handle = team_meta[128 + team];
+        const int handle = pb_handle<PB>(X, team_meta, team);
         const bool cu = pb_cu<PB>(X, team);
         const int pt = pt_of<PB>(X, cu, handle, tot);
         int lo, hi;
@@ -1097,9 +1102,11 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
         const int fc = packed >> 2;          // 0 = no children pushed
         const int parent = gl < node_base ? scr[F_PAR * CAP + gl] : -2;
         const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
-        const int max_levels = __shfl(levels, 0) > __shfl(levels, 32) ? __shfl(levels, 0) : __shfl(levels, 32);
+        // `levels` counted the rounds of pass A including the one that found nothing left: a tree of L levels below the root
+        // needs L rounds here (a leaf is 0, every round carries the heights one level up)
+        const int max_levels = max(__builtin_amdgcn_readlane(levels, 0), __builtin_amdgcn_readlane(levels, 32));
         int h = 0;
-        for (int it = 0; it < max_levels; it++) {
+        for (int it = 0; it + 1 < max_levels; it++) {
             const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
             int hn = 0;
             if (nchild > 0) hn = h0 + 1;
