@@ -13,6 +13,9 @@ if [ -f "$OUT" ] && [ "$(stat -c %Y "$OUT")" -ge "$newest" ] && [ -z "${FORCE:-}
 # -disable-machine-licm: the observation kernel sits at its 128-VGPR / 102-SGPR ceiling (1024 threads a workgroup); hoisting
 # loop invariants out of the loops over the rounds of trees only adds spills (same-box A/B: cfg3 / cfg4 / cfg5 2.4 - 3.2 % faster
 # without it, cfg2 unchanged)
+# -amdgpu-atomic-optimizer-strategy=None: the atomics on one address are issued by ONE lane for its wavefront already (work-list
+# and queue counters); the optimizer's own wave reduction around them only adds instructions and waits (k_step 12.6 -> 12.0 us)
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -disable-machine-licm \
+  -mllvm -amdgpu-atomic-optimizer-strategy=None \
   -Wno-unused-result ${EXTRA_HIPCC_FLAGS:-} "${SRCS[@]}" -o "$OUT"
 echo "built $OUT"
