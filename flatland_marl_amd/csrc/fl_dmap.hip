@@ -326,6 +326,8 @@ static size_t dm_lds_bytes(const FlDev &d) {
     return Scap * 2 + (size_t)((d.Rcap + 1) & ~1) * 2 + (size_t)DM_WAVES * ((Scap + 31) / 32) * 4 + (size_t)DM_WAVES * DM_QCAP * 2 + 16;
 }
 
+int fl_dmap_fits(const FlDev &d) { return dm_lds_bytes(d) > 160 * 1024 ? FL_ERR_ARG : FL_OK; }  // no HIP call: usable before a device is touched
+
 int fl_dmap_prepare(const FlDev &d) {
     if (dm_lds_bytes(d) > 160 * 1024) return FL_ERR_ARG;
     if (hipFuncSetAttribute((const void *)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;

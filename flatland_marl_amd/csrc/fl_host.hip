@@ -139,6 +139,12 @@ int fl_reserve(fl_batch *h, int max_targets, int max_rail_cells) {
     if (!h || max_targets < 0 || max_rail_cells < 0) { set_err("fl_reserve: bad argument"); return FL_ERR_ARG; }
     if (h->committed) { set_err("fl_reserve: the capacities are fixed at the first fl_commit"); return FL_ERR_ARG; }
     if ((long long)max_rail_cells * 4 > 65532) { set_err("fl_reserve: at most 16383 rail cells per env (u16 rail states)"); return FL_ERR_ARG; }
+    {   // the reverse-BFS kernel keeps the env's neighbour table, four visited bitmaps and four queues in LDS (fl_dmap.hip)
+        FlDev probe = h->d;
+        probe.Rcap = max_rail_cells > 1 ? max_rail_cells : 1;
+        probe.Ucap = 1;
+        if (fl_dmap_fits(probe) != FL_OK) { set_err("fl_reserve: %d rail cells per env do not fit the distance-map kernel's LDS", max_rail_cells); return FL_ERR_ARG; }
+    }
     h->reserve_U = max_targets > h->A ? h->A : max_targets;
     h->reserve_R = max_rail_cells;
     return FL_OK;
@@ -313,6 +319,16 @@ int fl_commit(fl_batch *h) {
     const size_t BA = (size_t)B * A, HW = (size_t)h->H * h->W;
     FlDev &d = h->d;
     if (!h->committed) {
+        // a first commit that failed half way (allocation, LDS fit) left device pointers behind: release them, a retry starts clean
+        if (!h->allocs.empty()) {
+            for (void *p : h->allocs) (void)hipFree(p);
+            h->allocs.clear();
+            const int B0 = h->d.B, A0 = h->d.A, H0 = h->d.H, W0 = h->d.W;
+            memset(&h->d, 0, sizeof h->d);
+            h->d.B = B0; h->d.A = A0; h->d.H = H0; h->d.W = W0;
+            memset(&h->obs, 0, sizeof h->obs);
+            h->mask_dev = nullptr;
+        }
         int Ucap = h->reserve_U > 1 ? h->reserve_U : 1, Rcap = h->reserve_R > 1 ? h->reserve_R : 1;
         for (int b = 0; b < B; b++) {
             Ucap = h->h_U[b] > Ucap ? h->h_U[b] : Ucap;
@@ -320,12 +336,16 @@ int fl_commit(fl_batch *h) {
         }
         d.Ucap = Ucap; d.Rcap = Rcap;
         const size_t Scap = (size_t)Rcap * 4;
+        {   // before anything is allocated: do the capacities fit the table kernels' LDS?
+            const int rc_dm = fl_dmap_prepare(d);
+            if (rc_dm != FL_OK) { set_err("fl_commit: %d rail cells per env do not fit the distance-map kernel's LDS", Rcap); return rc_dm; }
+        }
         h->h_rcell.assign((size_t)B * Rcap, 0); h->h_rgrid.assign((size_t)B * Rcap, 0); h->h_rtype.assign((size_t)B * Rcap, 0); h->h_nbr.assign((size_t)B * Scap, FL_R_NONE);
         h->h_ut_r.assign((size_t)B * Ucap, 0);
         if (h->H > h->W) h->h_rkey.assign((size_t)B * Rcap, 0);
         DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
         DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.R, B); DALLOC(d.K, B);
-        DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2);
+        DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2); DALLOC(d.score_sums, (size_t)B * 2);
         DALLOC(d.grid, B * HW); DALLOC(d.ridx, B * HW);
         DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.rtype, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
         d.rkey = nullptr;
@@ -339,8 +359,6 @@ int fl_commit(fl_batch *h) {
         DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
         DALLOC(h->mask_dev, B);
         if (fl_step_prepare() != FL_OK) { set_err("fl_commit: hipFuncSetAttribute failed"); return FL_ERR_HIP; }
-        const int rc_dm = fl_dmap_prepare(d);
-        if (rc_dm != FL_OK) { set_err("fl_commit: %d rail cells per env do not fit the distance-map kernel's LDS", Rcap); return rc_dm; }
         int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
         if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
     }
@@ -433,7 +451,7 @@ int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8
 int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev, uint8_t *dones_dev,
                   uint8_t *done_all_dev, int auto_reset) {
     NEED_COMMIT(h);
-    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 1) { set_err("fl_step_synth: bad argument"); return FL_ERR_ARG; }
+    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 2) { set_err("fl_step_synth: bad argument"); return FL_ERR_ARG; }
     fl_launch_step(h->d, nullptr, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, auto_reset, h->stream);
     HIPCHK(hipGetLastError());
     return FL_OK;
@@ -444,7 +462,7 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
                 float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
                 uint8_t *valid_actions_dev, double *props_dev, int tree_max_depth, int tree_pred_depth, double *tree_out_dev) {
     NEED_COMMIT(h);
-    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 1) { set_err("fl_step_obs: bad step argument"); return FL_ERR_ARG; }
+    if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 2) { set_err("fl_step_obs: bad step argument"); return FL_ERR_ARG; }
     if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED || tree_max_depth < 0 ||
         tree_max_depth > 3 || (tree_max_depth > 0 && (tree_pred_depth < 0 || tree_pred_depth > pred_depth || !tree_out_dev))) {
         set_err("fl_step_obs: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [0,3], 0 <= tree_pred_depth <= pred_depth",
@@ -494,6 +512,15 @@ int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset) {
     NEED_COMMIT(h);
     if (!out4_dev) { set_err("fl_metrics: null buffer"); return FL_ERR_ARG; }
     fl_launch_metrics(h->d, (long long *)out4_dev, reset, h->stream);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_scores(fl_batch *h, double *out3_dev, int reset) {
+    NEED_COMMIT(h);
+    if (!out3_dev) { set_err("fl_scores: null buffer"); return FL_ERR_ARG; }
+    // (call it BEFORE fl_metrics(reset): the episode count it reports is fl_metrics' counter)
+    fl_launch_scores(h->d, out3_dev, reset, h->stream);
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -591,6 +618,13 @@ int fl_set_state(fl_batch *h, const int32_t *state, const int32_t *aux, const in
         }
         pos[g] = on ? r * W + c : -1;
         old_pos[g] = orow >= 0 ? orow * W + ocol : -1;
+        // an agent on the map stands on a rail cell: the kernels index the env's rail tables with the rail index of its position
+        // (a cell without rail has none)
+        const size_t hw0 = (g / h->A) * (size_t)H * W;
+        if ((on && h->h_ridx[hw0 + pos[g]] == FL_R_NONE) || (orow >= 0 && h->h_ridx[hw0 + old_pos[g]] == FL_R_NONE)) {
+            set_err("fl_set_state: env %zu agent %zu: position (%d, %d) / old position (%d, %d) is not a rail cell", g / h->A, g % h->A, r, c, orow, ocol);
+            return FL_ERR_STATE_SYNC;
+        }
         arrival[g] = o[8];
         malf[g] = (uint32_t)mf | ((uint32_t)nmf << 16);
         int prev = 7, sig = mf > 0, dead = 0, done = st == ST_DONE;

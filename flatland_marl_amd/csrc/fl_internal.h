@@ -72,6 +72,8 @@ struct FlDev {
     int *env_list;  // [B + 1] scratch of the table (re)builds: the envs being rebuilt, their number at [B] (k_env_list)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
     int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
+    double *score_sums;  // [B][2] running sums over the env's finished episodes: normalized reward 1 + R / (T * A), arrived / A
+                         // (flatland/evaluators/service.py:875-879, 900-913)
     uint16_t *grid;   // [B][H*W] transition bitmap per cell (step kernel)
     uint16_t *ridx;   // [B][H*W] rail index of a cell, FL_R_NONE = no rail
     uint16_t *rgrid;  // [B][Rcap] transition bitmap per rail cell
@@ -134,6 +136,7 @@ __host__ __device__ inline uint32_t action_hash(uint32_t seed, uint32_t b, uint3
 __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint32_t t, uint32_t a, int kind) {
     uint32_t h = action_hash(seed, b, t, a);
     if (kind == 0) return h % 5u;
+    if (kind == 2) return h;  // shortest-path following: the step kernel derives the action from the agent's state (fl_step_body.h)
     uint32_t r = h % 100u;
     return r >= 95 ? 0u : r >= 90 ? 4u : r >= 85 ? 3u : r >= 80 ? 1u : 2u;
 }
@@ -146,7 +149,9 @@ void fl_launch_segments(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 void fl_launch_nexthop(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 void fl_launch_hop8(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);       // after fl_launch_nexthop
 int fl_dmap_prepare(const FlDev &d);                                               // LDS attribute / size check
+int fl_dmap_fits(const FlDev &d);                                                  // the size check alone
 void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s);
+void fl_launch_scores(const FlDev &d, double *out3, int reset, hipStream_t s);
 void fl_launch_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo, long long *adj_out,
                            long long *no_out, long long *eo_out, hipStream_t s);
 void fl_launch_info(const FlDev &d, uint8_t *action_required, int32_t *malfunction, uint8_t *state, double *scores, hipStream_t s);

@@ -61,6 +61,24 @@ void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s
     hipLaunchKernelGGL(k_metrics, dim3(1), dim3(256), 0, s, d, out4, reset);
 }
 
+// sums of the evaluator's per-episode scores over the envs, in env order (one thread: a fixed order of additions)
+__global__ void k_scores(FlDev d, double *out3, int reset) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s0 = 0.0, s1 = 0.0;
+    long long ep = 0;
+    for (int b = 0; b < d.B; b++) {
+        s0 += d.score_sums[(size_t)b * 2 + 0];
+        s1 += d.score_sums[(size_t)b * 2 + 1];
+        ep += d.metrics[(size_t)b * 4 + 3];
+        if (reset) { d.score_sums[(size_t)b * 2 + 0] = 0.0; d.score_sums[(size_t)b * 2 + 1] = 0.0; }
+    }
+    out3[0] = s0; out3[1] = s1; out3[2] = (double)ep;
+}
+
+void fl_launch_scores(const FlDev &d, double *out3, int reset, hipStream_t s) {
+    hipLaunchKernelGGL(k_scores, dim3(1), dim3(64), 0, s, d, out3, reset);
+}
+
 // plfActor.get_feature casts + Network.modify_adjacency (solution/plfActor.py:48-74, nn/net_tree.py:105-116)
 __global__ void k_policy_pack(int B, int A, int E, const int32_t *adj, const int32_t *no, const int32_t *eo,
                               long long *adj_out, long long *no_out, long long *eo_out) {

@@ -278,6 +278,32 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         old_pos = pos; old_dir = dir;  // :521-522
         uint32_t raw = SYNTH ? synth_action(seed, stream_base + (uint32_t)b, (uint32_t)(t - 1), (uint32_t)i, synth_kind)
                              : (uint32_t)actions[g];
+        if (SYNTH && synth_kind == 2) {
+            // shortest-path-following stream (flatland_marl_amd/synth.py spfollow_actions, the bench's dense-traffic workload):
+            // READY_TO_DEPART -> FORWARD; off the map -> DO_NOTHING; a counter-hash STOP with probability 3 %; on a cell with one
+            // transition FORWARD; else the first of LEFT / FORWARD / RIGHT whose next (cell, direction) is closest to the target
+            const uint32_t h = raw;  // kind 2: synth_action returns the raw hash
+            if (state == ST_READY) raw = ACT_FORWARD;
+            else if (!is_on_map(state) || pos < 0) raw = ACT_NOTHING;
+            else if (h % 100u < 3u) raw = ACT_STOP;
+            else {
+                const uint32_t bits = nibble(grid[pos], dir);
+                raw = ACT_FORWARD;
+                if (__popc(bits) != 1) {
+                    const uint16_t *dm_t = d.dm + ((size_t)b * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4);
+                    const uint16_t *ridx = d.ridx + (size_t)b * HW;
+                    uint32_t best = 0xFFFFFFFFu;
+                    for (uint32_t act3 = ACT_LEFT; act3 <= ACT_RIGHT; act3++) {
+                        const uint32_t nd = (dir + act3 + 2u) & 3u;
+                        if (!((bits >> (3u - nd)) & 1u)) continue;
+                        const uint32_t nr = ridx[step_cell(pos, nd, W)];
+                        if (nr == FL_R_NONE) continue;
+                        const uint32_t v = dm_t[nr * 4u + nd];
+                        if (v != FL_INF16 && v < best) { best = v; raw = act3; }
+                    }
+                }
+            }
+        }
         // eval_env.parse_actions (solution/eval_env.py:33-39): an agent without action_required (rail_env.py:243-258) is
         // dropped from the action dict
         if (filter_required && !(state == ST_READY || (is_on_map(state) && scount == 0))) raw = 255u;
@@ -392,6 +418,10 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
                 atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
                 d.last_episode[(size_t)b * 2 + 0] = L.misc[5];  // evaluator scoring inputs (service.py:875-879,900-913)
                 d.last_episode[(size_t)b * 2 + 1] = L.misc[6];
+                // the evaluator's per-episode terms, summed per env in episode order (service.py:875-879: normalized reward =
+                // cumulative reward / (max_episode_steps * n_agents) + 1; :900-913: complete agents / agents)
+                d.score_sums[(size_t)b * 2 + 0] += 1.0 + (double)L.misc[5] / ((double)T * (double)A);
+                d.score_sums[(size_t)b * 2 + 1] += (double)L.misc[6] / (double)A;
             }
             if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
         }

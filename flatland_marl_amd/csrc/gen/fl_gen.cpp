@@ -741,6 +741,20 @@ int flg_generate(int width, int height, int n_agents, int grid_mode, int max_rai
                  int32_t *city_orientations, int32_t *n_stations, int32_t *stations, int max_stations, int32_t *init_pos,
                  int32_t *init_dir, int32_t *target, double *speed, int32_t *earliest, int32_t *latest,
                  int32_t *max_episode_steps) {
+    return flg_generate_seeded_rail(width, height, n_agents, grid_mode, max_rails_between_cities, max_rail_pairs_in_city, n_cities,
+                                    city_positions, neighbour_order, n_speeds, speed_values, speed_probs, nullptr, nullptr, mt_key, mt_pos,
+                                    grid, city_orientations, n_stations, stations, max_stations, init_pos, init_dir, target, speed,
+                                    earliest, latest, max_episode_steps);
+}
+
+int flg_generate_seeded_rail(int width, int height, int n_agents, int grid_mode, int max_rails_between_cities, int max_rail_pairs_in_city,
+                             int n_cities, const int32_t *city_positions, const int32_t *neighbour_order, int n_speeds,
+                             const double *speed_values, const double *speed_probs, uint32_t *rail_mt_key, int *rail_mt_pos,
+                             uint32_t *mt_key, int *mt_pos, uint16_t *grid,
+                             int32_t *city_orientations, int32_t *n_stations, int32_t *stations, int max_stations, int32_t *init_pos,
+                             int32_t *init_dir, int32_t *target, double *speed, int32_t *earliest, int32_t *latest,
+                             int32_t *max_episode_steps) {
+    if ((rail_mt_key != nullptr) != (rail_mt_pos != nullptr) || (rail_mt_pos && (*rail_mt_pos < 0 || *rail_mt_pos > 624))) { set_err("flg_generate_seeded_rail: bad rail stream"); return FLG_ERR_ARG; }
     if (!city_positions || !mt_key || !mt_pos || !grid || !init_pos || !init_dir || !target || !speed || !earliest || !latest ||
         !max_episode_steps || n_cities < 2 || n_agents <= 0 || width <= 0 || height <= 0 || *mt_pos < 0 || *mt_pos > 624 ||
         (n_speeds > 0 && (!speed_values || !speed_probs))) { set_err("flg_generate: bad argument"); return FLG_ERR_ARG; }
@@ -749,7 +763,15 @@ int flg_generate(int width, int height, int n_agents, int grid_mode, int max_rai
     for (int k = 0; k < n_cities; k++) cities[k] = Cell(city_positions[2 * k], city_positions[2 * k + 1]);
     Rng rng = load_rng(mt_key, *mt_pos);
     RailOut R;
-    int rc = build_rail(width, height, plan, grid_mode != 0, cities, neighbour_order, rng, R);
+    int rc;
+    if (rail_mt_key) {  // SparseRailGen(seed=...): the rail is drawn from its own RandomState(seed) (rail_generators.py:221-222),
+                        // lines and timetable stay on the env's stream
+        Rng rail_rng = load_rng(rail_mt_key, *rail_mt_pos);
+        rc = build_rail(width, height, plan, grid_mode != 0, cities, neighbour_order, rail_rng, R);
+        store_rng(rail_rng, rail_mt_key, rail_mt_pos);
+    } else {
+        rc = build_rail(width, height, plan, grid_mode != 0, cities, neighbour_order, rng, R);
+    }
     if (rc != FLG_OK) return rc;
     const Grid &G = R.G;
     memcpy(grid, G.g.data(), G.g.size() * 2);

@@ -39,11 +39,24 @@ def barrier():
         dist.barrier()
 
 
-def reduce_metrics(metrics):
-    """all-reduce(SUM) of the int64[4] metrics tensor (sum reward, arrived, agent-steps, episodes)."""
+SCORE_SCALE = float(2 ** 32)   # fixed point of the evaluator's score sums inside the int64 metrics vector
+
+
+def reduce_metrics(metrics, scores=None):
+    """ONE all-reduce(SUM) of the int64 metrics vector (sum reward, arrived, agent-steps, episodes).  With `scores` (the
+    float64[3] tensor of BatchedRailEnv.scores(): sum of normalized rewards, sum of completion ratios, episodes) the two score
+    sums ride in the same vector as 2**-32 fixed point -- integer sums do not depend on the order the ranks are added in -- and
+    the call returns (metrics int64[4], scores float64[2]) of the whole job (flatland/evaluators/service.py:900-913 divides
+    them by the number of episodes)."""
+    if scores is None:
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+        return metrics
+    fixed = torch.round(scores[:2].to(torch.float64) * SCORE_SCALE).to(torch.int64).to(metrics.device)
+    vec = torch.cat([metrics.to(torch.int64), fixed])
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
-    return metrics
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    return vec[:4], vec[4:6].to(torch.float64) / SCORE_SCALE
 
 
 def gather_agent_steps(metrics, device=None):

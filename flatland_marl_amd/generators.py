@@ -17,7 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "gen", "libflatland_gen.so")
-SYMBOLS = ("flg_last_error", "flg_city_positions", "flg_generate")
+SYMBOLS = ("flg_last_error", "flg_city_positions", "flg_generate", "flg_generate_seeded_rail")
 _lib = None
 
 
@@ -39,6 +39,8 @@ def lib():
         L.flg_last_error.restype = C.c_char_p
         L.flg_city_positions.argtypes = [i32] * 6 + [vp, C.POINTER(i32), C.POINTER(i32), vp]
         L.flg_generate.argtypes = [i32] * 7 + [vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+        L.flg_generate_seeded_rail.argtypes = [i32] * 7 + [vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, C.POINTER(i32), vp, vp, vp, vp, i32, vp, vp, vp,
+                                               vp, vp, vp, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -104,15 +106,18 @@ def generate_env(width, height, number_of_agents, rail_generator, line_generator
     receives city_positions / city_orientations / train_stations."""
     L = lib()
     rg, lg = rail_generator, line_generator
-    if rg.seed is not None:                      # SparseRailGen(seed=...) re-seeds (rail_generators.py:221-222)
-        st = np.random.RandomState(rg.seed).get_state()
-        mt_key, mt_pos = st[1], st[2]
     key = np.ascontiguousarray(mt_key, dtype=np.uint32).copy()
     pos = C.c_int(int(mt_pos))
+    # SparseRailGen(seed=...): the rail (city positions included) comes from a private RandomState(seed)
+    # (rail_generators.py:221-222); lines, timetable and the state the env keeps afterwards stay on the env's own stream
+    rkey, rpos = key, pos
+    if rg.seed is not None:
+        st = np.random.RandomState(rg.seed).get_state()
+        rkey, rpos = np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int(int(st[2]))
     n = C.c_int(0)
     cities = np.zeros((max(rg.max_num_cities, 2), 2), dtype=np.int32)
     _chk(L.flg_city_positions(int(width), int(height), rg.max_num_cities, int(rg.grid_mode), rg.max_rails_between_cities,
-                              rg.max_rail_pairs_in_city, _p(key), C.byref(pos), C.byref(n), _p(cities)))
+                              rg.max_rail_pairs_in_city, _p(rkey), C.byref(rpos), C.byref(n), _p(cities)))
     nc = n.value
     cities = np.ascontiguousarray(cities[:nc])
     order = None
@@ -132,10 +137,12 @@ def generate_env(width, height, number_of_agents, rail_generator, line_generator
     idr, ea, la = (np.zeros(A, dtype=np.int32) for _ in range(3))
     speed = np.zeros(A, dtype=np.float64)
     T = C.c_int(0)
-    _chk(L.flg_generate(int(width), int(height), A, int(rg.grid_mode), rg.max_rails_between_cities, rg.max_rail_pairs_in_city, nc,
-                        _p(cities), None if order is None else _p(order), len(srm), _p(sv) if len(srm) else None,
-                        _p(sp) if len(srm) else None, _p(key), C.byref(pos), _p(grid), _p(orient), _p(nst), _p(stations), max_st,
-                        _p(ip), _p(idr), _p(tg), _p(speed), _p(ea), _p(la), C.byref(T)))
+    seeded = rg.seed is not None
+    _chk(L.flg_generate_seeded_rail(int(width), int(height), A, int(rg.grid_mode), rg.max_rails_between_cities, rg.max_rail_pairs_in_city,
+                                    nc, _p(cities), None if order is None else _p(order), len(srm), _p(sv) if len(srm) else None,
+                                    _p(sp) if len(srm) else None, _p(rkey) if seeded else None, C.byref(rpos) if seeded else None,
+                                    _p(key), C.byref(pos), _p(grid), _p(orient), _p(nst), _p(stations), max_st,
+                                    _p(ip), _p(idr), _p(tg), _p(speed), _p(ea), _p(la), C.byref(T)))
     if hints is not None:
         hints.update(city_positions=[tuple(map(int, c)) for c in cities], city_orientations=[int(o) for o in orient],
                      train_stations=[[((int(s[0]), int(s[1])), int(s[2])) for s in stations[c, :nst[c]]] for c in range(nc)],

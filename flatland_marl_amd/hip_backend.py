@@ -26,7 +26,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
+           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -83,6 +83,7 @@ def lib():
         L.fl_step_synth.argtypes = [vp, u32, u32, i32, vp, vp, vp, i32]
         L.fl_check.argtypes = [vp]
         L.fl_metrics.argtypes = [vp, vp, i32]
+        L.fl_scores.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
         L.fl_step_obs.argtypes = [vp, vp, u32, u32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 7 + [i32, i32, vp]
@@ -299,6 +300,15 @@ class BatchedRailEnv:
             self._metrics = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
         _chk(lib().fl_metrics(self.h, self._metrics.data_ptr(), int(reset)))
         return self._metrics
+
+    def scores(self, reset=False):
+        """float64[3] device tensor: (sum of normalized rewards, sum of completion ratios, episodes) over the episodes finished
+        since the counters were reset -- the evaluator's mean_normalized_reward / mean_percentage_complete as sums
+        (flatland/evaluators/service.py:875-879, 900-913).  Call it before metrics(reset=True): the episode count is that counter."""
+        if not hasattr(self, "_scores"):
+            self._scores = self.torch.zeros(3, dtype=self.torch.float64, device=self.device)
+        _chk(lib().fl_scores(self.h, self._scores.data_ptr(), int(reset)))
+        return self._scores
 
     def check(self):
         _chk(lib().fl_check(self.h))

@@ -217,27 +217,71 @@ class TreeObsForRailEnv(ObservationBuilder):
         return cfg, props, L["valid_actions"].astype(bool).tolist()
 
 
+NODE_FIELDS = ("dist_own_target_encountered", "dist_other_target_encountered", "dist_other_agent_encountered",
+               "dist_potential_conflict", "dist_unusable_switch", "dist_to_next_branch", "dist_min_to_target",
+               "num_agents_same_direction", "num_agents_opposite_direction", "num_agents_malfunctioning",
+               "speed_min_fractional", "num_agents_ready_to_depart")
+# flatland.envs.observations.Node (observations.py:20-32): the 12 features + the `childs` dict
+Node = collections.namedtuple("Node", NODE_FIELDS + ("childs",))
+
+
+def nodes_from_dense(arr, max_depth):
+    """the nested Node namedtuples TreeObsForRailEnv.get() returns (observations.py:117-254, 464-494) from one agent's dense
+    [N(max_depth), 12] array in DFS pre-order (node, L, F, R, B): a missing child is -inf (:247, :489), the nodes of the last
+    level have an empty `childs` dict (:491-492)."""
+    sz = [(4 ** (max_depth - d + 1) - 1) // 3 for d in range(max_depth + 2)]   # rows of a subtree rooted at depth d
+
+    def build(idx, depth):
+        childs = {}
+        if depth < max_depth:
+            for k, ch in enumerate("LFRB"):
+                c = idx + 1 + k * sz[depth + 1]
+                childs[ch] = build(c, depth + 1) if arr[c, 0] != -np.inf else -np.inf
+        return Node(*(float(v) for v in arr[idx]), childs)
+    return build(0, 0)
+
+
+def dense_from_nodes(node, max_depth):
+    """inverse of nodes_from_dense (what the golden fixtures store): [N(max_depth), 12], -inf rows for missing subtrees"""
+    rows = []
+
+    def walk(n, depth):
+        if not isinstance(n, tuple):
+            rows.extend([[-np.inf] * 12] * ((4 ** (max_depth - depth + 1) - 1) // 3))
+            return
+        rows.append([getattr(n, f) for f in NODE_FIELDS])
+        if depth < max_depth:
+            for ch in "LFRB":
+                walk(n.childs.get(ch, -np.inf), depth + 1)
+    walk(node, 0)
+    return np.array(rows, dtype=np.float64)
+
+
 class TreeObsUpstream(ObservationBuilder):
-    """flatland.envs.observations.TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense
-    float64 array per agent: [N(max_depth), 12] in DFS pre-order (node, L, F, R, B), missing subtree = -inf
-    (observations.py:20-32 gives the 12 field names, in this order)."""
+    """flatland.envs.observations.TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth))
+    (observations.py:34-532).  get_many() returns what the reference returns: {handle: Node}, nested namedtuples with a
+    `childs` dict ('L', 'F', 'R', 'B' -> Node or -inf).  get_many_dense() / the batched tensor API keep the dense form the
+    kernel writes: float64 [N(max_depth), 12] per agent in DFS pre-order (node, L, F, R, B), missing subtree = -inf."""
 
     checks_errors = True
-    FIELDS = ("dist_own_target_encountered", "dist_other_target_encountered", "dist_other_agent_encountered",
-              "dist_potential_conflict", "dist_unusable_switch", "dist_to_next_branch", "dist_min_to_target",
-              "num_agents_same_direction", "num_agents_opposite_direction", "num_agents_malfunctioning",
-              "speed_min_fractional", "num_agents_ready_to_depart")
+    FIELDS = NODE_FIELDS
+    tree_explored_actions_char = ["L", "F", "R", "B"]     # observations.py:41
 
-    def __init__(self, max_depth=2, pred_depth=30):
+    def __init__(self, max_depth=2, pred_depth=30, predictor=None):
         super().__init__()
-        self.max_depth, self.pred_depth = max_depth, pred_depth
+        self.max_depth = max_depth
+        self.pred_depth = pred_depth if predictor is None else getattr(predictor, "max_depth", pred_depth)
+        self.observation_dim = 11                         # observations.py:46
 
-    def get_many(self, handles=None):
+    def get_many_dense(self, handles=None):
         t = self.env._batch.obs_tree(self.max_depth, self.pred_depth)
         self.env._batch.check()
         arr = t[0].cpu().numpy()
         handles = range(self.env.get_num_agents()) if handles is None else handles
         return {h: arr[h] for h in handles}
+
+    def get_many(self, handles=None):
+        return {h: nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}
 
 
 class RailEnv:
@@ -268,6 +312,7 @@ class RailEnv:
             self._seed(random_seed)
         self.num_resets = 0
         self._static, self._hints, self._batch = None, None, None
+        self._from_static = False
         self.rail, self.agents, self.distance_map = None, [], None
         self._max_episode_steps = None
         self._elapsed_steps = 0
@@ -282,6 +327,10 @@ class RailEnv:
         mfp = MalfunctionParameters(float(static["malf_rate"]), int(static["malf_min"]), int(static["malf_max"]))
         env = cls(W, H, number_of_agents=len(static["init_dir"]), obs_builder_object=obs_builder_object,
                   malfunction_generator=ParamMalfunctionGen(mfp), device=device)
+        # no generators: like the reference's rail_from_file / line_from_file / timetable from a file, reset() re-adopts this
+        # same description (solution/eval_env.py:102 calls env.reset() on such an env)
+        env.rail_generator = env.line_generator = None
+        env._from_static = True
         env._adopt(static)
         return env
 
@@ -317,6 +366,11 @@ class RailEnv:
     def get_num_agents(self):
         return len(self.agents)
 
+    @property
+    def agent_positions(self):
+        """RailEnv.agent_positions (rail_env.py:341-342, 360-367): int [H, W], the handle of the agent on a cell, -1 = free"""
+        return self._batch.positions_map(0)
+
     def get_agent_handles(self):
         return range(self.get_num_agents())
 
@@ -349,9 +403,12 @@ class RailEnv:
                 st = self.np_random.get_state()
                 self._batch.set_rng_state(np.asarray(st[1], dtype=np.uint32)[None], np.array([st[2]], dtype=np.int32))
         mfp = self.malfunction_generator.MFP
-        if regenerate_rail or self._static is None:
-            if self._static is not None and self._hints is None and not isinstance(self.rail_generator, generators.SparseRailGen):
-                raise NotImplementedError("this env was created from a static description without a rail generator")
+        if self._from_static:
+            # an env loaded from a description (the reference: rail_from_file + line_from_file): the same map, the same lines and
+            # timetable again; regenerate_schedule makes fresh agents (EnvAgent.from_line, rail_env.py:315-317), without it
+            # EnvAgent.reset() keeps arrival_time (agent_utils.py:90-105).  The MT19937 stream runs on.
+            self._batch.reset(fresh=bool(regenerate_rail or regenerate_schedule))
+        elif regenerate_rail or self._static is None:
             key, pos = self._rng_state()
             hints = {}
             static = generators.generate_env(self.width, self.height, self.number_of_agents, self.rail_generator, self.line_generator,
@@ -365,13 +422,15 @@ class RailEnv:
         else:
             self._batch.reset(fresh=False)      # EnvAgent.reset() literally: arrival_time survives (agent_utils.py:90-105)
         self.num_resets += 1
+        self.obs_builder.set_env(self)      # rail_env.py:305 (a builder assigned to env.obs_builder after construction is bound here)
         self.obs_builder.reset()
         self.dones = dict.fromkeys(list(range(self.number_of_agents)) + ["__all__"], False)
         self.rewards_dict = {i: 0 for i in range(self.number_of_agents)}
         self._refresh()
         return self._get_observations(), self.get_info_dict()
 
-    def step(self, action_dict):  # rail_env.py:501-634
+    def step(self, action_dict_):  # rail_env.py:501-634
+        action_dict = action_dict_
         if self.dones["__all__"]:
             self._elapsed_steps += 1
             raise Exception("Episode is done, cannot call step()")

@@ -49,3 +49,37 @@ def forward_biased_actions(seed, b, t, n_agents):
     out[r >= 90] = 4
     out[r >= 95] = 0
     return out
+
+
+def spfollow_actions(seed, b, t, state, pos, direction, grid, dm_u16, target_slot, p_stop_percent=3):
+    """kind 2 of the on-device stream (csrc/fl_step_body.h): shortest-path following with counter-hash stops.
+    state / direction int[A], pos int[A, 2] (row, col; -1 off the map) BEFORE the step, grid u16[H, W],
+    dm_u16 [U, H, W, 4] (0xFFFF = unreachable), target_slot int[A]."""
+    A = len(state)
+    h = action_hash(seed, b, t, np.arange(A))
+    out = np.zeros(A, dtype=np.uint8)
+    for i in range(A):
+        st, d = int(state[i]), int(direction[i])
+        r, c = int(pos[i][0]), int(pos[i][1])
+        if st == 1:                       # READY_TO_DEPART
+            out[i] = 2
+        elif st < 3 or st > 5 or r < 0:   # not on the map
+            out[i] = 0
+        elif int(h[i]) % 100 < p_stop_percent:
+            out[i] = 4
+        else:
+            bits = (int(grid[r, c]) >> ((3 - d) * 4)) & 15
+            out[i] = 2
+            if bin(bits).count("1") != 1:
+                best = None
+                for a in (1, 2, 3):
+                    nd = (d + a + 2) % 4
+                    if not (bits >> (3 - nd)) & 1:
+                        continue
+                    nr, nc = r + (-1, 0, 1, 0)[nd], c + (0, 1, 0, -1)[nd]
+                    if not (0 <= nr < grid.shape[0] and 0 <= nc < grid.shape[1]) or grid[nr, nc] == 0:
+                        continue
+                    v = int(dm_u16[int(target_slot[i]), nr, nc, nd])
+                    if v != 0xFFFF and (best is None or v < best):
+                        best, out[i] = v, a
+    return out

@@ -43,6 +43,17 @@ int flg_generate(int width, int height, int n_agents, int grid_mode, int max_rai
                  int32_t *init_dir, int32_t *target, double *speed, int32_t *earliest, int32_t *latest,
                  int32_t *max_episode_steps);
 
+/* flg_generate for sparse_rail_generator(seed=s): the reference draws the RAIL (city positions included) from a private
+ * RandomState(s) (rail_generators.py:221-222) while lines, timetable and the env's stream afterwards stay on env.np_random.
+ * rail_mt_key / rail_mt_pos: that private stream (as left by flg_city_positions), advanced in place; NULL, NULL = the env's
+ * stream draws everything (= flg_generate). */
+int flg_generate_seeded_rail(int width, int height, int n_agents, int grid_mode, int max_rails_between_cities, int max_rail_pairs_in_city,
+                             int n_cities, const int32_t *city_positions, const int32_t *neighbour_order, int n_speeds,
+                             const double *speed_values, const double *speed_probs, uint32_t *rail_mt_key, int *rail_mt_pos,
+                             uint32_t *mt_key, int *mt_pos, uint16_t *grid, int32_t *city_orientations, int32_t *n_stations,
+                             int32_t *stations, int max_stations, int32_t *init_pos, int32_t *init_dir, int32_t *target,
+                             double *speed, int32_t *earliest, int32_t *latest, int32_t *max_episode_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,24 @@ enum {
     FL_ERR_CAPACITY = 6      /* an internal fixed-capacity buffer overflowed (BFS frontier, prediction index) */
 };
 
+/* Limits of this build (FL_ERR_ARG / FL_ERR_CAPACITY beyond them):
+ *   FL_MAX_AGENTS          agents per env (one lane per agent in the step kernel)
+ *   FL_MAX_SPEED_COUNT     SpeedCounter.max_count = int(1 / speed) - 1 (4 bits of the packed agent word), i.e. speed >= 1/16
+ *   FL_MAX_RAIL_CELLS      rail cells per env: rail states r * 4 + orientation are u16 (0xFFFF reserved); the observation
+ *                          kernels keep the env's rail-cell index in LDS, which holds about 6000 cells (the largest Round-2 map,
+ *                          158 x 158 / 41 cities, has 2710)
+ *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (one 32-lane team per tree; the solution uses 31)
+ *   FL_MAX_PRED_DEPTH      predictor depth of either builder (the solution uses 500 / 30)
+ *   FL_MAX_TREE_DEPTH      max_depth of the upstream TreeObsForRailEnv (85 nodes at depth 3)
+ *   every env of one batch shares (A, H, W); an env loaded into a live batch has to fit the capacities of the first
+ *   commit (fl_reserve). */
+#define FL_MAX_AGENTS 1024
+#define FL_MAX_SPEED_COUNT 15
+#define FL_MAX_RAIL_CELLS 16383
+#define FL_MAX_CUTILS_NODES 32
+#define FL_MAX_PRED_DEPTH 500
+#define FL_MAX_TREE_DEPTH 3
+
 #define FL_STEP_AUTO_RESET 1
 #define FL_STEP_FILTER_REQUIRED 2
 #define FL_ACTION_ABSENT 255 /* agent missing from the action dict (rail_env.py:527 -> DO_NOTHING) */
@@ -111,7 +129,8 @@ int fl_reset_dev(fl_batch *h, const uint8_t *mask_dev, int fresh);
 int fl_step(fl_batch *h, const uint8_t *actions_dev, int32_t *rewards_dev, uint8_t *dones_dev,
             uint8_t *done_all_dev, int auto_reset);
 /* Same, with the counter-hash synthetic action stream generated on device (flatland_marl_amd/synth.py):
- * kind 0 = uniform 0..4, 1 = forward-biased; env b uses stream id stream_base + b and its own step counter. */
+ * kind 0 = uniform 0..4, 1 = forward-biased, 2 = shortest-path following on the distance map with counter-hash stops (dense
+ * traffic, agents arrive); env b uses stream id stream_base + b and its own step counter. */
 int fl_step_synth(fl_batch *h, uint32_t seed, uint32_t stream_base, int kind, int32_t *rewards_dev,
                   uint8_t *dones_dev, uint8_t *done_all_dev, int auto_reset);
 /* RailEnv.step() returns the observations of the new state (rail_env.py:634 -> _get_observations, :660-666): fl_step /
@@ -136,6 +155,12 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
  * (sum of terminal rewards, arrived agents, agent-steps, finished episodes) -- the scalars the multi-GPU
  * harness all-reduces; mirrors eval_env.final_metric's inputs (solution/eval_env.py:81-94). */
 int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset);
+/* The evaluator's aggregate scores over every episode finished since the last reset of the counters
+ * (flatland/evaluators/service.py:875-879, 900-913: mean_normalized_reward = mean over episodes of 1 + sum(rewards) / (T * A),
+ * mean_percentage_complete = mean over episodes of arrived / A), as sums a multi-GPU harness can all-reduce:
+ * out3_dev float64[3] (device) = (sum of normalized rewards, sum of completion ratios, episodes).  The per-episode terms
+ * are accumulated on the device in double precision in episode order per env and summed over the envs in env order. */
+int fl_scores(fl_batch *h, double *out3_dev, int reset);
 /* Synchronise and return the first error any kernel recorded (FL_OK if none); clears it. */
 int fl_check(fl_batch *h);
 

@@ -22,12 +22,20 @@ from flatland.core.grid.grid_utils import Vec2dOperations  # noqa: E402
 ROWS = [("Test_0", 3), ("Test_2", 3), ("Test_3", 2), ("Test_4", 3), ("Test_8", 3), ("Test_13", 2)]   # Test_3 is taller than wide
 
 
-def capture(test_id, level, grid_mode=False):
+def capture(test_id, level, grid_mode=False, rail_seed=None, resets=1):
+    """rail_seed: sparse_rail_generator(seed=rail_seed) -- the rail from a private RandomState, lines and timetable from the env's
+    (rail_generators.py:221-222).  resets = 2: the golden is the SECOND reset() of one env (the first one's MT19937 state is the
+    input), i.e. a new map drawn from the running stream."""
     row = cg.csv_row(test_id, "Level_%d" % level)
     if grid_mode:
         row = dict(row)
         row["grid_mode"] = True
     env, mp = cg.make_env(row)
+    if rail_seed is not None:
+        env.rail_generator.seed = rail_seed
+    st_first = env.np_random.get_state()
+    for _ in range(resets - 1):
+        env.reset()
     st0 = env.np_random.get_state()
     hints = {}
     gen = env.rail_generator
@@ -59,8 +67,15 @@ def capture(test_id, level, grid_mode=False):
                mt_key_before=np.asarray(st0[1], dtype=np.uint32), mt_pos_before=np.int32(st0[2]),
                city_positions=cp, city_orientations=np.array([int(o) for o in hints["city_orientations"]], dtype=np.int32),
                neighbour_order=order, n_stations=ns, stations=stations)
+    if rail_seed is not None:
+        out["rail_seed"] = np.int64(rail_seed)
+    if resets > 1:   # the state the env was seeded with, before its first reset()
+        out["mt_key_first"] = np.asarray(st_first[1], dtype=np.uint32)
+        out["mt_pos_first"] = np.int32(st_first[2])
+        out["resets"] = np.int32(resets)
     assert np.array_equal(out["mt_key"], st1[1]) and int(out["mt_pos"]) == st1[2]
-    name = "gen_%s_L%d%s" % (test_id, level, "_grid" if grid_mode else "")
+    name = "gen_%s_L%d%s%s%s" % (test_id, level, "_grid" if grid_mode else "", "_railseed%d" % rail_seed if rail_seed is not None else "",
+                                 "_reset%d" % resets if resets > 1 else "")
     path = os.path.join(cg.GOLD, name + ".npz")
     np.savez_compressed(path, **out)
     print(name, "%dx%d" % (row["x_dim"], row["y_dim"]), "cities", len(cp), "agents", row["n_agents"], "T", int(out["T"]),
@@ -77,3 +92,12 @@ if __name__ == "__main__":
     if not only or "grid" in only:
         capture("Test_2", 5, grid_mode=True)
         capture("Test_4", 4, grid_mode=True)
+    if not only or "seeded" in only:      # sparse_rail_generator(seed=...)
+        capture("Test_2", 6, rail_seed=7)
+        capture("Test_4", 3, rail_seed=123)
+    if not only or "reset2" in only:      # two consecutive reset() calls on one MT19937 stream
+        capture("Test_2", 0, resets=2)
+        capture("Test_4", 1, resets=2)
+        capture("Test_0", 0, resets=3)
+    if not only or "Test_14" in only:     # the largest Round-2 map: 158x158, 425 agents, 41 cities
+        capture("Test_14", 0)

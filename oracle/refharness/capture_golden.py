@@ -441,6 +441,9 @@ JOBS = {
                                              snap_onmap=(25, 40, 50), pytree=[(3, 30)]),
     "dense_cfg5_spfollow": lambda: run_dense("dense_cfg5_spfollow", "Test_13", "Level_0", seed=42, max_steps=900,
                                              snap_onmap=(60, 100, 150), pytree=[(3, 30)]),
+    # the largest Round-2 map: Test_14 = 158x158, 425 agents, 41 cities; first 320 steps of a shortest-path-following stream
+    "test14_spfollow_head": lambda: run_episode("test14_spfollow_head", "Test_14", "Level_0", "spfollow", seed=71, max_steps=320,
+                                                obs_every=80, pytree=[(3, 30)], pytree_every=160),
 }
 for lv in range(1, 8):
     JOBS[f"base_cfg2_L{lv}"] = (lambda lv=lv: static_only(f"base_cfg2_L{lv}", "Test_2", f"Level_{lv}"))

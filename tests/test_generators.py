@@ -23,7 +23,8 @@ def built():
 def _run(fx, order="numpy"):
     rg = gen.sparse_rail_generator(max_num_cities=int(fx["max_num_cities"]), grid_mode=bool(fx["grid_mode"]),
                                    max_rails_between_cities=int(fx["max_rails_between_cities"]),
-                                   max_rail_pairs_in_city=int(fx["max_rail_pairs_in_city"]))
+                                   max_rail_pairs_in_city=int(fx["max_rail_pairs_in_city"]),
+                                   seed=int(fx["rail_seed"]) if "rail_seed" in fx else None)   # a private rail stream (rail_generators.py:221-222)
     lg = gen.sparse_line_generator(dict(zip(fx["speed_values"].tolist(), fx["speed_probs"].tolist())))
     hints = {}
     st = gen.generate_env(int(fx["width"]), int(fx["height"]), int(fx["n_agents"]), rg, lg, fx["mt_key_before"], int(fx["mt_pos_before"]),
@@ -64,8 +65,9 @@ def test_seed_to_state_restatement_matches_the_capture_stub():
     for name in GEN[:4]:
         fx = util.load(name)
         st = gen.np_random(int(fx["random_seed"])).get_state()
-        np.testing.assert_array_equal(st[1], fx["mt_key_before"])
-        assert st[2] == int(fx["mt_pos_before"])
+        first = "mt_key_first" in fx      # a later reset(): the seeded state is the one before the FIRST reset
+        np.testing.assert_array_equal(st[1], fx["mt_key_first" if first else "mt_key_before"])
+        assert st[2] == int(fx["mt_pos_first" if first else "mt_pos_before"])
 
 
 def test_infeasible_map_raises_like_the_reference():
@@ -82,3 +84,26 @@ def test_stable_order_equals_numpy_order_without_ties():
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
 
+
+
+@pytest.mark.parametrize("name", [n for n in GEN if "_reset" in n])
+def test_consecutive_resets_on_one_stream(name):
+    """RailEnv.reset() called again draws a NEW map from the running MT19937 stream: starting from the state the env was
+    seeded with, the n-th generate_env() has to land on the reference's n-th reset() (inputs of every reset but the last are
+    only the stream state the one before left behind)"""
+    fx = util.load(name)
+    rg = gen.sparse_rail_generator(max_num_cities=int(fx["max_num_cities"]), grid_mode=bool(fx["grid_mode"]),
+                                   max_rails_between_cities=int(fx["max_rails_between_cities"]),
+                                   max_rail_pairs_in_city=int(fx["max_rail_pairs_in_city"]))
+    lg = gen.sparse_line_generator(dict(zip(fx["speed_values"].tolist(), fx["speed_probs"].tolist())))
+    key, pos = fx["mt_key_first"], int(fx["mt_pos_first"])
+    st = None
+    for k in range(int(fx["resets"])):
+        if k == int(fx["resets"]) - 1:
+            np.testing.assert_array_equal(key, fx["mt_key_before"])
+            assert pos == int(fx["mt_pos_before"])
+        st = gen.generate_env(int(fx["width"]), int(fx["height"]), int(fx["n_agents"]), rg, lg, key, pos, float(fx["malf_rate"]),
+                              int(fx["malf_min"]), int(fx["malf_max"]))
+        key, pos = st["mt_key"], int(st["mt_pos"])
+    for k in ("grid", "init_pos", "init_dir", "target", "speed", "earliest", "latest", "T", "mt_key", "mt_pos"):
+        np.testing.assert_array_equal(st[k], fx[k], err_msg=k)

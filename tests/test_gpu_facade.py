@@ -62,19 +62,35 @@ def test_facade_episode_matches_reference(name):
     np.testing.assert_array_equal(dm, exp)
 
 
-def test_upstream_tree_builder_and_positions_map():
-    from flatland_marl_amd.rail_env import RailEnv, TreeObsUpstream
+@pytest.mark.parametrize("depth", [2, 3])
+def test_upstream_tree_builder_and_positions_map(depth):
+    """TreeObsUpstream.get_many() returns the reference's nested Node namedtuples (observations.py:20-32, 239-254, 464-494):
+    walked through `childs` and flattened the way the capture script flattens the reference's, they are the golden trees"""
+    from flatland_marl_amd.rail_env import RailEnv, TreeObsUpstream, Node, dense_from_nodes
     fx = util.load("cfg1_uniform")
-    env = RailEnv.from_static(util.static_of(fx), obs_builder_object=TreeObsUpstream(2, 30))
+    env = RailEnv.from_static(util.static_of(fx), obs_builder_object=TreeObsUpstream(depth, 30))
     obs, _ = env.reset(False, False)
+    key = "py_d%d_p30" % depth
     py_steps = {int(t): k for k, t in enumerate(fx["py_steps"])}
-    np.testing.assert_array_equal(np.stack([obs[i] for i in range(env.get_num_agents())]), fx["py_d2_p30"][py_steps[0]])
+    A = env.get_num_agents()
+
+    def flat(o):
+        assert sorted(o) == list(range(A)) and all(isinstance(o[i], Node) for i in range(A))
+        return np.stack([dense_from_nodes(o[i], depth) for i in range(A)])
+    np.testing.assert_array_equal(flat(obs), fx[key][py_steps[0]])
     for t, row in enumerate(fx["actions"][:60]):
         obs, _, _, _ = env.step(_action_dict(row))
         if (t + 1) in py_steps:
-            np.testing.assert_array_equal(np.stack([obs[i] for i in range(env.get_num_agents())]),
-                                          fx["py_d2_p30"][py_steps[t + 1]])
-    pm = env._batch.positions_map(0)
+            np.testing.assert_array_equal(flat(obs), fx[key][py_steps[t + 1]])
+    root = obs[0]
+    assert set(root.childs) == {"L", "F", "R", "B"} and root.dist_own_target_encountered == 0
+    for ch in root.childs.values():     # a child is a Node or -inf; the last level has no children
+        assert ch == -np.inf or (isinstance(ch, Node) and (set(ch.childs) == {"L", "F", "R", "B"} if depth > 1 else ch.childs == {}))
+    one = env.obs_builder.get(2)
+    assert isinstance(one, Node)
+    np.testing.assert_array_equal(env.obs_builder.get_many_dense([2])[2], dense_from_nodes(one, depth))
+    np.testing.assert_array_equal(env.agent_positions, env._batch.positions_map(0))
+    pm = env.agent_positions
     exp = np.full((env.height, env.width), -1, dtype=np.int32)
     for i, (r, c) in enumerate(zip(fx["s_row"][59], fx["s_col"][59])):
         if r >= 0:
@@ -119,3 +135,27 @@ def test_reference_style_constructor_generates_the_golden_env_and_steps_like_it(
     env.step({i: 2 for i in range(A)})
     env.reset(False, False)
     assert env._elapsed_steps == 0 and np.array_equal(env.rail.grid, env._static["grid"])
+
+
+def test_reset_of_an_env_loaded_from_a_description_keeps_its_map():
+    """LocalTestEnvWrapper.reset() calls env.reset() with the defaults (solution/eval_env.py:102): on an env that was loaded from a
+    description (the reference: rail_from_file / line_from_file) that re-adopts the SAME map, lines and timetable and starts the
+    episode over with fresh agents; the MT19937 stream runs on"""
+    from flatland_marl_amd.rail_env import RailEnv, TreeObsForRailEnv, LocalTestEnvWrapper
+    fx = util.load("cfg1_spfollow")
+    env = RailEnv.from_static(util.static_of(fx), obs_builder_object=TreeObsForRailEnv(31, 500))
+    wrapper = LocalTestEnvWrapper(env)
+    obs = wrapper.reset()
+    np.testing.assert_array_equal(env.rail.grid, fx["grid"])
+    assert env._max_episode_steps == int(fx["T"])
+    np.testing.assert_array_equal(obs[0]["agent_attr"].astype(np.float32), fx["o_attr"][0])
+    A = env.get_num_agents()
+    for t, row in enumerate(util.actions_of(fx)[:40]):      # the stream was not touched: the golden episode follows
+        _, rew, dones, info = env.step(_action_dict(row))
+        assert [int(info["state"][i]) for i in range(A)] == fx["s_state"][t].tolist()
+        assert [info["malfunction"][i] for i in range(A)] == fx["s_malf"][t].tolist()
+    key_before = env._batch.rng_state()[0].copy()
+    wrapper.reset()                                          # again, mid-episode
+    np.testing.assert_array_equal(env.rail.grid, fx["grid"])
+    assert env._elapsed_steps == 0 and all(a.position is None and a.arrival_time is None for a in env.agents)
+    np.testing.assert_array_equal(env._batch.rng_state()[0], key_before)

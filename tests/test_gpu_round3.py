@@ -1,0 +1,151 @@
+"""GPU, round 3: the evaluator's aggregate scores as device sums (fl_scores), the refusal of a position off the rail
+(fl_set_state), the on-device shortest-path-following action stream shadowed by the oracle, distinct generated maps in one
+batch, and bench.py starting its own ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(envs, **kw):
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    return BatchedRailEnv(envs, **kw)
+
+
+def test_score_sums_equal_the_reference_evaluator_scores():
+    """fl_scores = sum over finished episodes of (1 + R / (T * A), arrived / A) (flatland/evaluators/service.py:875-879, 900-913):
+    two replicas of the golden `cfg2_filtered` episode, one of them run twice (auto-reset), against the scores the capture
+    script computed from the reference env"""
+    import torch
+    fx = util.load("cfg2_filtered")
+    st = util.static_of(fx)
+    env = _env([st, dict(st)])
+    raw = np.array(fx["actions"], dtype=np.uint8)
+    for t in range(len(raw)):
+        a = torch.from_numpy(np.stack([raw[t], raw[t]])).cuda()
+        _, _, done_all = env.step(a, filter_required=True)
+    assert done_all.cpu().numpy().tolist() == [1, 1]
+    s = env.scores().cpu().numpy()
+    exp = fx["evaluator_scores"]
+    assert s[2] == 2 and s[0] == exp[0] + exp[0] and s[1] == exp[1] + exp[1]
+    m = env.metrics().cpu().numpy()
+    assert m[3] == 2
+    # the all-reduce helper carries the two sums as 2**-32 fixed point beside the int64 metrics (world size 1 here)
+    from flatland_marl_amd import dist_utils
+    mm, ss = dist_utils.reduce_metrics(env.metrics().clone(), env.scores().clone())
+    assert mm.cpu().numpy().tolist() == m.tolist()
+    np.testing.assert_allclose(ss.cpu().numpy(), s[:2], rtol=0, atol=2.0 ** -32)
+    # reset of the counters
+    env.scores(reset=True)
+    env.metrics(reset=True)
+    assert env.scores().cpu().numpy().tolist() == [0.0, 0.0, 0.0]
+    env.check()
+
+
+def test_set_state_refuses_a_position_off_the_rail():
+    from flatland_marl_amd.hip_backend import FlatlandHipError
+    fx = util.load("cfg1_uniform")
+    env = _env([util.static_of(fx)])
+    grid = np.asarray(fx["grid"])
+    empty = np.argwhere(grid == 0)[0]
+    st, _ = env.state()
+    st[0, 0, 0], st[0, 0, 1], st[0, 0, 3] = empty[0], empty[1], 3          # MOVING on a cell without rail
+    with pytest.raises(FlatlandHipError, match="FL_ERR_STATE_SYNC"):
+        env.set_state(st)
+    st, _ = env.state()
+    st[0, 1, 9], st[0, 1, 10] = empty[0], empty[1]                          # old_position off the rail
+    with pytest.raises(FlatlandHipError, match="FL_ERR_STATE_SYNC"):
+        env.set_state(st)
+    env.step_synth(1, 0, 0, auto_reset=False)                               # the batch is untouched and keeps running
+    env.obs_cutils()
+    env.check()
+
+
+@pytest.mark.parametrize("name,steps", [("cfg2_uniform", 400), ("cfg3_uniform", 250)])
+def test_shortest_path_following_stream_is_shadowed_by_the_oracle(name, steps):
+    """kind 2 of the on-device action stream: the oracle gets the actions synth.spfollow_actions derives on the host from ITS
+    state; states, rewards, dones and the observations have to stay equal -- under dense traffic, with arrivals"""
+    from flatland_marl_amd import synth
+    from oracle import orc
+    fx = util.load(name)
+    st = util.static_of(fx)
+    envs = [st, dict(st)]
+    envs[1]["mt_key"], envs[1]["mt_pos"] = np.random.RandomState([5]).get_state()[1:3]
+    env = _env(envs)
+    oracles = [orc.OracleEnv(e) for e in envs]
+    dm, slot = oracles[0].distance_map()
+    seed, arrived, tc = 9, 0, [0, 0]
+    for t in range(steps):
+        acts = []
+        for b, o in enumerate(oracles):
+            s = o.state()
+            acts.append(synth.spfollow_actions(seed, b, tc[b], s[:, 3], s[:, 0:2], s[:, 2], np.asarray(st["grid"]), dm, slot))
+        rew, done, done_all = env.step_synth(seed, 0, 2, auto_reset=True)
+        obs = env.obs_cutils()
+        got, _ = env.state()
+        for b, o in enumerate(oracles):
+            r_o, d_o, da = o.step(acts[b])
+            tc[b] += 1
+            np.testing.assert_array_equal(got[b], o.state(), err_msg=f"env {b} step {t}")
+            np.testing.assert_array_equal(rew.cpu().numpy()[b], r_o)
+            assert bool(done_all.cpu().numpy()[b]) == da
+            exp = o.obs_cutils(31, 500)
+            if t % 10 == 0:
+                np.testing.assert_array_equal(obs["forest"].cpu().numpy()[b], exp["forest"], err_msg=f"forest env {b} step {t}")
+            if da:
+                arrived += int((o.state()[:, 3] == 6).sum())
+                key, pos = o.get_rng()
+                oracles[b] = orc.OracleEnv(envs[b])
+                oracles[b].set_rng(key, pos)
+                tc[b] = 0
+    env.check()
+    assert arrived >= env.A // 2, "the stream is supposed to bring agents to their targets"
+
+
+def test_distinct_generated_maps_in_one_batch_match_the_oracle():
+    from flatland_marl_amd import synth, workload as wl
+    from oracle import orc
+    envs, seed = wl.make_envs("cfg2", B=10, distinct=10)
+    assert len({e["grid"].tobytes() for e in envs}) == 10
+    env = _env(envs)
+    oracles = [orc.OracleEnv(e) for e in envs]
+    for t in range(60):
+        rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=False)
+        o, tree = env.obs_both(2, 30)
+        st, _ = env.state()
+        for b, orc_env in enumerate(oracles):
+            orc_env.step(synth.uniform_actions(seed, b, t, env.A))
+            np.testing.assert_array_equal(st[b], orc_env.state(), err_msg=f"env {b} step {t}")
+            exp = orc_env.obs_cutils(31, 500)
+            if t % 6 == 0:
+                np.testing.assert_array_equal(o["forest"].cpu().numpy()[b], exp["forest"])
+                np.testing.assert_array_equal(o["agent_attr"].cpu().numpy()[b], exp["attr"])
+                np.testing.assert_array_equal(tree.cpu().numpy()[b], orc_env.obs_pytree(2, 30))
+    env.check()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks before any GPU call and relays rank 0's line
+    (here both ranks share the one GPU of the box: FL_DIST_BACKEND=gloo)"""
+    env = dict(os.environ, FL_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--envs", "8",
+                        "--no-dephase", "--event-steps", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["agent_steps_per_rank"]) == 2
+    A = d["config"]["agents"]
+    assert d["agent_steps_per_rank"] == [8 * A * 12, 8 * A * 12] and d["agent_steps"] == 2 * 8 * A * 12
+    assert abs(d["value"] - 2 * 8 * A * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 1e-6 * d["value"]     # sum over ranks / max time
+    assert "cpu_baseline" not in d and d["scaling"] == "weak"
+    assert d["roofline"]["frac"] > 0 and "note" in d["roofline"]
