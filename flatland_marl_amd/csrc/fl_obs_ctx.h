@@ -1,0 +1,181 @@
+// fl_obs_ctx.h -- context of one observation build (the env's LDS-resident tables and per-agent snapshot), the static
+// topology of a branch walk, and the node tables of the trees.  Device code; included by fl_obs_body.h.
+#pragma once
+#include <stdio.h>
+#include <type_traits>
+
+#include "../../include/flatland_hip.h"
+#include "fl_obs_layout.h"
+
+struct ObsCtx {
+    int A, R;
+    int SS;                       // stride (in rail states) between the per-target slabs of dm / hop8
+    const uint32_t *cellw;        // LDS per rail cell: rail bitmap (low 16) | occupied-cell table index (high 16, 0xFFFF = none)
+    const uint16_t *nbr;          // LDS [R * 4]: rail index of the neighbour in direction m, FL_R_NONE
+    const uint16_t *snext;        // LDS [R * 4] successor of a single-transition state, or nullptr (derived from cellw + nbr)
+    const uint16_t *rkey;         // LDS [R] compact prediction key (col * W + row collides when H > W, tool.h:391-398); nullptr: key = r
+    const int *slot_agent;        // LDS: highest on-map handle on the cell (last writer of location_has_agent*), -1
+    const int *slot_ready;        // LDS: number of off-map agents whose initial position is the cell
+    const uint32_t *cell_target;  // LDS bitmap over rail cells: some agent's target (upstream location_has_target)
+    const uint16_t *a_vpos;       // LDS per agent: virtual position (rail index)
+    const uint8_t *a_dir, *a_state;
+    const uint16_t *a_malf;       // real down counter
+    const double *a_speed;
+    const uint16_t *a_tpc;        // times per cell of the predictor
+    const double *a_tq;           // time per cell of the tree walk: float 1.0 / speed of cutils (treeobs.cpp:304, held exactly
+                                  // in a double) or np.reciprocal(speed) of the upstream builder (observations.py:277)
+    const uint16_t *a_tslot;
+    const uint16_t *a_target;     // rail index
+    const uint16_t *a_srank;      // rank of the agent's speed among the env's agents (number of slower agents; static, host-computed)
+    const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
+    const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
+    const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
+    const uint16_t *bk_rel;       // HBM [K * OBS_BK_NB]: end of time bucket b inside key k's list, relative to the list's start;
+                                  // nullptr = lists not bucketed
+    int Tn;                       // number of predicted time entries (0 = no predictor)
+    const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
+    const uint4 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
+    // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
+    uint2 *wl_occ, *wl_cf;
+    int wl_occ_cap, wl_cf_cap;
+    bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
+    int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
+    const int *long_lists;        // LDS flag: some key's list has more than CF_DIRECT items (else no conflict query needs chunks)
+    const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
+    int tshift;
+    // pass B over the trees of BOTH builders at once (PB = 2): teams below n_cu are flatland_cutils trees and use the members
+    // above, the others are upstream trees and use the upstream predictor's index:
+    int n_cu;
+    const int *u_csr_end;
+    const uint32_t *u_items;
+    const unsigned long long *u_tmask;
+    int u_Tn, u_tshift;
+    const double *a_tq2;          // np.reciprocal(speed)
+    // Own-path filter of the classify loop (small envs): a cell that is waypoint tot of the walking agent's own predicted
+    // path always has that agent's own item around the queried time.  tmask_m2 / u_tmask_m2 = buckets covered by at least
+    // TWO items of the key, so the own item's buckets can be taken out of the test exactly; nullptr = no filter.
+    const unsigned long long *tmask_m2, *u_tmask_m2;
+    const uint16_t *path;         // HBM [A][pred_cap] predicted paths of the env (state per waypoint)
+    int pred_cap;
+    const uint16_t *a_lp, *a_lp2, *a_tpc2;  // last waypoint in the first / second index, times per cell of the second
+    long long *dbg;               // diagnostic builds
+    int dbg_base;
+};
+
+__device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int r) { return X.cellw[r] & 0xFFFFu; }
+// occupied-cell table index of the cell, 0xFFFF = nobody on it and nobody waiting to depart from it
+__device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int r) { return X.cellw[r] >> 16; }
+__device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int r) { return X.cellw[r]; }
+__device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? (int)X.rkey[r] : r; }
+// Pass B serves one builder (PB 0 = upstream, 1 = flatland_cutils) or both in one pass (PB 2): cu says which builder's
+// rules apply to a team
+template <int PB>
+__device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 2 ? team < X.n_cu : PB == 1; }
+// the agent of a team: from the team table, or -- both builders in one pass -- from the numbering of trees_merged (no memory access)
+template <int PB>
+__device__ __forceinline__ int pb_handle(const ObsCtx &X, const int *team_meta, int team) {
+    return PB == 2 ? (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
+}
+// predicted time at which the walking agent reaches a cell tot steps away (treeobs.cpp:378 / observations.py:329)
+template <int PB>
+__device__ __forceinline__ int pt_of(const ObsCtx &X, bool cu, int handle, int tot) {
+    if (PB == 2 && !cu) return (int)((double)tot * X.a_tq2[handle]);
+    return cu ? (int)((float)tot * (float)X.a_tq[handle]) : (int)((double)tot * X.a_tq[handle]);
+}
+// items of rail cell r's key a conflict query at predicted time pt has to look at: [lo, hi)
+template <int PB>
+__device__ __forceinline__ void list_range(const ObsCtx &X, bool cu, int r, int pt, int &lo, int &hi) {
+    const int key = key_of(X, r);
+    if (PB == 2 && !cu) {
+        lo = key > 0 ? X.u_csr_end[key - 1] : 0;
+        hi = X.u_csr_end[key];
+        return;
+    }
+    const int base = key > 0 ? X.csr_end[key - 1] : 0;
+    if (X.bk_rel) {
+        const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+        const uint16_t *rel = X.bk_rel + (size_t)key * OBS_BK_NB;
+        lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
+        hi = base + (int)rel[b2];
+    } else {
+        lo = base;
+        hi = X.csr_end[key];
+    }
+}
+// successor of a state with exactly one transition (chain interior): one LDS load when the table is resident
+__device__ __forceinline__ uint32_t chain_next(const ObsCtx &X, uint32_t s, uint32_t bits16) {
+    if (X.snext) return X.snext[s];
+    const uint32_t nd = first_dir(nibble(bits16, s & 3u));
+    return ((uint32_t)X.nbr[(s & ~3u) | nd] << 2) | nd;
+}
+// state reached by leaving rail cell r in direction m, -1 when there is no rail there
+__device__ __forceinline__ int state_towards(const ObsCtx &X, int r, uint32_t m) {
+    const uint32_t nr = X.nbr[r * 4 + (int)m];
+    return nr == FL_R_NONE ? -1 : (int)((nr << 2) | m);
+}
+
+// One node of a tree = one branch walk (_explore_branch: treeobs.cpp:258-610 / observations.py:256-494).
+// Where the walk ends, how long it is and its first "unusable switch" are static per start state (segment table,
+// fl_dmap.hip); the stop at the agent's own target follows from the distance map: along a chain of single-transition
+// cells the distance drops by one per step, so the target is on the chain iff dm[start] <= chain length.
+struct NodeDesc {
+    int start;      // start state cell << 2 | dir, -1 = null cell
+    int tot0;       // tot_dist at the first visited cell
+    int nvis;       // number of visited cells (feature block executions)
+    int end;        // end state (direction unknown / irrelevant when the walk stops at the target)
+    uint32_t flags; // bit 0 target stop, 1 switch, 2 dead end, 3 terminal (zero transition or cycle), 4 zero transition
+    int unus;       // tot_dist of the first unusable switch or -1
+    uint32_t kids01, kids23;  // start states of the end state's children (u16 each, FL_R_NONE = null), valid for switch / dead end
+};
+
+// dm_t = the distance slab of the agent's target, target = its rail index (per-agent constants, hoisted by the callers)
+__device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, const uint16_t *dm_t, int target, int start, int tot0) {
+    NodeDesc n;
+    n.start = start;
+    n.tot0 = tot0;
+    const uint4 e = X.seg[start];
+    const uint32_t dv = dm_t[start];
+    const int len = SEG_LEN(e), unus = SEG_UNUS(e);
+    n.kids01 = e.z; n.kids23 = e.w;
+    if (dv != FL_INF16 && (int)dv <= len) {  // reaches its own target first
+        n.nvis = (int)dv + 1;
+        n.end = target << 2;
+        n.flags = ND_TARGET;
+        n.unus = (unus != 0xFFFF && unus < (int)dv) ? tot0 + unus : -1;  // the target cell breaks before that check
+    } else {
+        n.nvis = len + 1;
+        n.end = SEG_END(e);
+        const uint32_t k = SEG_KIND(e);
+        n.flags = k == SEG_SWITCH ? ND_SWITCH : k == SEG_DEAD_END ? ND_DEAD_END : k == SEG_ZERO ? (ND_TERMINAL | ND_ZERO) : ND_TERMINAL;
+        n.unus = unus != 0xFFFF ? tot0 + unus : -1;
+    }
+    return n;
+}
+
+// advance k cells along a chain of single-transition cells (no features)
+__device__ __forceinline__ uint32_t skip_cells(const ObsCtx &X, uint32_t s, int k) {
+    for (int v = 0; v < k; v++) s = chain_next(X, s, X.snext ? 0u : cw_bits(X, (int)(s >> 2)));
+    return s;
+}
+
+// ---- node tables (fl_obs_layout.h): word w of node k of a table with `cap` slots
+__device__ __forceinline__ int &nt_w(int *scr, int cap, int w, int k) { return scr[w * cap + k]; }
+__device__ __forceinline__ int nt_r(const int *scr, int cap, int w, int k) { return scr[w * cap + k]; }
+__device__ __forceinline__ int nt_start(uint32_t se) { const uint32_t s = se & 0xFFFFu; return s == N_NONE ? -1 : (int)s; }
+__device__ __forceinline__ int nt_end(uint32_t se) { return (int)(se >> 16); }
+__device__ __forceinline__ int nt_tot(uint32_t tv) { return (int)(tv & 0xFFFFu); }
+__device__ __forceinline__ int nt_vis(uint32_t tv) { return (int)(tv >> 16); }
+__device__ __forceinline__ int nt_unus(uint32_t uf) { const uint32_t u = uf & 0xFFFFu; return u == 0xFFFFu ? -1 : (int)u; }
+__device__ __forceinline__ uint32_t nt_flags(uint32_t uf) { return (uf >> 16) & 31u; }
+__device__ __forceinline__ int nt_row(uint32_t uf) { return (int)((uf >> 21) & 127u); }
+// descriptor of a node into its slot; err: latched when a distance does not fit 16 bits (no Flatland map comes close)
+__device__ __forceinline__ void nt_store_desc(int *scr, int cap, int k, const NodeDesc &nd, int row, int *err) {
+    if ((uint32_t)(nd.tot0 + nd.nvis) > 0xFFFEu && err) atomicCAS(err, 0, FL_ERR_CAPACITY);
+    nt_w(scr, cap, N_SE, k) = (int)(((uint32_t)nd.start & 0xFFFFu) | ((uint32_t)nd.end << 16));
+    nt_w(scr, cap, N_TV, k) = (int)(((uint32_t)nd.tot0 & 0xFFFFu) | ((uint32_t)nd.nvis << 16));
+    nt_w(scr, cap, N_UF, k) = (int)(((uint32_t)(nd.unus < 0 ? 0xFFFF : nd.unus) & 0xFFFFu) | (nd.flags << 16) | ((uint32_t)row << 21));
+}
+__device__ __forceinline__ void nt_clear_desc(int *scr, int cap, int k) {
+    nt_w(scr, cap, N_SE, k) = (int)N_NONE;
+    nt_w(scr, cap, N_TV, k) = 0;
+}

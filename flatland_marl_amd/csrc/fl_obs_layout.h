@@ -1,0 +1,114 @@
+// fl_obs_layout.h -- what the host side (fl_obs.hip: LDS carving, launch configuration) and the device side (fl_obs_*.h) of
+// the observation kernels share: tunables, the packing of a prediction item, the node tables of the trees, the list of LDS
+// arrays of a launch and the launch arguments.
+#pragma once
+#include <stdint.h>
+
+#include "fl_obs.h"
+
+#define OBS_NT 1024
+#ifndef CF_CHUNK
+#define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
+#endif
+#ifndef OBS_GLB_BATCH
+#define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
+#endif
+#ifndef OBS_WL_OCC_DIV
+#define OBS_WL_OCC_DIV 6            // occupant work list = 1 / OBS_WL_OCC_DIV of the work-list entries, conflicts get the rest
+#endif
+#ifndef OBS_TSHIFT
+#define OBS_TSHIFT 1                 // time-bucket width of the per-key masks for long horizons: 1 << OBS_TSHIFT steps
+#endif
+#define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
+#define CF_DIRECT 32                 // when no list of the env is longer, every conflict entry is scanned by its lane alone, in one pass
+#define OBS_ITEMS2_CAP 4096          // items of the second (upstream) index built by stage 1 of the fused launch
+#define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
+#define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
+// Large maps (items in HBM, hundreds of agents): inside a key's list the items are grouped by bucket of 64 time steps, an
+// item sits in every bucket its interval touches, and a conflict query scans only the buckets its three time steps fall in
+// (an eighth of a busy cell's list instead of all of it).
+#define OBS_BK_NB 8
+#define OBS_BK_SHIFT 6
+
+// prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
+//   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
+//   6-9 interval length - 1, 10 "until the end of the horizon", 11-19 t_lo, 20-29 agent
+#define IT_DIR(it) ((it)&3u)
+#define IT_DNEXT(it) (((it) >> 2) & 3u)
+#define IT_DPREV(it) (((it) >> 4) & 3u)
+#define IT_THI(it, tlast) ((((it) >> 10) & 1u) ? (uint32_t)(tlast) : IT_TLO(it) + (((it) >> 6) & 15u))
+#define IT_TLO(it) (((it) >> 11) & 511u)
+#define IT_TOEND(it) (((it) >> 10) & 1u)
+#define IT_AGENT(it) ((int)((it) >> 20))
+
+// Node table of one tree (= one pass B team) in LDS: field-major, CAP entries per 32-bit word-field.  Descriptor words are
+// written by pass A, the accumulators are merged by the event handlers of pass B with LDS atomics.
+//   N_SE    start state (lo16, 0xFFFF = no node) | end state (hi16)
+//   N_TV    tot_dist at the first visited cell (lo16) | number of visited cells (hi16)
+//   N_UF    tot_dist of the first unusable switch (lo16, 0xFFFF = none) | ND_* flags (bits 16-20) | DFS row of the node (bits 21-27, upstream)
+//   N_INCL  inclusive prefix of the visit counts (24 bits) | next node with cells << 24 (0xFF = none)   (team_prepare)
+//   N_OA, N_PC   min tot_dist of "other agent encountered" / "potential conflict" (0x7fffffff = none)
+//   N_CNT   agents in the same direction (lo16) | in the opposite direction (hi16)
+//   N_RM    agents ready to depart (lo16) | flatland_cutils: "some occupant is malfunctioning" (bit 16)
+//   N_MS    slowest occupant in the same direction: speed rank << 10 | agent (0xFFFFFFFF = none); the speed is static per agent
+//           and the ranks are computed on the host, so the minimum of a double is a 32-bit atomicMin
+//   N_PH    flatland_cutils: parent + 2 (bits 0-7) | (first child's node index << 2 | action + 1) << 8
+//   N_OT, N_MALF   upstream: min tot_dist of "other target encountered", max malfunction down counter of an occupant
+enum { N_SE = 0, N_TV, N_UF, N_INCL, N_OA, N_PC, N_CNT, N_RM, N_MS, N_PH, N_WORDS_C = 10, N_OT = 9, N_MALF = 10, N_WORDS_T = 11 };
+#define N_NONE 0xFFFFu
+enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO = 16 };
+
+// flatland_cutils trees: 32-lane team, 32 slots (max_nodes <= 32).  Upstream trees: on maps where no (cell, direction) has
+// more than two transitions -- every Flatland rail cell type -- level L has at most 2^L nodes, a depth-3 tree 14: a 16-lane
+// team with 16 slots (four trees a wavefront).  Any other grid: one slot per DFS row (32 lanes / 32 slots up to depth 2,
+// 64 lanes / 88 slots at depth 3).
+#define OBS_CAP_C 32
+#define OBS_CAP_T_COMPACT 16
+
+// LDS words of the trees' node tables: one slot per team that can hold an agent plus one dummy slot that the idle teams share
+__host__ __device__ inline int obs_scr_words(int nwaves, int A, int tw_c, int tw_t, int tpw_t) {
+    const int n_c = 2 * nwaves <= A ? 2 * nwaves : A + 1, n_t = tpw_t * nwaves <= A ? tpw_t * nwaves : A + 1;
+    const int w_c = n_c * tw_c, w_t = n_t * tw_t;
+    return w_c > w_t ? w_c : w_t;
+}
+
+// LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
+enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
+       L_A_TARGET, L_A_MALF, L_A_TPC, L_A_TQ, L_A_TQ2, L_A_RAW, L_RTYPE, L_A_LP, L_A_N, L_A_SRANK, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
+       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_TMASK2, L_NH, L_CSR2, L_TMASKB, L_TMASKB2, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
+#define L_ABSENT 0xFFFFFFFFu
+struct ObsLayout {
+    unsigned off[L_COUNT];  // byte offset into the dynamic LDS, L_ABSENT = not in this launch
+    unsigned total;         // bytes of dynamic LDS
+    int nt;                 // threads per workgroup
+    int wl_bytes;           // size of the pass B work lists
+    int tab_lds;            // the env's dm / seg / nh / hop8 tables are staged in LDS (kernel template TAB_LDS)
+    int items_cap, items2_cap;  // entries of the LDS copies of the prediction items (first / second index); an env with more
+                                // falls back to the items in HBM scratch / to the two stages
+};
+
+// outputs of the flatland_cutils builder and of the upstream dense tree builder (k_obs MODE 0 / 1 / 2 = both)
+struct ObsArgs {
+    int max_nodes, pred_depth, max_depth, tree_pred;  // pred_depth: cutils predictor, tree_pred: upstream predictor
+    float *attr, *forest;
+    int32_t *adjacency, *node_order, *edge_order;
+    uint8_t *valid;
+    double *props;
+    double *tree_out;
+    int n_tree_nodes;
+    long long *dbg;  // diagnostic builds only (-DFL_OBS_TIMING): per-env phase clocks
+    int tw_c, tw_t, tpw_t;  // node-table words per team of the cutils / upstream builder (0 = builder not in this launch), upstream teams per wavefront
+    int compact_t;     // upstream trees in compact slots (no direction of a cell of the batch has more than two transitions)
+    int use_tmask;     // per-key time-bucket masks in LDS
+    int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
+    int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
+    int bk;            // large maps: the cutils index is grouped by time bucket (OBS_BK_NB); built in the node tables' LDS
+    int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged)
+    ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
+};
+
+// kernel launchers, one translation unit per MODE (0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch);
+// var: see obs_body (1 = static tables in LDS, 2 = work lists in HBM scratch)
+int fl_obs_launch_m0(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_m1(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_m2(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

@@ -10,7 +10,8 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 
 
 def episode_fixtures():
-    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLD, "cfg*.npz")))
+    # cfg*: the five BASELINE configs; test14*: the largest Round-2 map (158x158, 425 agents, 41 cities)
+    return sorted(os.path.basename(f)[:-4] for pat in ("cfg*.npz", "test14*.npz") for f in glob.glob(os.path.join(GOLD, pat)))
 
 
 def base_fixtures(prefix="base_"):

@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
 # same-box A/B of builds of the C-ABI library:  [WL="cfg3 3"] tools/gpu_ab.sh TAG lib1.so lib2.so ...   ("-" = the in-tree build)
+set -euo pipefail
+mkdir -p gpurun_out
 tag=$1; shift
 set -- "$@"
 read wl depth <<< "${WL:-cfg2 2}"

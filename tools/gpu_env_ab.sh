@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
 # same-box A/B of environment settings on the cfg2 bench line:  tools/gpu_env_ab.sh TAG "VAR=1" "VAR=2 OTHER=x" ...   ("-" = none)
+set -euo pipefail
+mkdir -p gpurun_out
 tag=$1; shift
 for rep in 1 2; do
   n=0

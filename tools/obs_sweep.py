@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 workload, depth = sys.argv[1], sys.argv[2]
 for force in sys.argv[3:]:
     env = dict(os.environ, FL_OBS_FORCE=force, FL_OBS_VERBOSE="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--workload", workload, "--tree-depth", depth,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-workloads", "--workload", workload, "--tree-depth", depth,
                         "--steps", "120", "--warmup", "20"], env=env, capture_output=True, text=True)
     cfg = [l for l in p.stderr.splitlines() if l.startswith("[fl_obs]")]
     try:
