@@ -45,7 +45,8 @@ struct fl_batch {
     std::vector<void *> allocs;
     // host copy of every env's static description (filled by fl_load_env; kept after commit: live map replacement,
     // fl_distance_map's expansion to the dense layout)
-    std::vector<uint16_t> h_grid, h_ridx, h_rgrid, h_nbr, h_rkey, h_init_r, h_target_r, h_ut_r;
+    std::vector<uint16_t> h_grid, h_ridx, h_rgrid, h_nbr, h_rkey, h_init_r, h_target_r, h_ut_r, h_srank;
+    std::vector<int> h_maxbr;  // per env: most transitions of any (cell, direction)
     std::vector<uint32_t> h_rcell;
     std::vector<int> h_init_pos, h_target, h_earliest, h_latest, h_tslot, h_ut, h_U, h_R, h_K, h_T, h_mt_pos, h_malf_min, h_malf_max;
     std::vector<uint32_t> h_spk, h_mt;
@@ -103,7 +104,7 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
     h->reserve_U = 0; h->reserve_R = 0;
     h->h_grid.assign(B * HW, 0); h->h_ridx.assign(B * HW, FL_R_NONE);
     h->h_init_pos.assign(BA, 0); h->h_target.assign(BA, 0); h->h_earliest.assign(BA, 0); h->h_latest.assign(BA, 0);
-    h->h_init_r.assign(BA, 0); h->h_target_r.assign(BA, 0);
+    h->h_init_r.assign(BA, 0); h->h_target_r.assign(BA, 0); h->h_srank.assign(BA, 0); h->h_maxbr.assign(B, 0);
     h->h_tslot.assign(BA, 0); h->h_spk.assign(BA, 0); h->h_speed.assign(BA, 1.0);
     h->h_ut.assign(BA, 0); h->h_U.assign(B, 0); h->h_R.assign(B, 0); h->h_K.assign(B, 0); h->h_T.assign(B, 0); h->h_mt_pos.assign(B, 624);
     h->h_malf_min.assign(B, 0); h->h_malf_max.assign(B, 0); h->h_thr.assign(B, 0);
@@ -240,7 +241,7 @@ static int upload_envs(fl_batch *h, int b0, int nb) {
     UPLOAD_RANGE(d.ut_r, h->h_ut_r, b * Ucap, n * Ucap);
     const size_t g0 = b * A, ng = n * A;
     UPLOAD_RANGE(d.init_pos, h->h_init_pos, g0, ng); UPLOAD_RANGE(d.target, h->h_target, g0, ng);
-    UPLOAD_RANGE(d.init_r, h->h_init_r, g0, ng); UPLOAD_RANGE(d.target_r, h->h_target_r, g0, ng);
+    UPLOAD_RANGE(d.init_r, h->h_init_r, g0, ng); UPLOAD_RANGE(d.target_r, h->h_target_r, g0, ng); UPLOAD_RANGE(d.srank, h->h_srank, g0, ng);
     UPLOAD_RANGE(d.earliest, h->h_earliest, g0, ng); UPLOAD_RANGE(d.latest, h->h_latest, g0, ng);
     UPLOAD_RANGE(d.tslot, h->h_tslot, g0, ng); UPLOAD_RANGE(d.spk, h->h_spk, g0, ng); UPLOAD_RANGE(d.speed, h->h_speed, g0, ng);
     return FL_OK;
@@ -296,6 +297,15 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
         h->h_spk[g] = (uint32_t)init_dir[i] | ((uint32_t)((int)(1.0 / speed[i]) - 1) << 2);
         h->h_tslot[g] = tslot[i];
         h->h_ut[g] = i < (int)ut.size() ? ut[i] : 0;
+        int rank = 0;
+        for (int j = 0; j < A; j++) rank += speed[j] < speed[i];
+        h->h_srank[g] = (uint16_t)rank;
+    }
+    {
+        int mb = 0;
+        for (size_t c = 0; c < HW; c++)
+            for (int dd = 0; dd < 4; dd++) mb = std::max(mb, __builtin_popcount((grid[c] >> ((3 - dd) * 4)) & 15u));
+        h->h_maxbr[b] = mb;
     }
     h->h_U[b] = (int)ut.size();
     h->h_R[b] = (int)rail_cells;
@@ -353,7 +363,7 @@ int fl_commit(fl_batch *h) {
         DALLOC(d.ut_r, (size_t)B * Ucap);
         DALLOC(d.dm, (size_t)B * Ucap * Scap); DALLOC(d.seg, (size_t)B * Scap);
         DALLOC(d.nh, (size_t)B * Ucap * Rcap); DALLOC(d.hop8, (size_t)B * Ucap * Scap);
-        DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.init_r, BA); DALLOC(d.target_r, BA);
+        DALLOC(d.init_pos, BA); DALLOC(d.target, BA); DALLOC(d.init_r, BA); DALLOC(d.target_r, BA); DALLOC(d.srank, BA);
         DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
         DALLOC(d.spk, BA); DALLOC(d.speed, BA);
         DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
@@ -362,6 +372,8 @@ int fl_commit(fl_batch *h) {
         int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
         if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
     }
+    d.max_branch = 0;
+    for (int b = 0; b < B; b++) d.max_branch = std::max(d.max_branch, h->h_maxbr[b]);
     // (re)build the host tables of every env loaded since the last commit and upload them; the device tables of exactly
     // those envs are rebuilt below, their agents reset (fresh)
     bool any = false;
@@ -806,10 +818,22 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
 }
 
 // diagnostic (not part of the public header): threads, LDS bytes, keys in LDS, next-hop in LDS, work-list bytes, time masks,
-// second index, items in LDS of the fused observation launch on this batch
-extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out8) {
+// second index, items in LDS, one pass B for both builders, compact upstream trees of the fused observation launch on this batch
+extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out10) {
     NEED_COMMIT(h);
-    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out8);
+    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out10);
+}
+
+// diagnostic (not part of the public header), no GPU needed: the same for a batch of the given sizes -- agents, rail-cell and
+// unique-target capacities, maps taller than wide (compact prediction keys), most transitions of a (cell, direction)
+extern "C" int fl_debug_obs_config_of(int A, int Rcap, int Ucap, int tall, int max_branch, int pred_depth, int max_depth, int tree_pred,
+                                      int *out10) {
+    FlDev d;
+    memset(&d, 0, sizeof d);
+    d.A = A; d.Rcap = Rcap; d.Ucap = Ucap; d.max_branch = max_branch;
+    static uint16_t dummy_key;
+    d.rkey = tall ? &dummy_key : nullptr;
+    return fl_obs_config_of_fused(d, pred_depth, max_depth, tree_pred, out10);
 }
 
 double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {

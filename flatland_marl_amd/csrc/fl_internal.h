@@ -57,6 +57,8 @@ __host__ __device__ inline uint32_t pk_make(uint32_t dir, uint32_t old_dir, uint
 struct FlDev {
     int B, A, H, W;
     int Ucap, Rcap;  // capacity per env: unique targets, rail cells (rail states: 4 * Rcap)
+    int max_branch;  // most transitions any (rail cell, direction) of the batch has: 2 on every Flatland rail cell type (the upstream
+                     // trees then use compact node tables, fl_obs_layout.h)
     // per env
     int *t;
     int *T;
@@ -89,6 +91,7 @@ struct FlDev {
     // static per agent
     int *init_pos, *target, *earliest, *latest, *tslot;
     uint16_t *init_r, *target_r;
+    uint16_t *srank;  // number of agents of the env with a smaller speed (the observation kernels take minima over speeds as ranks)
     uint32_t *spk;
     double *speed;
     // dynamic per agent

@@ -27,4 +27,4 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
-int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[8]);  // diagnostic
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[10]);  // diagnostic

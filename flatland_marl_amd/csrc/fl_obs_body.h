@@ -1,0 +1,846 @@
+// fl_obs_body.h -- one observation build for the workgroup's env (obs_body: staging, per-agent phase, predicted paths and the
+// per-key prediction index, then the trees) and the kernel template.  Device code; the three fl_obs_m<MODE>.hip units
+// instantiate it.  DESIGN.md section 4 describes the phases; tools/obs_phase_clocks.py measures them.
+//
+// Replaces (paths relative to /root/reference):
+//   flatland_cutils/src/loader.cpp:221-327      AgentsLoader::update (snapshot, dist_target, road_type, valid actions)
+//   flatland_cutils/src/deadlock_checker.cpp    DeadlockChecker (restated as a least fixpoint, see phase 1)
+//   flatland_cutils/src/predictions.cpp:78-235  shortest-path predictor (greedy strict descent on the distance map)
+//   flatland_cutils/src/treeobs.cpp:30-610      get_many / get / _explore_branch / scale_node
+//   flatland_cutils/src/tool.h:468-524          calculate_evaluation_orders
+//   flatland_cutils/src/feature_parser.cpp:3-98 AgentAttrParser::get_features
+//   flatland-rl/flatland/envs/observations.py:60-494 + predictions.py:97-180   upstream TreeObsForRailEnv
+//
+// Everything is indexed by RAIL CELLS (rail index r, rail state s = r * 4 + orientation; fl_internal.h), not by grid cells:
+// the per-cell words, the neighbour / successor tables, the prediction keys and their time masks of a 150x150 map
+// (2680 rail cells) fit LDS like those of a 30x30 one.
+//
+// Layout of one launch (gfx950): one workgroup (up to 16 wavefronts) per env.  The env's rail words, neighbour tables and
+// an occupied-cell table are staged in LDS once.  Then, concurrently: eight lanes per agent walk its predicted path (static
+// next-hop / eight-hop tables), one wavefront does the per-agent part (deadlock fixpoint, valid actions, 83-float attribute
+// row) and the other wavefronts derive the topology of the trees from the static segment table (pass A).  A per-key index
+// of prediction items (+ per-key time-bucket masks) is built in LDS.  Pass B splits the visited cells of all trees evenly
+// over all lanes, classifies them, and processes the few cells that need work from work lists on packed wavefronts; rows
+// are written straight to HBM.
+#pragma once
+#include "fl_obs_trees.h"
+
+// One observation build for the workgroup's env.  STAGE 0: stand-alone; the fused launch (both builders) runs STAGE 1
+// (cutils; also prepares what the second stage needs) and then STAGE 2 (upstream tree), which reuses the LDS-resident
+// rail words / occupancy table / static tables and the predicted paths of stage 1: the upstream predictor's path
+// is a prefix of the cutils one (same greedy descent, it only stops at the target and after fewer steps).
+// VAR 1 (small maps): the env's distance map, segment, next-hop and eight-hop tables are staged in LDS.  VAR 2 (large maps):
+// the pass B work lists live in HBM scratch, which leaves the LDS to the time masks and lifts the cap on their entries.
+// MERGED (its own kernel, MODE 3): stage 1 of the fused launch builds the trees of BOTH builders, one pass B per round
+// (trees_merged); there is no stage 2.  The launcher sizes the LDS copy of the second index for the exact bound on its items, so
+// this mode never has to fall back.
+template <bool CUTILS, int VAR, int STAGE, int MERGED = 0>
+__device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
+    constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
+    const int Rcap = d.Rcap, Scap = Rcap * 4;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    extern __shared__ __align__(16) unsigned char lds[];
+    const ObsLayout &L = P.L;
+#define LDS_AT(T, which) reinterpret_cast<T *>(lds + L.off[which])
+#define LDS_OPT(T, which) (L.off[which] == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L.off[which]))
+    uint32_t *cellw = LDS_AT(uint32_t, L_CELLW);  // rail bitmap | occupied-cell table index << 16
+    uint16_t *nbr = LDS_AT(uint16_t, L_NBR);
+    uint16_t *snext = LDS_OPT(uint16_t, L_SNEXT);
+    uint16_t *rkey = LDS_OPT(uint16_t, L_RKEY);
+    int *slot_agent = LDS_AT(int, L_SLOT_AGENT);
+    int *slot_ready = LDS_AT(int, L_SLOT_READY);
+    uint32_t *cell_target = LDS_AT(uint32_t, L_CELL_TARGET);
+    double *a_speed = LDS_AT(double, L_A_SPEED);
+    uint16_t *a_vpos = LDS_AT(uint16_t, L_A_VPOS);
+    int *a_pos = LDS_AT(int, L_A_POS);
+    uint16_t *a_tslot = LDS_AT(uint16_t, L_A_TSLOT);
+    uint16_t *a_target = LDS_AT(uint16_t, L_A_TARGET);
+    uint16_t *a_malf = LDS_AT(uint16_t, L_A_MALF);
+    uint16_t *a_tpc = LDS_AT(uint16_t, L_A_TPC);
+    double *a_tq = LDS_AT(double, L_A_TQ);
+    uint16_t *a_lp = LDS_AT(uint16_t, L_A_LP);
+    uint16_t *a_n = LDS_AT(uint16_t, L_A_N);  // waypoints of the agent's predicted path
+    uint16_t *a_srank = LDS_AT(uint16_t, L_A_SRANK);
+    uint8_t *a_dir = LDS_AT(uint8_t, L_A_DIR);
+    uint8_t *a_state = LDS_AT(uint8_t, L_A_STATE);
+    uint8_t *a_free = LDS_AT(uint8_t, L_A_FREE);
+    uint8_t *a_dead = LDS_AT(uint8_t, L_A_DEAD);
+    int *misc = LDS_AT(int, L_MISC);
+    int *team_meta = LDS_AT(int, L_TEAM_META);
+    int *wave_scr = LDS_AT(int, L_WAVE_SCR);  // the teams' node tables
+    int *csr = LDS_AT(int, L_CSR);
+    uint32_t *items_lds = LDS_OPT(uint32_t, L_ITEMS);
+    uint32_t *wl_lds = WL_HBM ? nullptr : LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
+    int *partial = (WL_HBM || L.off[L_PARTIAL] != L_ABSENT) ? LDS_AT(int, L_PARTIAL) : reinterpret_cast<int *>(wl_lds);
+    const int wl_entries = WL_HBM ? S.wl_cap : L.wl_bytes / 8;
+    unsigned long long *tmask = LDS_OPT(unsigned long long, L_TMASK);
+    uint16_t *nh_lds = LDS_OPT(uint16_t, L_NH);
+    // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
+    int *csr2 = LDS_OPT(int, L_CSR2);
+    unsigned long long *tmaskb = LDS_OPT(unsigned long long, L_TMASKB);
+    unsigned long long *tmask_m2 = LDS_OPT(unsigned long long, L_TMASK2), *tmaskb_m2 = LDS_OPT(unsigned long long, L_TMASKB2);  // own-path filter
+    uint32_t *items2 = LDS_OPT(uint32_t, L_ITEMS2);
+    uint16_t *a_lp2 = LDS_OPT(uint16_t, L_A_LP2);
+    uint16_t *a_tpc2 = LDS_OPT(uint16_t, L_A_TPC2);
+    double *a_tq2 = LDS_OPT(double, L_A_TQ2);
+    // what phase 1 and the root rows read per agent (pk, spk, malfunction word, latest, earliest, arrival, initial rail cell) and the
+    // road types of the rail cells: LDS copies when there is room (small envs), else HBM
+    uint32_t *a_raw = LDS_OPT(uint32_t, L_A_RAW);
+    uint8_t *rtype_lds = LDS_OPT(uint8_t, L_RTYPE);
+    // static tables of the env: LDS copies (TAB_LDS) or HBM
+    uint4 *seg_lds = TAB_LDS ? LDS_AT(uint4, L_SEG) : nullptr;
+    uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
+    uint16_t *hop8_lds = TAB_LDS ? LDS_AT(uint16_t, L_HOP8) : nullptr;
+    const uint4 *gseg = d.seg + (size_t)b * Scap;
+    const uint16_t *gdm = d.dm + (size_t)b * d.Ucap * Scap;
+    const uint16_t *ghop8 = d.hop8 + (size_t)b * d.Ucap * Scap;
+    const uint16_t *gnh = d.nh + (size_t)b * d.Ucap * Rcap;
+
+    const int T = d.T[b], tnow = d.t[b];
+#ifdef FL_OBS_TIMING
+#define OBS_STAMP(k) do { __syncthreads(); if (tid == 0) { const long long now_ = (long long)wall_clock64(); P.dbg[(size_t)b * 64 + (STAGE == 2 ? 32 : 0) + (k)] = now_; P.dbg[(size_t)b * 64 + (STAGE == 2 ? 32 : 0) + 15] = now_; } } while (0)
+#else
+#define OBS_STAMP(k) do {} while (0)
+#endif
+#ifdef FL_OBS_TIMING
+    if (tid < 64 && STAGE != 2) P.dbg[(size_t)b * 64 + tid] = 0;
+    __syncthreads();
+#endif
+    OBS_STAMP(0);
+
+    const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
+    const bool any_pred = STAGE == 0 ? my_pred_depth >= 0 : true;
+    const bool nh_in_lds = nh_lds != nullptr && any_pred;
+    // ---- phase 0: stage the rail words and the static tables, clear the per-cell maps, per-agent snapshot into LDS
+    bool prefilled = false, bg_prefill = false;
+    if (STAGE != 2) {
+        // per-agent snapshot first, on the LAST lanes: its two dependent HBM reads (state, then the rail index of the position)
+        // overlap with the staging of the tables by everybody else
+        const uint16_t *gridx = d.ridx + (size_t)b * d.H * d.W;
+        for (int i = nt - 1 - tid; i < A; i += nt) {
+            const int g = b * A + i;
+            const uint32_t pk = d.pk[g];
+            const uint32_t state = PK_STATE(pk);
+            const int pos = d.pos[g];
+            const int init_r = d.init_r[g], target_r = d.target_r[g];
+            const double speed = d.speed[g];
+            const int pos_r = pos < 0 ? -1 : (int)gridx[pos];  // the dynamic state keeps cell ids (C-ABI, step kernel)
+            a_pos[i] = pos_r;
+            a_vpos[i] = (uint16_t)(is_off_map(state) ? init_r : (is_on_map(state) ? pos_r : target_r));  // loader.cpp:74-82
+            a_dir[i] = (uint8_t)PK_DIR(pk);
+            a_state[i] = (uint8_t)state;
+            a_dead[i] = (uint8_t)PK_DEADLOCK(pk);
+            const uint32_t malfw = d.malf[g];
+            a_malf[i] = (uint16_t)(malfw & 0xFFFFu);
+            if (a_raw) {
+                uint32_t *r8 = a_raw + i * 8;
+                r8[0] = pk; r8[1] = d.spk[g]; r8[2] = malfw; r8[3] = (uint32_t)d.latest[g]; r8[4] = (uint32_t)d.earliest[g];
+                r8[5] = (uint32_t)d.arrival[g]; r8[6] = (uint32_t)init_r;
+            }
+            a_speed[i] = speed;
+            a_tslot[i] = (uint16_t)d.tslot[g];
+            a_target[i] = (uint16_t)target_r;
+            a_srank[i] = d.srank[g];
+            a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
+            a_tq[i] = CUTILS ? (double)(float)(1.0 / (double)(float)speed) : 1.0 / speed;
+            if (CUTILS && STAGE == 1 && P.dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
+        }
+        {
+            const uint16_t *grg = d.rgrid + (size_t)b * Rcap;
+            for (int r = tid; r < R; r += nt) cellw[r] = (uint32_t)grg[r] | 0xFFFF0000u;
+            // u16 tables: two entries per load (every base is 4-byte aligned: Scap is a multiple of 4, Rcap * U pairs up below)
+            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(d.nbr + (size_t)b * Scap);
+            uint32_t *l2 = reinterpret_cast<uint32_t *>(nbr);
+            for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
+            if (snext) {
+                g2 = reinterpret_cast<const uint32_t *>(d.snext + (size_t)b * Scap);
+                l2 = reinterpret_cast<uint32_t *>(snext);
+                for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
+            }
+            if (rkey) {
+                const uint16_t *gk = d.rkey + (size_t)b * Rcap;
+                for (int r = tid; r < R; r += nt) rkey[r] = gk[r];
+            }
+            if (TAB_LDS) {
+                const uint2 *gs2 = reinterpret_cast<const uint2 *>(gdm);   // 8-byte pieces: Scap * 2 B is a multiple of 8
+                uint2 *ld2 = reinterpret_cast<uint2 *>(dm_lds);
+                const int n8 = U * Scap / 4;
+                for (int c = tid; c < n8; c += nt) ld2[c] = gs2[c];
+                gs2 = reinterpret_cast<const uint2 *>(ghop8);
+                ld2 = reinterpret_cast<uint2 *>(hop8_lds);
+                for (int c = tid; c < n8; c += nt) ld2[c] = gs2[c];
+                for (int c = tid; c < NS; c += nt) seg_lds[c] = gseg[c];
+            }
+            if (nh_in_lds)
+                for (int c = tid; c < U * Rcap; c += nt) nh_lds[c] = gnh[c];
+            if (rtype_lds) {
+                const uint8_t *grt = d.rtype + (size_t)b * Rcap;
+                for (int r = tid; r < R; r += nt) rtype_lds[r] = grt[r];
+            }
+        }
+        // (with a job queue in phase 2 -- cutils builder in the launch, a predictor, a wavefront left beside the walkers -- the rows
+        // are pre-filled there by whoever is free, beside the path walk, instead of here by everybody)
+        const int nw_walk0 = min((nt >> 6) - ((nt >> 6) > 4 ? 1 : 0), max(2, (A + 7) / 8));
+        bg_prefill = CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6);
+        if ((!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill) {
+            // the upstream trees of the env: every row that is not a real node is -inf (observations.py:247, 489); the builders
+            // only write the real rows later.  Coalesced 16-byte stores beside the staging.  The wait below (before the barrier
+            // that ends this phase) lets them reach the L2 ahead of any later store of this workgroup to the same rows -- same CU,
+            // same L2 -- without the L2 write-back an agent-scope release fence costs on this multi-XCD part (70 us).
+            double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)b * A * P.n_tree_nodes * 12);
+            const int n2 = A * P.n_tree_nodes * 6;
+            const double2 ninf = make_double2(-INFINITY, -INFINITY);
+            for (int k = tid; k < n2; k += nt) o2[k] = ninf;
+            prefilled = true;
+        }
+        for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
+        for (int c = tid; c < (R + 31) / 32; c += nt) cell_target[c] = 0;
+        if (tid < 64) misc[tid] = 0;
+        __syncthreads();
+        // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
+        // Occupied cells get an entry in a small table; the per-cell word only holds the entry index.
+        for (int i = tid; i < A; i += nt) {
+            const uint32_t state = a_state[i];
+            const bool on = !is_off_map(state) && a_pos[i] >= 0, off = is_off_map(state);
+            if (on || off) {
+                const int c = a_vpos[i];  // on the map: the position; off the map: the initial position
+                int slot = -1;
+                unsigned int cur = *(volatile unsigned int *)&cellw[c];
+                while (true) {  // claim (or find) the cell's table entry
+                    const unsigned int have = cur >> 16;
+                    if (have != 0xFFFFu) { slot = (int)have; break; }
+                    if (slot < 0) slot = atomicAdd(&misc[1], 1);
+                    const unsigned int old = atomicCAS(&cellw[c], cur, (cur & 0xFFFFu) | ((unsigned int)slot << 16));
+                    if (old == cur) break;
+                    cur = old;
+                }
+                if (on) atomicMax(&slot_agent[slot], i);
+                else atomicAdd(&slot_ready[slot], 1);
+            }
+            if (!CUTILS || STAGE == 1) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
+        }
+    } else {
+        // second stage: only the predictor's times-per-cell differ (int(np.reciprocal(speed)), predictions.py:139)
+        for (int i = tid; i < A; i += nt) { a_tpc[i] = (uint16_t)(int)(1.0 / a_speed[i]); a_tq[i] = 1.0 / a_speed[i]; }
+    }
+    if (prefilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    ObsCtx X;
+    X.A = A; X.R = R; X.SS = Scap;
+    X.cellw = cellw; X.nbr = nbr; X.snext = snext; X.rkey = rkey;
+    X.slot_agent = slot_agent; X.slot_ready = slot_ready; X.cell_target = cell_target;
+    X.seg = TAB_LDS ? seg_lds : gseg;
+    X.dm = TAB_LDS ? dm_lds : gdm;
+    X.dbg = P.dbg ? P.dbg + (size_t)b * 64 : nullptr;
+    X.dbg_base = STAGE == 2 ? 32 : 0;
+    X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
+    X.a_tpc = a_tpc; X.a_tq = a_tq; X.a_tslot = a_tslot; X.a_target = a_target; X.a_srank = a_srank;
+    uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
+    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr;
+    X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
+    // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
+    X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
+    X.wl_hbm = WL_HBM;
+    X.wl_occ = WL_HBM ? S.wl + (size_t)b * S.wl_cap : reinterpret_cast<uint2 *>(wl_lds);
+    X.wl_occ_cap = X.tmask ? wl_entries / P.wl_occ_div : wl_entries;  // a share of the entries
+    X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
+    X.wl_cnt = misc + 8;
+    X.long_lists = misc + 11;
+    X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = min(t >> tshift, 63)
+    // one pass B over the trees of both builders (stage 1 of the fused launch): the upstream builder's side of the context
+    constexpr bool merged = MERGED != 0;   // 1: at most 32 agents (one round), 2: rounds of 32 agents
+    X.n_cu = OBS_MERGED_ROUND; X.round_base = 0;
+    X.u_csr_end = csr2; X.u_items = items2; X.u_tmask = tmaskb; X.a_tq2 = a_tq2;
+    X.tmask_m2 = merged ? tmask_m2 : nullptr; X.u_tmask_m2 = tmaskb_m2;
+    X.path = S.path + (size_t)b * A * S.pred_cap; X.pred_cap = S.pred_cap;
+    X.a_lp = a_lp; X.a_lp2 = a_lp2; X.a_tpc2 = a_tpc2;
+    X.u_Tn = P.tree_pred + 1; X.u_tshift = X.u_Tn <= 64 ? 0 : P.tshift;
+
+    OBS_STAMP(1);
+    // ---- phase 1 (cutils only): deadlock flags, valid actions, attribute rows.  The deadlock check is the work of ONE
+    // wavefront (wave-level synchronisation only) and runs beside the path walkers of phase 2; the per-agent rest is spread
+    // over all wavefronts (phase1b).
+    auto phase1a = [&]() __attribute__((always_inline)) {
+        // DeadlockChecker (deadlock_checker.cpp:11-110) as a least fixpoint: an active agent is "free" when one of
+        // its exits leads to an empty cell or to a free, not yet deadlocked agent (or it has no exit at all);
+        // every other active agent becomes (and stays) deadlocked.  Equivalent to the reference's DFS + _fix_deps.
+        if (A <= 64) {
+            // one agent a lane: who blocks whom is looked up once (a bit mask of the agents on the exits), the fixpoint
+            // itself runs on ballots, without a memory access
+            const int i = lane;
+            bool active = false, fr = false;
+            unsigned long long blockers = 0;
+            if (i < A && is_on_map(a_state[i]) && !a_dead[i]) {
+                active = true;
+                const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
+                if (bits == 0) fr = true;
+                for (uint32_t m = 0; m < 4; m++) {
+                    if (!((bits >> (3 - m)) & 1)) continue;
+                    const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                    if (nr == FL_R_NONE) { fr = true; continue; }  // leaves the grid / the rail: nobody can be there
+                    const uint32_t sl = cw_slot(X, (int)nr);
+                    const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
+                    if (opp < 0) fr = true;
+                    else if (!a_dead[opp]) blockers |= 1ull << opp;
+                }
+            }
+            unsigned long long free_set = __ballot(fr);
+            while (true) {  // monotone: any evaluation order reaches the same least fixpoint
+                if (active && !fr && (free_set & blockers)) fr = true;
+                const unsigned long long next = __ballot(fr);
+                if (next == free_set) break;
+                free_set = next;
+            }
+            if (i < A) a_free[i] = fr;
+            team_sync();
+        } else {
+            for (int i = lane; i < A; i += 64) {
+                bool fr = false;
+                if (is_on_map(a_state[i]) && !a_dead[i]) {
+                    const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
+                    if (bits == 0) fr = true;
+                    for (uint32_t m = 0; m < 4 && !fr; m++) {
+                        if (!((bits >> (3 - m)) & 1)) continue;
+                        const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                        if (nr == FL_R_NONE) { fr = true; continue; }  // leaves the grid / the rail: nobody can be there
+                        const uint32_t sl = cw_slot(X, (int)nr);
+                        if (sl == 0xFFFFu || slot_agent[sl] < 0) fr = true;
+                    }
+                }
+                a_free[i] = fr;
+            }
+            team_sync();
+            while (true) {  // monotone: any evaluation order reaches the same least fixpoint
+                bool changed = false;
+                for (int i = lane; i < A; i += 64) {
+                    if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
+                        const uint32_t bits = nibble(cw_bits(X, a_pos[i]), a_dir[i]);
+                        bool fr = false;
+                        for (uint32_t m = 0; m < 4 && !fr; m++) {
+                            if (!((bits >> (3 - m)) & 1)) continue;
+                            const uint32_t nr = nbr[a_pos[i] * 4 + (int)m];
+                            const uint32_t sl = nr != FL_R_NONE ? cw_slot(X, (int)nr) : 0xFFFFu;
+                            const int opp = sl != 0xFFFFu ? slot_agent[sl] : -1;
+                            if (opp >= 0 && !a_dead[opp] && a_free[opp]) fr = true;
+                        }
+                        if (fr) { a_free[i] = 1; changed = true; }
+                    }
+                }
+                team_sync();
+                if (!__any(changed)) break;
+            }
+        }
+        for (int i = lane; i < A; i += 64) {  // commit the new deadlocks; the deadlock flag of the attribute row and of props
+            const int g = b * A + i;
+            if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
+                a_dead[i] = 1;
+                d.pk[g] |= (1u << 18);
+            }
+            P.attr[(size_t)g * FL_CUTILS_ATTR + 41] = (float)a_dead[i];
+            if (P.props) P.props[(size_t)g * 3 + 1] = (double)a_dead[i];
+        }
+    };
+    // Rest of phase 1, per agent: valid actions, props, attribute row (everything but the deadlock flag).  A team of 32
+    // lanes per agent: every lane derives the agent's scalars (broadcast loads) and writes elements gl, gl + 32, gl + 64 of
+    // the row, so it can run on any wavefront beside the deadlock check.
+    // what phase1b reads from HBM: requested ahead of the hoisted pass A so that the two latencies overlap
+    struct AgentRaw { uint32_t pk, spk, malfw; int latest, earliest, arrival, init_r, road_type; };
+    auto phase1b_load = [&](int i) __attribute__((always_inline)) {
+        const int g = b * A + i, pos = a_pos[i];
+        AgentRaw r;
+        if (a_raw) {
+            const uint32_t *r8 = a_raw + i * 8;
+            r.pk = r8[0]; r.spk = r8[1]; r.malfw = r8[2]; r.latest = (int)r8[3]; r.earliest = (int)r8[4]; r.arrival = (int)r8[5]; r.init_r = (int)r8[6];
+        } else {
+            r.pk = d.pk[g]; r.spk = d.spk[g]; r.malfw = d.malf[g];
+            r.latest = d.latest[g]; r.earliest = d.earliest[g]; r.arrival = d.arrival[g];
+            r.init_r = d.init_r[g];
+        }
+        // static per rail cell (fl_host.hip)
+        r.road_type = pos < 0 ? 0 : rtype_lds ? (int)rtype_lds[pos] : (int)d.rtype[(size_t)b * Rcap + pos];
+        return r;
+    };
+    auto phase1b = [&](int i, int gl, const AgentRaw &raw) __attribute__((always_inline)) {
+        const int g = b * A + i;
+        const uint32_t state = a_state[i];
+        const uint32_t pk = raw.pk, spk = raw.spk;
+        const int pos = a_pos[i];
+        const uint32_t dir = a_dir[i];
+        const uint32_t scount = PK_SCOUNT(pk), max_count = SPK_MAX_COUNT(spk), init_dir = SPK_INIT_DIR(spk);
+        const uint32_t old_dir = PK_OLD_DIR(pk) == 4 ? dir : PK_OLD_DIR(pk);
+        // update_dist_target (loader.cpp:163-179)
+        const int dmb = a_tslot[i] * X.SS;
+        const uint16_t dv_init = X.dm[dmb + raw.init_r * 4 + (int)init_dir];
+        const float init_dist = dv_init == FL_INF16 ? INFINITY : (float)dv_init;
+        float dist_target;
+        if (state == ST_DONE) dist_target = 0;
+        else if (is_off_map(state)) dist_target = init_dist;
+        else {
+            const uint16_t dv = X.dm[dmb + pos * 4 + (int)dir];
+            dist_target = dv == FL_INF16 ? INFINITY : (float)dv;
+        }
+        // valid-action mask (loader.cpp:273-312)
+        uint32_t va = 0;
+        const uint32_t cell = pos >= 0 ? cw_bits(X, pos) : 0;
+        if (state == ST_MOVING || state == ST_STOPPED) {
+            if (scount == 0) {
+                const uint32_t bits = nibble(cell, dir);
+                int cnt = 0;
+                bool has_branch = false;
+                for (uint32_t a = ACT_LEFT; a <= ACT_RIGHT; a++) {
+                    const uint32_t nd = (dir + a + 2u) & 3u;
+                    if ((bits >> (3 - nd)) & 1) {
+                        va |= 1u << a;
+                        cnt++;
+                        const uint32_t nr = nbr[pos * 4 + (int)nd];
+                        if (nr != FL_R_NONE && __popc(cw_bits(X, (int)nr)) > 2) has_branch = true;
+                    }
+                }
+                if (__popc(cell) > 2 || (cnt == 1 && has_branch)) va |= 1u << ACT_STOP;
+            } else va |= 1u << ACT_NOTHING;
+        } else if (state == ST_READY) va = (1u << ACT_FORWARD) | (1u << ACT_STOP);
+        else va = 1u << ACT_NOTHING;
+        if (gl < 5) P.valid[(size_t)g * 5 + gl] = (va >> gl) & 1;
+        if (P.props && gl == 5) {
+            P.props[(size_t)g * 3 + 0] = (double)dist_target;
+            P.props[(size_t)g * 3 + 2] = (double)(state == ST_READY);
+        }
+        // AgentAttrParser::get_features (feature_parser.cpp:3-98): elements 0 .. 69 are 0 / 1 -- bit j of (m_lo, m_hi)
+        const int road_type = raw.road_type;
+        const uint32_t malfw = raw.malfw;
+        const uint32_t malf01 = (malfw & 0xFFFFu) != 0, nmalf01 = (malfw >> 16) != 0;
+        const uint32_t rev = __brev(cell) >> 16;  // element 49 + k = bit 15 - k of the rail word
+        unsigned long long m_lo = (state < 7u ? 1ull << state : 0ull) | (road_type < 11 ? 1ull << (7 + road_type) : 0ull) | (1ull << (18 + nmalf01)) |
+                                  (1ull << (28 + init_dir)) | (1ull << (32 + dir)) | (1ull << (36 + old_dir)) |
+                                  ((unsigned long long)(state == ST_MOVING) << 40) | ((unsigned long long)PK_SIGMALF(pk) << 42) |
+                                  ((unsigned long long)(!malf01) << 43) | ((unsigned long long)(scount == 0) << 44) |
+                                  ((unsigned long long)(scount == max_count) << 45) | ((unsigned long long)(state == ST_MALF || state == ST_MALF_OFF) << 46) |
+                                  ((unsigned long long)is_off_map(state) << 47) | ((unsigned long long)is_on_map(state) << 48) |
+                                  ((unsigned long long)(rev & 0x7FFFu) << 49);
+        const uint32_t m_hi = (rev >> 15) | (va << 1);
+        // elements 70 .. 82
+        const float max_t = (float)T, max_dist_target = (float)((d.H + d.W) * 8);
+        const float f_step = (float)tnow / max_t;
+        const float f_latest = (float)raw.latest / max_t;
+        const float f_before = f_latest - f_step;
+        const float f_dist = isinf(dist_target) ? 8.0f : dist_target / max_dist_target;
+        const float fv[13] = {(float)i / (float)A, f_step, (float)raw.earliest / max_t, f_latest, (float)raw.arrival / max_t, f_before, f_dist,
+                              f_before < f_dist ? f_before : f_dist, (float)max_count / 10, (float)a_speed[i] / 1.0f, (float)scount / 10,
+                              (float)malf01 / 10, isinf(init_dist) ? 8.0f : init_dist / max_dist_target};
+        float *o = P.attr + (size_t)g * FL_CUTILS_ATTR;
+        o[gl] = (float)((m_lo >> gl) & 1ull);
+        if (gl + 32 != 41) o[gl + 32] = (float)((m_lo >> (gl + 32)) & 1ull);  // element 41: the deadlock flag (phase 1a)
+        if (gl + 64 < FL_CUTILS_ATTR) {
+            float v = (float)((m_hi >> gl) & 1u);
+#pragma unroll
+            for (int k = 0; k < 13; k++) v = gl == 6 + k ? fv[k] : v;
+            o[gl + 64] = v;
+        }
+    };
+    // all agents of the env, one team of 32 lanes each
+    auto phase1b_all = [&]() __attribute__((always_inline)) {
+        for (int i = wave * 2 + (lane >> 5); i < A; i += 2 * (nt >> 6)) phase1b(i, lane & 31, phase1b_load(i));
+    };
+
+    // eight walker lanes per agent, on at least four wavefronts (consecutive wavefronts of a workgroup land on different
+    // SIMDs): a lone wavefront issues at the full rate of its SIMD
+    const bool do_p1 = CUTILS && STAGE != 2;
+    // (with hundreds of agents every wavefront would walk: one of them is kept back for phase 1, which then runs beside the walk)
+    const int nw_walk = (X.Tn > 0 && STAGE != 2) ? min((nt >> 6) - ((do_p1 && (nt >> 6) > 4) ? 1 : 0), max(2, (A + 7) / 8)) : 0;
+    const bool p1_beside_walk = nw_walk < (nt >> 6);  // a wavefront is left over
+    // job queue of phase 2: pass A of four upstream trees (one pass B for both builders, see trees_merged; longest first), the
+    // rest of phase 1 of two agents.  (Ending the phase with the last pass A of a cutils tree and taking the rest of the queue
+    // beside the fill of the index measured 0.8 us slower: a job is a chain of HBM reads and takes as long as the fill.)
+    const int n_up_jobs = merged ? (min(A, OBS_MERGED_ROUND) + 3) / 4 : 0, n_p1_jobs = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
+    // ... and, last, the -inf pre-fill of the env's upstream rows (see phase 0) in chunks of 16 KB: pure stores that drain beside
+    // the latency-bound rest of the phase (no builder writes a row before the trees phase)
+    constexpr int PF_CHUNK = 64 * 16;  // double2 per job
+    const int pf_n2 = bg_prefill ? A * P.n_tree_nodes * 6 : 0, n_pf_jobs = (pf_n2 + PF_CHUNK - 1) / PF_CHUNK;
+    auto drain_jobs = [&]() __attribute__((always_inline)) {
+        bool stored = false;
+        while (n_up_jobs + n_p1_jobs + n_pf_jobs > 0) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&misc[6], 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= n_up_jobs + n_p1_jobs + n_pf_jobs) break;
+            if (j >= n_up_jobs + n_p1_jobs) {
+                double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)b * A * P.n_tree_nodes * 12);
+                const double2 ninf = make_double2(-INFINITY, -INFINITY);
+                const int k0 = (j - n_up_jobs - n_p1_jobs) * PF_CHUNK + lane;
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (k0 + q * 64 < pf_n2) o2[k0 + q * 64] = ninf;
+                stored = true;
+            } else if (j < n_up_jobs) {
+                const int u = 4 * j + (lane >> 4);
+                upstream_pass_a<16, OBS_CAP_T_COMPACT, true, 32>(X, P, b, u, u < A, lane & 15, merged_table_t(wave_scr, min(u, OBS_MERGED_ROUND - 1)), &d.err[b]);
+            } else {
+                const int i = 2 * (j - n_up_jobs) + (lane >> 5);
+                if (i < A) phase1b(i, lane & 31, phase1b_load(i));
+            }
+        }
+        if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in the L2 before the barrier that ends the phase
+    };
+    if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
+        if (wave == 0) phase1a();
+        phase1b_all();
+        __syncthreads();
+    }
+    OBS_STAMP(2);
+    // ---- phase 2: predicted paths + per-key CSR index of (agent, waypoint, time interval)
+    if (X.Tn > 0) {
+        // fused launch: stage 1 builds the upstream predictor's index too (same paths, one pass over the waypoints); stage 2
+        // then starts at its trees.  misc[4] tells stage 2 that the second index is complete.
+        const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
+        const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
+        const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
+        // large maps: bucketed lists (OBS_BK_NB).  Their per-(key, bucket) counters -- u16, two per word -- live in the node
+        // tables' LDS while the index is built (so no tree work is hoisted beside the walk), the offsets go to HBM afterwards
+        const bool bk = CUTILS && STAGE != 2 && P.bk != 0 && X.Tn > 64 && X.tmask != nullptr;
+        uint32_t *bkc = reinterpret_cast<uint32_t *>(wave_scr);
+        if (!reuse) {
+            for (int k = tid; k <= K; k += nt) csr[k] = 0;
+            if (tid == 0) misc[11] = 0;
+            if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
+            if (bk) for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) bkc[k] = 0u;
+        }
+        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
+        __syncthreads();
+        const int pred_depth = my_pred_depth;
+        if (STAGE != 2) {
+        // Roles of the wavefronts while the paths are walked (a chain of dependent loads on one lane per agent): the LAST
+        // nw_walk wavefronts walk, the one before them does phase 1, and every wavefront (the walkers afterwards) runs pass A
+        // of the first round of cutils trees for its two agents -- none of that needs the prediction index.
+        const int w_first = (nt >> 6) - nw_walk, wsel = wave - w_first;
+        if (do_p1 && p1_beside_walk && wave == w_first - 1) {
+            phase1a();
+#ifdef FL_OBS_TIMING
+            if (lane == 0) atomicMax((unsigned long long *)&X.dbg[20], (unsigned long long)wall_clock64());
+#endif
+        }
+        if (wsel >= 0) __builtin_amdgcn_s_setprio(3);  // the walk is the critical path: its wavefronts issue first
+        // Greedy strict descent on the distance map (predictions.cpp:107-133 / rail_env_shortest_paths.py:245-265): the choice
+        // at every (target, cell, orientation) is static (k_nexthop), so the predicted path is the chain of next-hops from
+        // the agent's state until nothing is strictly closer (on the target, or at once when it is unreachable), cut after
+        // n_max waypoints: cutils walks max_depth iterations and appends the final waypoint (predictions.cpp:131-133),
+        // upstream stops after max_depth waypoints (rail_env_shortest_paths.py:245-267) and keeps the current position when
+        // there is no path (predictions.py:126,150-156).  EIGHT lanes walk one path: lane j takes j single hops and then
+        // eight hops at a time through the static hop8 table, recording the waypoints j, j + 8, j + 16, ...
+        const int n_max = CUTILS ? pred_depth + 1 : max(pred_depth, 1);
+        for (int base = 0; wsel >= 0 && base < A; base += 8 * nw_walk) {
+            const int slot = lane >> 3, j = lane & 7;
+            const int i = base + wsel * 8 + slot;
+            const bool have = i < A;
+            const int ia = have ? i : 0;
+            uint16_t *path = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            const int u = a_tslot[ia];
+            uint32_t st = ((uint32_t)a_vpos[ia] << 2) | a_dir[ia];
+            bool alive = have && j < n_max;
+            auto lead_in = [&](const uint16_t *nh_u) __attribute__((always_inline)) {
+                for (int h = 0; h < 7; h++) {
+                    if (alive && h < j) {
+                        const uint32_t hop = ((uint32_t)nh_u[st >> 2] >> (3u * (st & 3u))) & 7u;
+                        const uint32_t nr = hop == 4u ? (uint32_t)FL_R_NONE : (uint32_t)nbr[(st & ~3u) | hop];
+                        if (nr == FL_R_NONE) alive = false;
+                        else st = (nr << 2) | hop;
+                    }
+                }
+            };
+            // waypoints that can be occupied within the horizon enter the per-key index: they are counted as they are recorded
+            // (bucketed lists count per bucket, below)
+            const int hz1 = bk ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
+            const int hz2 = dual ? max(0, min(P.tree_pred - 1, (Tn2 - 1) / (int)a_tpc2[ia])) : -1;
+            auto walk8 = [&](const uint16_t *h8) __attribute__((always_inline)) {
+                int idx = j, last = -1;
+                while (__any(alive)) {
+                    if (alive) {
+                        path[idx] = (uint16_t)st;
+                        last = idx;
+                        if (idx <= hz1) {
+                            const int key = key_of(X, (int)(st >> 2));
+                            atomicAdd(&csr[key], 1);
+                            if (idx <= hz2) atomicAdd(&csr2[key], 1);
+                        }
+                        const uint32_t s8 = idx + 8 < n_max ? (uint32_t)h8[st] : (uint32_t)FL_R_NONE;
+                        if (s8 == FL_R_NONE) alive = false;
+                        else { st = s8; idx += 8; }
+                    }
+                }
+                return last;
+            };
+            // separate call sites so that each keeps a static address space (LDS copy vs HBM table)
+            if (nh_in_lds) lead_in(nh_lds + u * Rcap);
+            else lead_in(gnh + (size_t)u * Rcap);
+            int m = TAB_LDS ? walk8(hop8_lds + u * Scap) : walk8(ghop8 + (size_t)u * Scap);
+            m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
+            if (have && j == 0) {
+                const int n = m + 1;  // lane 0 always records the current position
+                // last waypoint that can be occupied within the horizon; only those enter the per-key index
+                const int tpc = a_tpc[i];
+                const int horizon = CUTILS ? (X.Tn - 2) / tpc + 1 : (X.Tn - 1) / tpc;
+                a_lp[i] = (uint16_t)max(0, min(n - 1, horizon));
+                a_n[i] = (uint16_t)n;
+                if (dual) {  // the upstream path is a prefix of this one (see stage 2 below)
+                    const int tpc2 = a_tpc2[i];
+                    const int n_py = (n - 1 < P.tree_pred) ? n : P.tree_pred;
+                    a_lp2[i] = (uint16_t)max(0, min(n_py - 1, (Tn2 - 1) / tpc2));
+                }
+            }
+        }
+        if (wsel >= 0) __builtin_amdgcn_s_setprio(0);
+#ifdef FL_OBS_TIMING
+        if (wsel >= 0 && lane == 0) atomicMax((unsigned long long *)&X.dbg[21], (unsigned long long)wall_clock64());
+#endif
+        {
+            const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
+#ifdef FL_OBS_TIMING
+            const long long t_pa0 = (long long)wall_clock64();
+#endif
+            if (CUTILS && !bk) {  // pass A of the team's first tree
+                int node_base, levels;
+                const bool have = team_id < A;
+                cutils_pass_a(X, d, P, b, team_id, have, grp, gl,
+                              merged ? merged_table_c(wave_scr, min(team_id, OBS_MERGED_ROUND - 1)) : wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (N_WORDS_C * OBS_CAP_C),
+                              a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
+                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 1] : d.spk[b * A + (have ? team_id : 0)],
+                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 2] : d.malf[b * A + (have ? team_id : 0)], node_base, levels);
+                if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
+            }
+#ifdef FL_OBS_TIMING
+            if (lane == 0) {
+                atomicMax((unsigned long long *)&X.dbg[19], (unsigned long long)wall_clock64());
+                atomicMax((unsigned long long *)&X.dbg[23], (unsigned long long)((long long)wall_clock64() - t_pa0));
+            }
+#endif
+            // The wavefronts are done with their roles at very different times (no tree to build, a short walk, a deep
+            // tree): what is left of this phase is a queue of jobs that whoever is free takes -- the rest of phase 1, two agents a job
+            // (longest first: pass A of four upstream trees when both builders share one pass B, see trees_merged)
+            drain_jobs();
+        }
+#ifdef FL_OBS_TIMING
+        if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
+#endif
+        if (bk) {  // bucketed lists: one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+            __syncthreads();
+            for (int i = wave; i < A; i += (nt >> 6)) {
+                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const int lp = a_lp[i];
+                const int tpc = a_tpc[i], tlast = X.Tn - 1;
+                for (int k = lane; k <= lp; k += 64) {
+                    const int key = key_of(X, (int)(path[k] >> 2));
+                    const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
+                    const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
+                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    for (int bb = b1; bb <= b2; bb++) {
+                        const int kb = key * OBS_BK_NB + bb;
+                        atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                    }
+                    atomicAdd(&csr[key], b2 - b1 + 1);
+                }
+            }
+        }
+        } else if (!reuse) {
+            // second stage: the upstream path is the prefix of the cutils path kept by stage 1 -- it stops at the target
+            // (which ends the cutils path too) and after pred_depth waypoints (rail_env_shortest_paths.py:245-267)
+            for (int i = tid; i < A; i += nt) {
+                const int n_c = a_n[i];
+                const int n_py = (n_c - 1 < pred_depth) ? n_c : pred_depth;
+                const int horizon = (X.Tn - 1) / a_tpc[i];
+                a_lp[i] = (uint16_t)max(0, min(n_py - 1, horizon));
+            }
+            __syncthreads();
+            for (int i = wave; i < A; i += (nt >> 6)) {
+                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const int lp = a_lp[i];
+                for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
+            }
+        }
+        __syncthreads();
+        OBS_STAMP(3);
+        // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan.  With the second
+        // index both counts share the scan, 16 bits each (the launcher guarantees totals below 65536).
+        if (!reuse) {
+            const int chunk = (K + 1 + nt - 1) / nt;
+            const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
+            int sum = 0;
+            int longest = 0;
+            for (int k = lo; k < hi; k++) {
+                sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
+                longest = max(longest, dual ? max(csr[k], csr2[k]) : csr[k]);
+            }
+            if (longest > CF_DIRECT) misc[11] = 1;  // (lists of the bucketed index count an item once per bucket: they only look longer)
+            partial[tid] = sum;
+            __syncthreads();
+            if (wave == 0) {
+                // each lane of wave 0 owns nt / 64 consecutive partials
+                constexpr int PER = OBS_NT / 64;
+                const int per = nt >> 6;
+                int loc[PER], tot = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { loc[q] = q < per ? partial[lane * per + q] : 0; tot += loc[q]; }
+                int incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+                int run = incl - tot;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { if (q < per) partial[lane * per + q] = run; run += loc[q]; }
+            }
+            __syncthreads();
+            int run = partial[tid];
+            if (dual) {
+                for (int k = lo; k < hi; k++) {
+                    const int v = csr[k] | (csr2[k] << 16);
+                    csr[k] = run & 0xFFFF; csr2[k] = (int)((unsigned)run >> 16);
+                    run += v;
+                }
+                if (hi == K + 1 && lo < hi) { misc[2] = run & 0xFFFF; misc[3] = (int)((unsigned)run >> 16); }
+            } else {
+                for (int k = lo; k < hi; k++) { const int v = csr[k]; csr[k] = run; run += v; }  // csr[k] = start of key k
+                if (hi == K + 1 && lo < hi) misc[2] = run;                                      // total number of items
+            }
+        }
+        __syncthreads();
+        if (reuse) {  // stage 1 built this index
+            csr = csr2; X.csr_end = csr2; X.items_lds = items2;
+            X.tmask = P.use_tmask ? tmaskb : nullptr;
+            if (!X.tmask) { X.wl_occ_cap = wl_entries; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
+        }
+        if (bk) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
+            for (int key = tid; key < K; key += nt) {
+                uint32_t *w4 = bkc + key * (OBS_BK_NB / 2);
+                uint32_t run = 0;
+#pragma unroll
+                for (int q = 0; q < OBS_BK_NB / 2; q++) {
+                    const uint32_t v = w4[q], c0 = v & 0xFFFFu, c1 = v >> 16;
+                    w4[q] = run | ((run + c0) << 16);
+                    run += c0 + c1;
+                }
+            }
+            __syncthreads();
+        }
+        const bool fit = items_lds != nullptr && misc[2] <= L.items_cap;
+        const bool dual_fill = dual && misc[3] <= L.items2_cap;
+        if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
+        if (merged && !dual_fill) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);  // (cannot happen: the LDS copy holds the exact bound)
+        if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
+        // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
+        // one wavefront per agent, one lane per waypoint
+        for (int i = wave; !reuse && i < A; i += (nt >> 6)) {
+            const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
+            const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
+            for (int k = lane; k <= lp; k += 64) {
+                const uint32_t w = path[k];
+                const uint32_t dnext = k < lp ? (path[k + 1] & 3u) : (w & 3u), dprev = k > 0 ? (path[k - 1] & 3u) : (w & 3u);
+                // closed time interval during which the agent is predicted on waypoint k
+                int tlo, span;
+                if (CUTILS) {  // w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp) afterwards
+                    tlo = k == 0 ? 0 : (k - 1) * tpc + 1;
+                    span = k == 0 ? 1 : tpc;
+                } else {       // w(t) = min(t / tpc, lp)
+                    tlo = k * tpc;
+                    span = tpc;
+                }
+                const bool to_end = k == lp || tlo + span - 1 >= tlast;
+                const int key = key_of(X, (int)(w >> 2));
+                if (X.tmask) {  // time buckets this item covers
+                    const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
+                    const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
+                    if (X.tmask_m2) {
+                        const unsigned long long seen = atomicOr(&tmask[key], bits);
+                        if (seen & bits) atomicOr(&tmask_m2[key], seen & bits);  // covered by a second item
+                    } else {
+                        atomicOr(&tmask[key], bits);
+                    }
+                }
+                const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                                      ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
+                    const int thi = to_end ? tlast : tlo + span - 1;
+                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    for (int bb = b1; bb <= b2; bb++) {
+                        const int kb = key * OBS_BK_NB + bb;
+                        const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                        csr_items[csr[key] + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
+                    }
+                    continue;
+                }
+                const int slot = atomicAdd(&csr[key], 1);
+                csr_items[slot] = item;
+                if (k <= lp2) {  // the same waypoint in the upstream predictor's index: w(t) = min(t / tpc, lp)
+                    const int tlo2 = k * tpc2, tlast2 = Tn2 - 1;
+                    const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
+                    const uint32_t dnext2 = k < lp2 ? dnext : (w & 3u);
+                    if (P.use_tmask) {
+                        const int b1 = min(tlo2 >> tshift2, 63), b2 = min((to_end2 ? tlast2 : tlo2 + tpc2 - 1) >> tshift2, 63);
+                        const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
+                        if (X.tmask_m2) {
+                            const unsigned long long seen = atomicOr(&tmaskb[key], bits);
+                            if (seen & bits) atomicOr(&tmaskb_m2[key], seen & bits);
+                        } else {
+                            atomicOr(&tmaskb[key], bits);
+                        }
+                    }
+                    const int slot2 = atomicAdd(&csr2[key], 1);
+                    items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
+                                    ((uint32_t)(tpc2 - 1) << 6) | (dprev << 4) | (dnext2 << 2) | (w & 3u);
+                }
+            }
+        }
+        __syncthreads();
+        if (bk) {  // bucket ends of every key to HBM (the node tables take their LDS back), list of key k = [csr[k], csr[k + 1])
+            uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
+            for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) g[k] = bkc[k];
+            X.csr_end = csr + 1;
+            X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
+            __syncthreads();
+        }
+    }
+
+    OBS_STAMP(4);
+    // ---- phase 3: trees.  Pass A derives the topology of a tree from the static segment table (O(1) per node, one
+    // BFS level per step); pass B evaluates the agent-dependent features with the visited cells of all nodes split
+    // evenly over the lanes of the workgroup (wg_pass_b); then one lane per node writes its row.
+    const float max_dist = (float)T;
+    const int nwaves = nt >> 6;
+    const bool items_in_lds = X.items_lds != nullptr;
+    if (merged) {
+        if (items_in_lds) trees_merged<true, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        else trees_merged<false, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+    } else if (CUTILS) {
+        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+    } else if (P.compact_t) {
+        if (items_in_lds) tree_upstream<16, OBS_CAP_T_COMPACT, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        else tree_upstream<16, OBS_CAP_T_COMPACT, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+    } else if (P.max_depth <= 2) {
+        if (items_in_lds) tree_upstream<32, 32, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        else tree_upstream<32, 32, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+    } else {
+        if (items_in_lds) tree_upstream<64, 88, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        else tree_upstream<64, 88, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+    }
+    OBS_STAMP(5);
+#undef LDS_AT
+#undef LDS_OPT
+}
+
+// MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch (two stages), 3 = both with one pass B per
+// round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents); VAR: see obs_body
+template <int MODE, int VAR>
+__global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
+    if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
+    else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
+    else if (MODE == 3) obs_body<true, VAR, 1, 1>(d, S, P);
+    else if (MODE == 4) obs_body<true, VAR, 1, 2>(d, S, P);
+    else {
+        obs_body<true, VAR, 1>(d, S, P);
+        __syncthreads();
+        obs_body<false, VAR, 2>(d, S, P);
+    }
+}
+

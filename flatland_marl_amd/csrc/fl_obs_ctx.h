@@ -45,7 +45,8 @@ struct ObsCtx {
     int tshift;
     // pass B over the trees of BOTH builders at once (PB = 2): teams below n_cu are flatland_cutils trees and use the members
     // above, the others are upstream trees and use the upstream predictor's index:
-    int n_cu;
+    int n_cu;                     // (= OBS_MERGED_ROUND: teams below are flatland_cutils trees)
+    int round_base;               // first agent of the round of trees being built
     const int *u_csr_end;
     const uint32_t *u_items;
     const unsigned long long *u_tmask;
@@ -74,7 +75,7 @@ __device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 
 // the agent of a team: from the team table, or -- both builders in one pass -- from the numbering of trees_merged (no memory access)
 template <int PB>
 __device__ __forceinline__ int pb_handle(const ObsCtx &X, const int *team_meta, int team) {
-    return PB == 2 ? (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
+    return PB == 2 ? X.round_base + (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
 }
 // predicted time at which the walking agent reaches a cell tot steps away (treeobs.cpp:378 / observations.py:329)
 template <int PB>

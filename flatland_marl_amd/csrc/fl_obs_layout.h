@@ -103,12 +103,15 @@ struct ObsArgs {
     int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
     int bk;            // large maps: the cutils index is grouped by time bucket (OBS_BK_NB); built in the node tables' LDS
-    int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged)
+    int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged); 1: one round (at most 32 agents), 2: several
+    int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
 };
 
-// kernel launchers, one translation unit per MODE (0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch);
+// kernel launchers, one translation unit per MODE (0 = flatland_cutils outputs, 1 = upstream dense tree, 2 / 3 = both in one launch);
 // var: see obs_body (1 = static tables in LDS, 2 = work lists in HBM scratch)
 int fl_obs_launch_m0(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_m1(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_m2(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_m3(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B, one round
+int fl_obs_launch_m4(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B per round of 32 agents

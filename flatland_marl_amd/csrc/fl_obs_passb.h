@@ -77,8 +77,10 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
     };
     // separate call sites so that each keeps a static address space; whole lists in HBM scratch (large maps without time
     // masks) are fetched in bigger batches: their round trips are what the scan costs
-    if (second) scan(X.u_items, std::integral_constant<int, 8>());      // (the second index is always LDS-resident)
-    else if (ITL) scan(X.items_lds, std::integral_constant<int, 8>());
+    // (one call site for the two LDS copies: the lanes of a wavefront work on entries of both builders, two sites would run
+    // one after the other)
+    if (ITL) scan(second ? X.u_items : X.items_lds, std::integral_constant<int, 8>());
+    else if (second) scan(X.u_items, std::integral_constant<int, 8>());      // (the second index is always LDS-resident)
     else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK>());  // chunked work-list entries: the whole chunk in flight at once
     else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
     return flags;
@@ -163,7 +165,8 @@ __device__ __forceinline__ void team_sync() {
 //
 // N_INCL word of node k: inclusive prefix (24 bits) | index of the next node with cells << 24 (0xFF = none).
 // Returns the team's number of cells; first_real = its first node with cells (0xFF = none).
-template <int TEAM, int CAP, bool UPSTREAM>
+// CAP = slots of the table, STRIDE = words between its fields (CAP, or 32 when two 16-slot tables share one, see team_table)
+template <int TEAM, int CAP, bool UPSTREAM, int STRIDE = CAP>
 __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int *scr, int &first_real) {
     constexpr int NCH = (CAP + TEAM - 1) / TEAM;
     const int tbase = ((int)__lane_id() / TEAM) * TEAM;
@@ -173,7 +176,7 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int k = c * TEAM + tl;
-        v[c] = (have && k < n_nodes && k < CAP) ? nt_vis((uint32_t)nt_r(scr, CAP, N_TV, k)) : 0;  // (an empty slot has no cells)
+        v[c] = (have && k < n_nodes && k < CAP) ? nt_vis((uint32_t)nt_r(scr, STRIDE, N_TV, k)) : 0;  // (an empty slot has no cells)
         real[c] = (__ballot(v[c] > 0) >> tbase) & tbits;
     }
     int run_base = 0;
@@ -191,11 +194,11 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
         const unsigned long long above = tl + 1 < TEAM ? real[c] >> ((tl + 1) & 63) : 0ull;
         if (above) nxt = k + __ffsll((long long)above);
         if (k < CAP) {
-            nt_w(scr, CAP, N_INCL, k) = incl | (nxt << 24);
-            nt_w(scr, CAP, N_OA, k) = 0x7fffffff; nt_w(scr, CAP, N_PC, k) = 0x7fffffff;
-            nt_w(scr, CAP, N_CNT, k) = 0; nt_w(scr, CAP, N_RM, k) = 0;
-            nt_w(scr, CAP, N_MS, k) = -1;  // nobody slower than 1.0
-            if (UPSTREAM) { nt_w(scr, CAP, N_OT, k) = 0x7fffffff; nt_w(scr, CAP, N_MALF, k) = 0; }
+            nt_w(scr, STRIDE, N_INCL, k) = incl | (nxt << 24);
+            nt_w(scr, STRIDE, N_OA, k) = 0x7fffffff; nt_w(scr, STRIDE, N_PC, k) = 0x7fffffff;
+            nt_w(scr, STRIDE, N_CNT, k) = 0; nt_w(scr, STRIDE, N_RM, k) = 0;
+            nt_w(scr, STRIDE, N_MS, k) = -1;  // nobody slower than 1.0
+            if (UPSTREAM) { nt_w(scr, STRIDE, N_OT, k) = 0x7fffffff; nt_w(scr, STRIDE, N_MALF, k) = 0; }
         }
         run_base = __shfl(incl, TEAM - 1, TEAM);
     }
@@ -216,16 +219,17 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 // The loop of step 1 is a chain of LDS round trips, so it is software-pipelined by hand: everything the NEXT cell needs
 // (rail word, successor, time mask, the next node's descriptor when the walk ends here) is requested while the work-list
 // reservation of the current cell is in flight -- about one round trip per cell.
-// Tables: PB 0 / 1: team t's table is scr0 + t * team_words with CAP slots.  PB 2 (both builders): the teams below X.n_cu are
-// flatland_cutils trees (OBS_CAP_C slots, N_WORDS_C words), the others upstream trees (X.cap_t slots, N_WORDS_T words) behind them.
+// Tables: PB 0 / 1: team t's table is scr0 + t * team_words, fields CAP words apart.  PB 2 (both builders, trees_merged): the
+// teams below OBS_MERGED_ROUND are flatland_cutils trees (32 slots, N_WORDS_C fields of 32 words); behind them the compact
+// upstream trees, TWO to a table of N_WORDS_T fields of 32 words (tree u uses the slots (u & 1) * 16 ... + 15 of every field):
+// the field stride is 32 words for every team, a compile-time constant in the classify loop.
+#define OBS_MERGED_ROUND 32
 template <int PB, int CAP>
-__device__ __forceinline__ int *team_table(const ObsCtx &X, int *scr0, int team_words, int team, int &cap) {
+__device__ __forceinline__ int *team_table(const ObsCtx &X, int *scr0, int team_words, int team) {
     if (PB == 2) {
-        const bool cu = team < X.n_cu;
-        cap = cu ? OBS_CAP_C : X.cap_t;
-        return cu ? scr0 + team * (N_WORDS_C * OBS_CAP_C) : scr0 + X.n_cu * (N_WORDS_C * OBS_CAP_C) + (team - X.n_cu) * (N_WORDS_T * X.cap_t);
+        const int u = team - OBS_MERGED_ROUND;
+        return u < 0 ? scr0 + team * (N_WORDS_C * 32) : scr0 + OBS_MERGED_ROUND * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
     }
-    cap = CAP;
     return scr0 + team * team_words;
 }
 
@@ -269,8 +273,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     int dbg_skip = 0;
 #endif
     if (pos < end) {
-        int cap;
-        const int *vs = team_table<PB, CAP>(X, scr0, team_words, team, cap);
+        constexpr int cap = PB == 2 ? 32 : CAP;   // words between the fields of a node table
+        const int *vs = team_table<PB, CAP>(X, scr0, team_words, team);
         int nn = team_meta[64 + team];
         int handle = pb_handle<PB>(X, team_meta, team);
         // first node of the team whose inclusive prefix exceeds the team-local position: three pivots per round trip
@@ -360,7 +364,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             const uint32_t e_dd = dd;
             const bool e_cu = cu;
             int *sc = const_cast<int *>(vs);
-            const int e_cap = cap;
+            constexpr int e_cap = cap;
             const uint2 entry = make_uint2(((uint32_t)cell << 2) | dd | ((uint32_t)team << 24), (uint32_t)tot | ((uint32_t)node << 24));
             // occupant?
             const uint32_t sl = cw >> 16;
@@ -409,7 +413,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                         node = nxt;
                     } else {  // next team with cells (the prefix says cells remain)
                         do { team++; } while (team < n_teams - 1 && team_meta[team] == 0);
-                        vs = team_table<PB, CAP>(X, scr0, team_words, team, cap);
+                        vs = team_table<PB, CAP>(X, scr0, team_words, team);
                         nn = team_meta[64 + team];
                         handle = pb_handle<PB>(X, team_meta, team);
                         node = team_meta[256 + team];
@@ -463,8 +467,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     for (int e = tid; e < n_occ; e += nt) {
         const uint2 w = X.wl_occ[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        int cap;
-        int *sc = team_table<PB, CAP>(X, scr0, team_words, team, cap);
+        constexpr int cap = PB == 2 ? 32 : CAP;
+        int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
         occ_event(X, pb_cu<PB>(X, team), sc, cap, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
     WAVE_MARK(X, 12, -1);
@@ -478,8 +482,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             int lo, hi;
             list_range<PB>(X, cu, cell, pt, lo, hi);
             if (hi > lo && conflict_hit(conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo, hi))) {
-                int cap;
-                int *sc = team_table<PB, CAP>(X, scr0, team_words, team, cap);
+                constexpr int cap = PB == 2 ? 32 : CAP;
+                int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
             }
         }
@@ -546,8 +550,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #endif
         if (nch == 1) {
             if (conflict_hit(f)) {
-                int cap;
-                int *sc = team_table<PB, CAP>(X, scr0, team_words, team, cap);
+                constexpr int cap = PB == 2 ? 32 : CAP;
+                int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(fy >> 24)), tot);
             }
         } else {
@@ -563,8 +567,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             w.y = wl_flags(X, &X.wl_cf[e]);
             if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) {
-                int cap;
-                int *sc = team_table<PB, CAP>(X, scr0, team_words, (int)(w.x >> 24), cap);
+                constexpr int cap = PB == 2 ? 32 : CAP;
+                int *sc = team_table<PB, CAP>(X, scr0, team_words, (int)(w.x >> 24));
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), (int)(w.y & 511u));
             }
         }

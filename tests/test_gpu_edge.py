@@ -369,31 +369,3 @@ def test_fused_step_after_episode_end_raises_like_the_reference():
     env.step_obs(np.zeros((1, env.A), dtype=np.uint8))
     with pytest.raises(EpisodeDoneError):
         env.check()
-
-
-@pytest.mark.parametrize("workload,depth,expect", [
-    # threads, the env's static tables in LDS, work lists in LDS (bytes; 0 = HBM scratch), time masks, second index of the fused
-    # launch, items in LDS -- the LDS budget is tight: a few hundred bytes more per workgroup silently cost a configuration
-    # (and 20 % throughput) once.  Depth 2 is the bench default, depth 3 is BASELINE's definition of configs[2] / configs[4].
-    ("cfg2", 2, dict(nt=1024, tab=0, wl=24576, tmask=1, dual=1, items=1)),  # one pass B for both builders: twice the node tables
-    ("cfg2", 3, dict(nt=1024, tab=0, wl=24576, tmask=1, dual=1, items=1)),
-    ("cfg3", 2, dict(nt=1024, tab=0, wl=24576, tmask=1, dual=1, items=1)),
-    ("cfg3", 3, dict(nt=1024, tab=0, wl=0, tmask=1, dual=1, items=1)),
-    ("cfg4", 2, dict(nt=1024, tab=0, wl=24576, tmask=1, dual=1, items=1)),
-    ("cfg4", 3, dict(nt=1024, tab=0, wl=0, tmask=1, dual=0, items=1)),
-    ("cfg5", 2, dict(nt=1024, tab=0, wl=0, tmask=1, dual=0, items=0)),
-    ("cfg5", 3, dict(nt=512, tab=0, wl=0, tmask=1, dual=0, items=0)),
-])
-def test_observation_launch_configuration_of_the_bench_workloads(workload, depth, expect):
-    import ctypes
-    from flatland_marl_amd import workload as wl
-    from flatland_marl_amd import hip_backend as hb
-    envs, _ = wl.make_envs(workload, B=1)
-    env = _env(envs)
-    L = hb.lib()
-    L.fl_debug_obs_config.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    out = (ctypes.c_int * 8)()
-    assert L.fl_debug_obs_config(env.h, 500, depth, 30, out) == 0
-    got = dict(nt=out[0], tab=out[2], wl=out[4], tmask=out[5], dual=out[6], items=out[7])
-    assert got == expect, (workload, depth, list(out))
-    assert out[1] <= 160 * 1024

@@ -1,0 +1,55 @@
+"""CPU: the launch configuration obs_pick_config (csrc/fl_obs.hip) chooses for the fused observation launch of every bench
+workload -- threads, what lives in LDS, one pass B for both builders, compact upstream trees.  The LDS budget (160 KiB a
+workgroup) is tight: a few hundred bytes more silently cost a configuration (and 20 % throughput) once, so the choices are
+pinned here.  Host code only (fl_debug_obs_config_of needs no GPU)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from flatland_marl_amd import hip_backend as hb
+from flatland_marl_amd import workload as wl
+
+KEYS = ("nt", "lds", "tab", "nh", "wl", "tmask", "dual", "items", "merged", "compact")
+
+
+def _config(A, R, U, depth, tall=0, max_branch=2, pred=500, tree_pred=30):
+    L = ctypes.CDLL(hb.LIB_PATH)       # plain dlopen: no torch, no GPU
+    out = (ctypes.c_int * 10)()
+    assert L.fl_debug_obs_config_of(A, R, U, tall, max_branch, pred, depth, tree_pred, out) == 0
+    return dict(zip(KEYS, out))
+
+
+def _sizes(workload):
+    envs, _ = wl.make_envs(workload, B=len(wl.WORKLOADS[workload]["bases"]))
+    A = len(envs[0]["init_dir"])
+    R = max(int((np.asarray(e["grid"]) != 0).sum()) for e in envs)
+    U = max(len({tuple(t) for t in np.asarray(e["target"]).tolist()}) for e in envs)
+    return A, R, U
+
+
+@pytest.mark.parametrize("workload,depth,expect", [
+    # depth 2 is the bench default, depth 3 is BASELINE's definition of configs[2] / configs[4].
+    # merged: one pass B for the trees of both builders (1 = one round, 2 = rounds of 32 agents); wl = 0: work lists in HBM scratch
+    ("cfg2", 2, dict(nt=1024, wl=24576, tmask=1, dual=1, items=1, merged=1, compact=1)),
+    ("cfg3", 3, dict(nt=1024, wl=36864, tmask=1, dual=1, items=1, merged=2, compact=1)),
+    ("cfg4", 2, dict(nt=1024, wl=0, tmask=1, dual=1, items=1, merged=2, compact=1)),
+    ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),
+    ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),   # round 2: 512 threads (85-slot tables)
+])
+def test_observation_launch_configuration_of_the_bench_workloads(workload, depth, expect):
+    got = _config(*_sizes(workload), depth)
+    assert {k: got[k] for k in expect} == expect, got
+    assert got["lds"] <= 160 * 1024
+
+
+def test_largest_round2_map_keeps_sixteen_wavefronts():
+    got = _config(425, 2710, 60, 3)        # Test_14: 158x158, 425 agents, 41 cities (tests/golden/gen_Test_14_L0.npz)
+    assert got["nt"] == 1024 and got["compact"] == 1 and got["lds"] <= 160 * 1024, got
+
+
+def test_grids_with_three_way_cells_take_the_dfs_slot_tables():
+    got = _config(20, 213, 5, 3, max_branch=3)
+    assert got["compact"] == 0 and got["merged"] == 0, got
+    got = _config(20, 213, 5, 2, tall=1)   # colliding prediction keys: two stages
+    assert got["merged"] == 0 and got["compact"] == 1, got
