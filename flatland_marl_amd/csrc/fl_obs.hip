@@ -11,7 +11,7 @@
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
     o.pred_cap = FL_OBS_MAX_PRED + 2;
-    o.items_cap = (size_t)d.A * (o.pred_cap + 2 * OBS_BK_NB + 2);  // bucketed lists: an item sits in every time bucket it touches
+    o.items_cap = (size_t)d.A * (o.pred_cap + 2 * OBS_FB_NB + 2);  // bucketed lists: an item sits in every time bucket it touches
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;
     if (hipMalloc(&p, BA * o.pred_cap * 2) != hipSuccess) return FL_ERR_HIP;
@@ -36,7 +36,7 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
 }
 
 // what a launch may keep in LDS besides the arrays every launch needs
-struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter; };
+struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb; };
 
 // carve the dynamic LDS of a launch: every array the kernel uses, in one place (the kernel follows ObsLayout::off)
 static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &o) {
@@ -82,6 +82,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
         put(L_ITEMS2, (size_t)std::max(L.items2_cap, 4) * 4);
         put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2); put(L_A_TQ2, A * 8);
     }
+    if (o.fb) put(L_BKREL, K1 * OBS_FB_NB * 2);
     if (o.tab) { put(L_SEG, NS * 16); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
     L.total = (unsigned)off;
     L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
@@ -131,28 +132,37 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP) {
         P.merged = d.A <= 32 ? 1 : 2;
         o.nt = OBS_NT; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
-        // (a round of 64 trees meets more occupied cells than a round of 32: a larger share of larger lists)
-        static const int wl_variants[5] = {36 * 1024, 24 * 1024, 16 * 1024, 0, 8 * 1024};  // 0: the work lists in HBM scratch
+        // Order of preference, from same-box sweeps (tools/gpu_env_sweep.sh).  One round (at most 32 agents, cfg2): 24 KB of LDS work
+        // lists, the items in LDS, plain lists (the extra counting pass of the bucketed lists costs more than their short scans
+        // save: 57.9 against 51.8 us).  Rounds of 32 agents: a round of 64 trees meets thousands of occupied cells, and a work
+        // list that overflows is handled cell by cell inside the classify loop (cfg3: 1.04 ms with 24 KB, 0.82 ms with 36 KB) -- so
+        // 36 KB of LDS lists, or else the lists in HBM scratch (no cap); the items in LDS before anything else (cfg4: 0.45 against
+        // 0.52 ms); lists grouped by 32-step time buckets where their offsets fit too (cfg4: 0.48 -> 0.45 ms, cfg3 neutral).
+        struct Pref { int fb, wl, items; };
+        static const Pref one_round[] = {{0, 24 * 1024, 1}, {0, 16 * 1024, 1}, {0, 0, 1}, {0, 24 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
+        static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 1}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
+                                      {1, 0, 0}, {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
         static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
-        for (o.own_filter = no_own ? 0 : 1; o.own_filter >= 0; o.own_filter--)
-            for (int wk = d.A <= 32 ? 1 : 0; wk < 5; wk++) {
-                o.wl_bytes = wl_variants[wk];
-                if (!ok(force.wl, o.wl_bytes)) continue;
-                for (o.items = 1; o.items >= 0; o.items--) {
-                    if (!ok(force.items, o.items) || (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP)) continue;
-                    if (o.own_filter && !o.items) continue;  // the filter's masks are built by the LDS fill
-                    for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
-                        if (!ok(force.nh, o.nh)) continue;
-                        const ObsLayout L = obs_layout(d, P, o);
-                        if (L.total > lds_limit) continue;
-                        P.L = L; P.use_tmask = 1; P.dual_index = 1; P.bk = 0;
-                        P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
-                        // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
-                        P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
-                        return true;
-                    }
+        static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
+        static const bool all_fb = getenv("FL_OBS_FB") != nullptr;   // diagnostic: bucketed lists in the one-round mode too
+        const Pref *prefs = P.merged == 1 ? one_round : rounds;
+        const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : (int)(sizeof rounds / sizeof rounds[0]);
+        for (int pk = 0; pk < n_prefs; pk++) {
+            o.fb = (prefs[pk].fb || all_fb) && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
+            if ((o.fb && no_fb) || !ok(force.wl, o.wl_bytes) || !ok(force.items, o.items) || (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP)) continue;
+            for (o.own_filter = (no_own || !o.items) ? 0 : 1; o.own_filter >= 0; o.own_filter--)  // (the filter's masks are built by the LDS fill)
+                for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
+                    if (!ok(force.nh, o.nh)) continue;
+                    const ObsLayout L = obs_layout(d, P, o);
+                    if (L.total > lds_limit) continue;
+                    P.L = L; P.use_tmask = 1; P.dual_index = 1;
+                    P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
+                    P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
+                    // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
+                    P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
+                    return true;
                 }
-            }
+        }
         P.merged = 0;
     }
     o = ObsOptions();
@@ -186,7 +196,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                 else if (force.tab == 1) continue;
                             } else if (force.tab == 1) continue;
                             P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
-                            P.bk = o.bk_room;
+                            P.bk = o.bk_room; P.bk_nb = OBS_BK_NB; P.bk_shift = OBS_BK_SHIFT;
                             // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
                             // whole horizon measured slower on every map size)
                             P.tshift = force_tshift >= 0 ? force_tshift : OBS_TSHIFT;

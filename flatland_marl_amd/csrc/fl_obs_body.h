@@ -184,6 +184,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // (with a job queue in phase 2 -- cutils builder in the launch, a predictor, a wavefront left beside the walkers -- the rows
         // are pre-filled there by whoever is free, beside the path walk, instead of here by everybody)
         const int nw_walk0 = min((nt >> 6) - ((nt >> 6) > 4 ? 1 : 0), max(2, (A + 7) / 8));
+        // (a slice of the pre-fill in every round of the first stage's trees instead measured slower at cfg5, 1.73 against 1.65 ms:
+        // the next global load of a wavefront waits for its stores)
         bg_prefill = CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6);
         if ((!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill) {
             // the upstream trees of the env: every row that is not a real node is -inf (observations.py:247, 489); the builders
@@ -240,7 +242,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tq = a_tq; X.a_tslot = a_tslot; X.a_target = a_target; X.a_srank = a_srank;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
-    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr;
+    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr; X.bk_rel_lds = nullptr;
+    X.bk_nb = P.bk_nb; X.bk_shift = P.bk_shift;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
@@ -500,13 +503,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
         // large maps: bucketed lists (OBS_BK_NB).  Their per-(key, bucket) counters -- u16, two per word -- live in the node
         // tables' LDS while the index is built (so no tree work is hoisted beside the walk), the offsets go to HBM afterwards
+        // (P.bk 1).  Small maps (P.bk 2): finer buckets, counters and offsets in an LDS array of their own.
         const bool bk = CUTILS && STAGE != 2 && P.bk != 0 && X.Tn > 64 && X.tmask != nullptr;
-        uint32_t *bkc = reinterpret_cast<uint32_t *>(wave_scr);
+        const bool bk_lds = bk && P.bk == 2;
+        const int bk_nb = P.bk_nb, bk_shift = P.bk_shift;
+        uint32_t *bkc = bk_lds ? LDS_AT(uint32_t, L_BKREL) : reinterpret_cast<uint32_t *>(wave_scr);
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (tid == 0) misc[11] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
-            if (bk) for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) bkc[k] = 0u;
+            if (bk) for (int k = tid; k < K * bk_nb / 2; k += nt) bkc[k] = 0u;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
         __syncthreads();
@@ -560,9 +566,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     if (alive) {
                         path[idx] = (uint16_t)st;
                         last = idx;
-                        if (idx <= hz1) {
+                        if (idx <= hz1 || idx <= hz2) {
                             const int key = key_of(X, (int)(st >> 2));
-                            atomicAdd(&csr[key], 1);
+                            if (idx <= hz1) atomicAdd(&csr[key], 1);
                             if (idx <= hz2) atomicAdd(&csr2[key], 1);
                         }
                         const uint32_t s8 = idx + 8 < n_max ? (uint32_t)h8[st] : (uint32_t)FL_R_NONE;
@@ -600,7 +606,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
             const long long t_pa0 = (long long)wall_clock64();
 #endif
-            if (CUTILS && !bk) {  // pass A of the team's first tree
+            if (CUTILS && (!bk || bk_lds)) {  // pass A of the team's first tree (not while the node tables hold the bucket counters)
                 int node_base, levels;
                 const bool have = team_id < A;
                 cutils_pass_a(X, d, P, b, team_id, have, grp, gl,
@@ -634,9 +640,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const int key = key_of(X, (int)(path[k] >> 2));
                     const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
                     const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
-                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
                     for (int bb = b1; bb <= b2; bb++) {
-                        const int kb = key * OBS_BK_NB + bb;
+                        const int kb = key * bk_nb + bb;
                         atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                     }
                     atomicAdd(&csr[key], b2 - b1 + 1);
@@ -672,7 +678,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 sum += dual ? (csr[k] | (csr2[k] << 16)) : csr[k];
                 longest = max(longest, dual ? max(csr[k], csr2[k]) : csr[k]);
             }
-            if (longest > CF_DIRECT) misc[11] = 1;  // (lists of the bucketed index count an item once per bucket: they only look longer)
+            // (a query of the bucketed index scans two or three buckets of a list: see below)
+            if (longest > CF_DIRECT && !bk) misc[11] = 1;
             partial[tid] = sum;
             __syncthreads();
             if (wave == 0) {
@@ -711,14 +718,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         if (bk) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
             for (int key = tid; key < K; key += nt) {
-                uint32_t *w4 = bkc + key * (OBS_BK_NB / 2);
-                uint32_t run = 0;
-#pragma unroll
-                for (int q = 0; q < OBS_BK_NB / 2; q++) {
+                uint32_t *w4 = bkc + key * (bk_nb / 2);
+                uint32_t run = 0, prev = 0, most = 0;  // most: the longest run of three consecutive buckets (what one query can scan)
+                for (int q = 0; q < bk_nb / 2; q++) {
                     const uint32_t v = w4[q], c0 = v & 0xFFFFu, c1 = v >> 16;
+                    most = max(most, max(prev + c0 + c1, c0 + c1));
+                    prev = c0 + c1;
                     w4[q] = run | ((run + c0) << 16);
                     run += c0 + c1;
                 }
+                if (most > CF_DIRECT) misc[11] = 1;
             }
             __syncthreads();
         }
@@ -761,16 +770,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                                       ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
                 if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
                     const int thi = to_end ? tlast : tlo + span - 1;
-                    const int b1 = min(tlo >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(thi >> OBS_BK_SHIFT, OBS_BK_NB - 1);
+                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
                     for (int bb = b1; bb <= b2; bb++) {
-                        const int kb = key * OBS_BK_NB + bb;
+                        const int kb = key * bk_nb + bb;
                         const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                         csr_items[csr[key] + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
                     }
-                    continue;
+                } else {
+                    const int slot = atomicAdd(&csr[key], 1);
+                    csr_items[slot] = item;
                 }
-                const int slot = atomicAdd(&csr[key], 1);
-                csr_items[slot] = item;
                 if (k <= lp2) {  // the same waypoint in the upstream predictor's index: w(t) = min(t / tpc, lp)
                     const int tlo2 = k * tpc2, tlast2 = Tn2 - 1;
                     const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
@@ -792,12 +801,17 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         __syncthreads();
-        if (bk) {  // bucket ends of every key to HBM (the node tables take their LDS back), list of key k = [csr[k], csr[k + 1])
-            uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
-            for (int k = tid; k < K * OBS_BK_NB / 2; k += nt) g[k] = bkc[k];
+        if (bk) {  // the list of key k is [csr[k], csr[k + 1]) now; the bucket ends of every key stay in LDS or go to HBM (the node
+                   // tables take their LDS back)
             X.csr_end = csr + 1;
-            X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
-            __syncthreads();
+            if (bk_lds) {
+                X.bk_rel_lds = reinterpret_cast<const uint16_t *>(bkc);
+            } else {
+                uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
+                for (int k = tid; k < K * bk_nb / 2; k += nt) g[k] = bkc[k];
+                X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
+                __syncthreads();
+            }
         }
     }
 

@@ -30,7 +30,9 @@ struct ObsCtx {
     const int *csr_end;           // LDS [K] end offset of key k's item list (start = csr_end[k-1], 0 for k = 0)
     const uint32_t *items_lds;    // IT_* packed items when they fit LDS ...
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
-    const uint16_t *bk_rel;       // HBM [K * OBS_BK_NB]: end of time bucket b inside key k's list, relative to the list's start;
+    const uint16_t *bk_rel_lds;   // the same table in LDS (small maps: finer buckets, see obs_body); at most one of the two is set
+    int bk_nb, bk_shift;          // number of time buckets of a list and log2 of their width in steps
+    const uint16_t *bk_rel;       // HBM [K * bk_nb]: end of time bucket b inside key k's list, relative to the list's start;
                                   // nullptr = lists not bucketed
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
@@ -93,9 +95,14 @@ __device__ __forceinline__ void list_range(const ObsCtx &X, bool cu, int r, int 
         return;
     }
     const int base = key > 0 ? X.csr_end[key - 1] : 0;
-    if (X.bk_rel) {
-        const int b1 = min(max(pt - 1, 0) >> OBS_BK_SHIFT, OBS_BK_NB - 1), b2 = min(min(pt + 1, X.Tn - 1) >> OBS_BK_SHIFT, OBS_BK_NB - 1);
-        const uint16_t *rel = X.bk_rel + (size_t)key * OBS_BK_NB;
+    if (X.bk_rel_lds) {  // (two call sites: each table keeps its address space)
+        const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
+        const uint16_t *rel = X.bk_rel_lds + key * X.bk_nb;
+        lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
+        hi = base + (int)rel[b2];
+    } else if (X.bk_rel) {
+        const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
+        const uint16_t *rel = X.bk_rel + (size_t)key * X.bk_nb;
         lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
         hi = base + (int)rel[b2];
     } else {

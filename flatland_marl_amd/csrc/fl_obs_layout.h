@@ -29,6 +29,10 @@
 // (an eighth of a busy cell's list instead of all of it).
 #define OBS_BK_NB 8
 #define OBS_BK_SHIFT 6
+// Small maps (index in LDS): sixteen buckets of 32 steps, their offsets in an LDS array of their own -- a query scans the
+// handful of items around its time instead of everybody who ever passes the cell (20 items a query at 80 agents).
+#define OBS_FB_NB 16
+#define OBS_FB_SHIFT 5
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
@@ -75,7 +79,7 @@ __host__ __device__ inline int obs_scr_words(int nwaves, int A, int tw_c, int tw
 // LDS arrays of a launch, in carving order (obs_layout on the host decides which exist and where)
 enum { L_CELLW = 0, L_NBR, L_SNEXT, L_RKEY, L_SLOT_AGENT, L_SLOT_READY, L_CELL_TARGET, L_A_SPEED, L_A_VPOS, L_A_POS, L_A_TSLOT,
        L_A_TARGET, L_A_MALF, L_A_TPC, L_A_TQ, L_A_TQ2, L_A_RAW, L_RTYPE, L_A_LP, L_A_N, L_A_SRANK, L_A_DIR, L_A_STATE, L_A_FREE, L_A_DEAD, L_MISC, L_TEAM_META, L_WAVE_SCR,
-       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_TMASK2, L_NH, L_CSR2, L_TMASKB, L_TMASKB2, L_ITEMS2, L_A_LP2, L_A_TPC2, L_SEG, L_DM, L_HOP8, L_COUNT };
+       L_CSR, L_ITEMS, L_WL, L_PARTIAL, L_TMASK, L_TMASK2, L_NH, L_CSR2, L_TMASKB, L_TMASKB2, L_ITEMS2, L_A_LP2, L_A_TPC2, L_BKREL, L_SEG, L_DM, L_HOP8, L_COUNT };
 #define L_ABSENT 0xFFFFFFFFu
 struct ObsLayout {
     unsigned off[L_COUNT];  // byte offset into the dynamic LDS, L_ABSENT = not in this launch
@@ -102,7 +106,9 @@ struct ObsArgs {
     int use_tmask;     // per-key time-bucket masks in LDS
     int tshift;        // width of their time buckets for horizons beyond 64 steps: 1 << tshift steps (bucket = min(t >> tshift, 63))
     int dual_index;    // fused launch: stage 1 also builds the upstream predictor's index (second set of LDS arrays)
-    int bk;            // large maps: the cutils index is grouped by time bucket (OBS_BK_NB); built in the node tables' LDS
+    int bk;            // the lists of the cutils index are grouped by time bucket: 1 = large maps (OBS_BK_NB buckets, counted in the node
+                       // tables' LDS, offsets in HBM scratch), 2 = small maps (OBS_FB_NB buckets, offsets in LDS: L_BKREL)
+    int bk_nb, bk_shift;
     int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged); 1: one round (at most 32 agents), 2: several
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)

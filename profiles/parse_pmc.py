@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_step<": "k_step<synth>"}
+NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_obs<3": "k_obs<cutils+tree>", "k_obs<4": "k_obs<cutils+tree>", "k_step<": "k_step<synth>"}
 
 
 def agg(d, counter):

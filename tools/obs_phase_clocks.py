@@ -35,6 +35,8 @@ for t in range(warm + 100):
         assert L.fl_debug_obs_clocks(env.h, out.ctypes.data) == 0
         acc.append(out)
 c = np.stack(acc).astype(np.float64)  # [steps, B, 64]
+# the kernels that build the trees of both builders in stage 1 have no stage 2: the kernel ends with stage 1's last stamp
+c[:, :, 37] = np.where(c[:, :, 37] > 0, c[:, :, 37], c[:, :, 5])
 
 
 def seg(a, b):
