@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict
         }
         const int cap = S;  // a longer walk has revisited a state
         int cur = s0, k = 0, unus = 0xFFFF;
-        uint32_t kind = SEG_ZERO;
+        uint32_t kind = SEG_ZERO, phantom = 0;
         while (true) {
             const uint32_t g = rg[cur >> 2];
             const uint32_t bits = nibble(g, cur & 3);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict
             if (num == 1) {
                 if (total == 1) { kind = SEG_DEAD_END; break; }
                 const int nx = seg_next(rg, nbr, cur);
-                if (nx < 0) { kind = SEG_ZERO; break; }
+                if (nx < 0) { kind = SEG_ZERO; phantom = 1; break; }  // (one transition, not a dead end: it leaves the rail)
                 cur = nx;
                 k++;
                 if (k > cap) {  // cycle: find the first revisited state (Brent), the walk is terminal there
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void k_segments(FlDev d, const int *__restrict
                 const uint32_t use = kind == SEG_DEAD_END ? (bd + 2u) & 3u : bd;
                 if ((pbits >> (3u - use)) & 1u) {
                     const uint32_t nr = nbr[ecell * 4u + use];
-                    if (nr != FL_R_NONE) kid[c] = (nr << 2) | use;
+                    kid[c] = nr != FL_R_NONE ? ((nr << 2) | use) : FL_R_PHANTOM;
                 }
             }
         }
-        out = make_uint4((uint32_t)cur | (kind << 20), (uint32_t)k | ((uint32_t)unus << 16), kid[0] | (kid[1] << 16), kid[2] | (kid[3] << 16));
+        out = make_uint4((uint32_t)cur | (kind << 20) | (phantom << 22), (uint32_t)k | ((uint32_t)unus << 16), kid[0] | (kid[1] << 16), kid[2] | (kid[3] << 16));
     }
     d.seg[(size_t)b * Scap + s0] = out;
     d.snext[(size_t)b * Scap + s0] = sn;

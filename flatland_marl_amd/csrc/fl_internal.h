@@ -26,7 +26,13 @@
 // x = end rail state | kind << 20;  y = steps to the end | first "unusable switch" offset << 16 (0xFFFF = none);
 // z, w = the start states of the end state's children left, forward | right, back (u16 each, FL_R_NONE = null cell):
 // treeobs.cpp:583-608 / observations.py:464-489 are a function of the end state alone
+// A transition that leaves the rail (a malformed map): the reference walks onto the empty cell, finds no transition there and
+// ends the walk as on a zero-transition cell (treeobs.cpp:528-535 throws, observations.py:420-425 makes the node terminal), with
+// the distance of that cell: inf.  Chain: kind SEG_ZERO + SEG_PHANTOM (the walk's last rail cell is the end state); child of a
+// switch / dead end: start state FL_R_PHANTOM (a node without cells).
 enum { SEG_SWITCH = 0, SEG_DEAD_END = 1, SEG_ZERO = 2, SEG_CYCLE = 3 };
+#define SEG_PHANTOM(e) (((e).x >> 22) & 1u)
+#define FL_R_PHANTOM 0xFFFEu
 #define SEG_END(e) ((int)((e).x & 0xFFFFFu))
 #define SEG_KIND(e) (((e).x >> 20) & 3u)
 #define SEG_LEN(e) ((int)((e).y & 0xFFFFu))

@@ -116,10 +116,10 @@ __device__ __forceinline__ uint32_t chain_next(const ObsCtx &X, uint32_t s, uint
     const uint32_t nd = first_dir(nibble(bits16, s & 3u));
     return ((uint32_t)X.nbr[(s & ~3u) | nd] << 2) | nd;
 }
-// state reached by leaving rail cell r in direction m, -1 when there is no rail there
+// state reached by leaving rail cell r through its transition m; -2 when that transition leaves the rail (see FL_R_PHANTOM)
 __device__ __forceinline__ int state_towards(const ObsCtx &X, int r, uint32_t m) {
     const uint32_t nr = X.nbr[r * 4 + (int)m];
-    return nr == FL_R_NONE ? -1 : (int)((nr << 2) | m);
+    return nr == FL_R_NONE ? -2 : (int)((nr << 2) | m);
 }
 
 // One node of a tree = one branch walk (_explore_branch: treeobs.cpp:258-610 / observations.py:256-494).
@@ -127,11 +127,11 @@ __device__ __forceinline__ int state_towards(const ObsCtx &X, int r, uint32_t m)
 // fl_dmap.hip); the stop at the agent's own target follows from the distance map: along a chain of single-transition
 // cells the distance drops by one per step, so the target is on the chain iff dm[start] <= chain length.
 struct NodeDesc {
-    int start;      // start state cell << 2 | dir, -1 = null cell
+    int start;      // start state cell << 2 | dir, -1 = null cell, -2 = an empty cell (the parent's transition leaves the rail)
     int tot0;       // tot_dist at the first visited cell
     int nvis;       // number of visited cells (feature block executions)
     int end;        // end state (direction unknown / irrelevant when the walk stops at the target)
-    uint32_t flags; // bit 0 target stop, 1 switch, 2 dead end, 3 terminal (zero transition or cycle), 4 zero transition
+    uint32_t flags; // bit 0 target stop, 1 switch, 2 dead end, 3 terminal (zero transition or cycle), 4 zero transition, 5 off the rail
     int unus;       // tot_dist of the first unusable switch or -1
     uint32_t kids01, kids23;  // start states of the end state's children (u16 each, FL_R_NONE = null), valid for switch / dead end
 };
@@ -141,6 +141,11 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, const uint16_
     NodeDesc n;
     n.start = start;
     n.tot0 = tot0;
+    if (start < 0) {  // -2: a node without cells on the rail (see FL_R_PHANTOM)
+        n.start = 0; n.nvis = 0; n.end = 0; n.flags = ND_TERMINAL | ND_ZERO | ND_PHANTOM; n.unus = -1;
+        n.kids01 = n.kids23 = 0xFFFFFFFFu;
+        return n;
+    }
     const uint4 e = X.seg[start];
     const uint32_t dv = dm_t[start];
     const int len = SEG_LEN(e), unus = SEG_UNUS(e);
@@ -154,7 +159,7 @@ __device__ __forceinline__ NodeDesc node_topology(const ObsCtx &X, const uint16_
         n.nvis = len + 1;
         n.end = SEG_END(e);
         const uint32_t k = SEG_KIND(e);
-        n.flags = k == SEG_SWITCH ? ND_SWITCH : k == SEG_DEAD_END ? ND_DEAD_END : k == SEG_ZERO ? (ND_TERMINAL | ND_ZERO) : ND_TERMINAL;
+        n.flags = k == SEG_SWITCH ? ND_SWITCH : k == SEG_DEAD_END ? ND_DEAD_END : k == SEG_ZERO ? (ND_TERMINAL | ND_ZERO | (SEG_PHANTOM(e) ? ND_PHANTOM : 0u)) : ND_TERMINAL;
         n.unus = unus != 0xFFFF ? tot0 + unus : -1;
     }
     return n;
@@ -174,14 +179,14 @@ __device__ __forceinline__ int nt_end(uint32_t se) { return (int)(se >> 16); }
 __device__ __forceinline__ int nt_tot(uint32_t tv) { return (int)(tv & 0xFFFFu); }
 __device__ __forceinline__ int nt_vis(uint32_t tv) { return (int)(tv >> 16); }
 __device__ __forceinline__ int nt_unus(uint32_t uf) { const uint32_t u = uf & 0xFFFFu; return u == 0xFFFFu ? -1 : (int)u; }
-__device__ __forceinline__ uint32_t nt_flags(uint32_t uf) { return (uf >> 16) & 31u; }
-__device__ __forceinline__ int nt_row(uint32_t uf) { return (int)((uf >> 21) & 127u); }
+__device__ __forceinline__ uint32_t nt_flags(uint32_t uf) { return (uf >> 16) & 63u; }
+__device__ __forceinline__ int nt_row(uint32_t uf) { return (int)((uf >> 22) & 127u); }
 // descriptor of a node into its slot; err: latched when a distance does not fit 16 bits (no Flatland map comes close)
 __device__ __forceinline__ void nt_store_desc(int *scr, int cap, int k, const NodeDesc &nd, int row, int *err) {
     if ((uint32_t)(nd.tot0 + nd.nvis) > 0xFFFEu && err) atomicCAS(err, 0, FL_ERR_CAPACITY);
     nt_w(scr, cap, N_SE, k) = (int)(((uint32_t)nd.start & 0xFFFFu) | ((uint32_t)nd.end << 16));
     nt_w(scr, cap, N_TV, k) = (int)(((uint32_t)nd.tot0 & 0xFFFFu) | ((uint32_t)nd.nvis << 16));
-    nt_w(scr, cap, N_UF, k) = (int)(((uint32_t)(nd.unus < 0 ? 0xFFFF : nd.unus) & 0xFFFFu) | (nd.flags << 16) | ((uint32_t)row << 21));
+    nt_w(scr, cap, N_UF, k) = (int)(((uint32_t)(nd.unus < 0 ? 0xFFFF : nd.unus) & 0xFFFFu) | (nd.flags << 16) | ((uint32_t)row << 22));
 }
 __device__ __forceinline__ void nt_clear_desc(int *scr, int cap, int k) {
     nt_w(scr, cap, N_SE, k) = (int)N_NONE;

@@ -49,7 +49,7 @@
 // written by pass A, the accumulators are merged by the event handlers of pass B with LDS atomics.
 //   N_SE    start state (lo16, 0xFFFF = no node) | end state (hi16)
 //   N_TV    tot_dist at the first visited cell (lo16) | number of visited cells (hi16)
-//   N_UF    tot_dist of the first unusable switch (lo16, 0xFFFF = none) | ND_* flags (bits 16-20) | DFS row of the node (bits 21-27, upstream)
+//   N_UF    tot_dist of the first unusable switch (lo16, 0xFFFF = none) | ND_* flags (bits 16-21) | DFS row of the node (bits 22-28, upstream)
 //   N_INCL  inclusive prefix of the visit counts (24 bits) | next node with cells << 24 (0xFF = none)   (team_prepare)
 //   N_OA, N_PC   min tot_dist of "other agent encountered" / "potential conflict" (0x7fffffff = none)
 //   N_CNT   agents in the same direction (lo16) | in the opposite direction (hi16)
@@ -60,7 +60,7 @@
 //   N_OT, N_MALF   upstream: min tot_dist of "other target encountered", max malfunction down counter of an occupant
 enum { N_SE = 0, N_TV, N_UF, N_INCL, N_OA, N_PC, N_CNT, N_RM, N_MS, N_PH, N_WORDS_C = 10, N_OT = 9, N_MALF = 10, N_WORDS_T = 11 };
 #define N_NONE 0xFFFFu
-enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO = 16 };
+enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO = 16, ND_PHANTOM = 32 /* the walk left the rail: distance inf */ };
 
 // flatland_cutils trees: 32-lane team, 32 slots (max_nodes <= 32).  Upstream trees: on maps where no (cell, direction) has
 // more than two transitions -- every Flatland rail cell type -- level L has at most 2^L nodes, a depth-3 tree 14: a 16-lane

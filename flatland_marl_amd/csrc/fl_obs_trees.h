@@ -12,7 +12,8 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
     const uint32_t flags = nt_flags(uf);
     const bool tgt = flags & ND_TARGET;
     double dist_min = 0;
-    if (!tgt) {
+    if (flags & ND_PHANTOM) dist_min = INFINITY;  // the distance map of a cell without rail
+    else if (!tgt) {
         const uint16_t dv = X.dm[X.a_tslot[handle] * X.SS + nt_end((uint32_t)nt_r(scr, cap, N_SE, k))];
         dist_min = dv == FL_INF16 ? INFINITY : (double)dv;
     }
@@ -37,7 +38,7 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
 __device__ __forceinline__ int child_state(const NodeDesc &nd, int k) {
     if (!(nd.flags & (ND_SWITCH | ND_DEAD_END))) return -1;
     const uint32_t c = ((k < 2 ? nd.kids01 : nd.kids23) >> (16 * (k & 1))) & 0xFFFFu;
-    return c == FL_R_NONE ? -1 : (int)c;
+    return c == FL_R_NONE ? -1 : c == FL_R_PHANTOM ? -2 : (int)c;
 }
 
 // scale_node (treeobs.cpp:111-152), float32 arithmetic
@@ -105,7 +106,7 @@ __device__ __forceinline__ void upstream_pass_a(const ObsCtx &X, const ObsArgs &
     for (int level = 1; level <= D; level++) {
         int ch[4] = {-1, -1, -1, -1};
         int ch_tot = 0;
-        if (have && tl < width && c_index >= 0 && c_state >= 0) {
+        if (have && tl < width && c_index >= 0 && c_state != -1) {
             const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
             nt_store_desc(scr, STRIDE, COMPACT ? width - 2 + tl : c_index, nd, c_index, err);
             ch_tot = nd.tot0 + nd.nvis;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void upstream_pass_a(const ObsCtx &X, const ObsArgs &
         if (tl < width && p_index >= 0) {
             int kk = which, st = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
             if (COMPACT) {  // the which-th child that exists
-                const uint32_t m4 = (uint32_t)(s0 >= 0) | ((uint32_t)(s1 >= 0) << 1) | ((uint32_t)(s2 >= 0) << 2) | ((uint32_t)(s3 >= 0) << 3);
+                const uint32_t m4 = (uint32_t)(s0 != -1) | ((uint32_t)(s1 != -1) << 1) | ((uint32_t)(s2 != -1) << 2) | ((uint32_t)(s3 != -1) << 3);
                 if (which == 0 && __popc(m4) > 2 && err) atomicCAS(err, 0, FL_ERR_CAPACITY);
                 const uint32_t m = which == 1 ? (m4 & (m4 - 1)) : m4;
                 kk = m ? __ffs((int)m) - 1 : -1;
@@ -244,7 +245,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         const int idx_node = node_base + gl;
         int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
         bool explored = false;
-        if (mine && c_state >= 0) {
+        if (mine && c_state != -1) {
             const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
             explored = true;
             ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk

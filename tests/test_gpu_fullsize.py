@@ -1,0 +1,82 @@
+"""GPU, BASELINE.json full sizes of the depth-3 configs: cfg3 (1024 envs x 35x30 x 80 agents, depth-3 tree) and the per-GPU
+shard of cfg5 (256 envs x 150x150 x 400 agents, depth-3 tree + masked distance-map rebuild of the envs that just reset) --
+the batch sizes at which the per-env HBM scratch strides (predicted paths, prediction items, bucket offsets, work lists) are
+actually exercised.  Size-independent properties: replica independence (an env inside the full batch == the same env stepped
+alone, observations included) on picked replicas, and two replicas shadowed by the CPU oracle step by step."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CUTILS = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("node_order", "node_order"),
+          ("edge_order", "edge_order"), ("valid_actions", "valid"), ("props", "props"))
+
+
+def _same(got, exp, msg):
+    got = np.asarray(got)
+    if not np.array_equal(got, exp):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{msg}: {len(bad)} mismatches, first {bad[0].tolist()}: {got[tuple(bad[0])]} vs {exp[tuple(bad[0])]}")
+
+
+@pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct", [
+    # (replicas with b % 7 == 3 have short episodes: 3, 766, 1018 / 3, 255 restart inside the window)
+    ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10),
+    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2),
+])
+def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct):
+    from flatland_marl_amd import synth, workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    from oracle import orc
+    envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
+    assert len({e["grid"].tobytes() for e in envs[:distinct]}) == distinct
+    # short episodes for some replicas, so that auto-resets (and the masked rebuild) happen inside the window
+    for b in range(B):
+        if b % 7 == 3:
+            envs[b] = dict(envs[b])
+            envs[b]["T"] = np.int32(17 + b % 11)
+    env = BatchedRailEnv(envs)
+    A = env.A
+    solo = {b: BatchedRailEnv([envs[b]]) for b in picks}
+    oracles = {b: orc.OracleEnv(envs[b]) for b in shadow}
+    tc = {b: 0 for b in shadow}
+    for t in range(steps):
+        rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=True)
+        o, tree = env.obs_both(3, 30)
+        if rebuild:
+            env.rebuild_distance_maps(env.done_all)
+        st, el = env.state()
+        check_obs = t % 8 == 0 or t == steps - 1
+        ob = {k: v.cpu().numpy() for k, v in o.items()} if check_obs else None
+        tr = tree.cpu().numpy() if check_obs else None
+        for b, s_env in solo.items():
+            s_rew, _, s_da = s_env.step_synth(seed, b, 0, auto_reset=True)
+            s_o, s_tree = s_env.obs_both(3, 30)
+            if rebuild:
+                s_env.rebuild_distance_maps(s_env.done_all)
+            _same(s_env.state()[0][0], st[b], f"replica {b} step {t} state")
+            _same(s_rew.cpu().numpy()[0], rew.cpu().numpy()[b], f"replica {b} step {t} rewards")
+            if check_obs:
+                for key, _ in CUTILS:
+                    _same(s_o[key].cpu().numpy()[0], ob[key][b], f"replica {b} step {t} {key}")
+                _same(s_tree.cpu().numpy()[0], tr[b], f"replica {b} step {t} depth-3 tree")
+        for b, orc_env in oracles.items():
+            r_o, d_o, da = orc_env.step(synth.uniform_actions(seed, b, tc[b], A))
+            tc[b] += 1
+            _same(st[b], orc_env.state(), f"oracle replica {b} step {t} state")
+            _same(rew.cpu().numpy()[b], r_o, f"oracle replica {b} step {t} rewards")
+            exp = orc_env.obs_cutils(31, 500)       # every step: the deadlock flags are sticky
+            if check_obs:
+                for key, okey in CUTILS:
+                    _same(ob[key][b], exp[okey], f"oracle replica {b} step {t} {key}")
+                _same(tr[b], orc_env.obs_pytree(3, 30), f"oracle replica {b} step {t} depth-3 tree")
+            if da:
+                key, pos = orc_env.get_rng()
+                oracles[b] = orc.OracleEnv(envs[b])
+                oracles[b].set_rng(key, pos)
+                tc[b] = 0
+    env.check()
+    m = env.metrics().cpu().numpy()
+    assert m[2] == B * A * steps and m[3] >= B // 7       # the short episodes ended (and restarted) inside the window
+    for s_env in solo.values():
+        s_env.check()
