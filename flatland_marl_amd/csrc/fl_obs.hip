@@ -82,7 +82,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
         put(L_ITEMS2, (size_t)std::max(L.items2_cap, 4) * 4);
         put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2); put(L_A_TQ2, A * 8);
     }
-    if (o.fb) put(L_BKREL, K1 * OBS_FB_NB * 2);
+    if (o.fb) put(L_BKREL, K1 * (OBS_FB_NB + 2) * 2);
     if (o.tab) { put(L_SEG, NS * 16); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
     L.total = (unsigned)off;
     L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
@@ -128,7 +128,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     P.merged = 0;
     P.wl_occ_div = OBS_WL_OCC_DIV;
     if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT) &&
-        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.snext, 1) && ok(force.tab, 0) &&
+        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.snext, 1) &&
         (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP) {
         P.merged = d.A <= 32 ? 1 : 2;
         o.nt = OBS_NT; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
@@ -144,11 +144,11 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                       {1, 0, 0}, {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
         static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
         static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
-        static const bool all_fb = getenv("FL_OBS_FB") != nullptr;   // diagnostic: bucketed lists in the one-round mode too
         const Pref *prefs = P.merged == 1 ? one_round : rounds;
         const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : (int)(sizeof rounds / sizeof rounds[0]);
         for (int pk = 0; pk < n_prefs; pk++) {
-            o.fb = (prefs[pk].fb || all_fb) && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
+            o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
+            o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
             if ((o.fb && no_fb) || !ok(force.wl, o.wl_bytes) || !ok(force.items, o.items) || (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP)) continue;
             for (o.own_filter = (no_own || !o.items) ? 0 : 1; o.own_filter >= 0; o.own_filter--)  // (the filter's masks are built by the LDS fill)
                 for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {

@@ -458,7 +458,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // job queue of phase 2: pass A of four upstream trees (one pass B for both builders, see trees_merged; longest first), the
     // rest of phase 1 of two agents.  (Ending the phase with the last pass A of a cutils tree and taking the rest of the queue
     // beside the fill of the index measured 0.8 us slower: a job is a chain of HBM reads and takes as long as the fill.)
-    const int n_up_jobs = merged ? (min(A, OBS_MERGED_ROUND) + 3) / 4 : 0, n_p1_jobs = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
+    // One pass B for both builders: the rest of phase 1 waits for the work-list step of the first round of trees, where the
+    // wavefronts finish at very different times (late_jobs) -- this phase then ends with the last pass A.
+    const int n_p1_all = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
+    const bool late_p1 = merged && n_p1_all > 0;
+    const int n_up_jobs = merged ? (min(A, OBS_MERGED_ROUND) + 3) / 4 : 0, n_p1_jobs = late_p1 ? 0 : n_p1_all;
     // ... and, last, the -inf pre-fill of the env's upstream rows (see phase 0) in chunks of 16 KB: pure stores that drain beside
     // the latency-bound rest of the phase (no builder writes a row before the trees phase)
     constexpr int PF_CHUNK = 64 * 16;  // double2 per job
@@ -488,6 +492,16 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in the L2 before the barrier that ends the phase
     };
+    auto late_jobs = [&]() __attribute__((always_inline)) {
+        while (late_p1) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&misc[7], 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= n_p1_all) break;
+            const int i = 2 * j + (lane >> 5);
+            if (i < A) phase1b(i, lane & 31, phase1b_load(i));
+        }
+    };
     if (do_p1 && (!p1_beside_walk || X.Tn == 0)) {
         if (wave == 0) phase1a();
         phase1b_all();
@@ -507,12 +521,15 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool bk = CUTILS && STAGE != 2 && P.bk != 0 && X.Tn > 64 && X.tmask != nullptr;
         const bool bk_lds = bk && P.bk == 2;
         const int bk_nb = P.bk_nb, bk_shift = P.bk_shift;
+        // counters / offsets per key: bk_nb time buckets; with LDS-resident offsets also the bucket of the items that stay until the
+        // end of the horizon (a path's last waypoint -- no copies of it in every later time bucket) and a padding entry
+        const int bk_w = bk_lds ? bk_nb + 2 : bk_nb;
         uint32_t *bkc = bk_lds ? LDS_AT(uint32_t, L_BKREL) : reinterpret_cast<uint32_t *>(wave_scr);
         if (!reuse) {
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (tid == 0) misc[11] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
-            if (bk) for (int k = tid; k < K * bk_nb / 2; k += nt) bkc[k] = 0u;
+            if (bk) for (int k = tid; k < K * bk_w / 2; k += nt) bkc[k] = 0u;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
         __syncthreads();
@@ -558,7 +575,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             };
             // waypoints that can be occupied within the horizon enter the per-key index: they are counted as they are recorded
             // (bucketed lists count per bucket, below)
-            const int hz1 = bk ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
+            // (bucketed lists with LDS-resident counters count per bucket right here; the one item whose interval runs to the end of the
+            // horizon -- the last one of the path -- is only known after the walk and is corrected then.  Counters in the node tables'
+            // LDS: a separate pass below)
+            const int hz1 = (bk && !bk_lds) ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
+            const int tpc_w = a_tpc[ia], tlast_w = X.Tn - 1;
+            uint32_t st_hz = 0;
             const int hz2 = dual ? max(0, min(P.tree_pred - 1, (Tn2 - 1) / (int)a_tpc2[ia])) : -1;
             auto walk8 = [&](const uint16_t *h8) __attribute__((always_inline)) {
                 int idx = j, last = -1;
@@ -568,7 +590,20 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         last = idx;
                         if (idx <= hz1 || idx <= hz2) {
                             const int key = key_of(X, (int)(st >> 2));
-                            if (idx <= hz1) atomicAdd(&csr[key], 1);
+                            if (idx <= hz1) {
+                                if (bk_lds) {  // cutils: waypoint idx is occupied during [(idx - 1) * tpc + 1, idx * tpc] (0 for idx = 0)
+                                    const int tlo = idx == 0 ? 0 : (idx - 1) * tpc_w + 1, thi = min(idx * tpc_w, tlast_w);
+                                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                                    for (int bb = b1; bb <= b2; bb++) {
+                                        const int kb = key * bk_w + bb;
+                                        atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                                    }
+                                    atomicAdd(&csr[key], b2 - b1 + 1);
+                                    if (idx == hz1) st_hz = st;
+                                } else {
+                                    atomicAdd(&csr[key], 1);
+                                }
+                            }
                             if (idx <= hz2) atomicAdd(&csr2[key], 1);
                         }
                         const uint32_t s8 = idx + 8 < n_max ? (uint32_t)h8[st] : (uint32_t)FL_R_NONE;
@@ -581,8 +616,29 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             // separate call sites so that each keeps a static address space (LDS copy vs HBM table)
             if (nh_in_lds) lead_in(nh_lds + u * Rcap);
             else lead_in(gnh + (size_t)u * Rcap);
-            int m = TAB_LDS ? walk8(hop8_lds + u * Scap) : walk8(ghop8 + (size_t)u * Scap);
+            const int my_last = TAB_LDS ? walk8(hop8_lds + u * Scap) : walk8(ghop8 + (size_t)u * Scap);
+            int m = my_last;
             m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
+            if (bk_lds && have) {
+                // the last indexed waypoint lp stays occupied until the end of the horizon: from its time bucket(s) to the bucket of
+                // such items
+                const int lp = max(0, min(m, hz1));
+                if (lp == m ? my_last == lp : j == (lp & 7)) {
+                    const uint32_t s_lp = lp == m ? st : st_hz;
+                    const int key = key_of(X, (int)(s_lp >> 2));
+                    const int tlo = lp == 0 ? 0 : (lp - 1) * tpc_w + 1, thi = min(lp * tpc_w, tlast_w);
+                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                    for (int bb = b1; bb <= b2; bb++) {
+                        const int kb = key * bk_w + bb;
+                        atomicSub(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                    }
+                    // (bk_w is even: the count of that bucket is the low half of the key's last word, the high half collects the
+                    // time buckets in which such items start)
+                    atomicAdd(&bkc[(key * bk_w + bk_nb) >> 1], 1u);
+                    atomicOr(&bkc[(key * bk_w + bk_nb) >> 1], 0x10000u << b1);
+                    if (b2 > b1) atomicSub(&csr[key], b2 - b1);
+                }
+            }
             if (have && j == 0) {
                 const int n = m + 1;  // lane 0 always records the current position
                 // last waypoint that can be occupied within the horizon; only those enter the per-key index
@@ -630,7 +686,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
 #endif
-        if (bk) {  // bucketed lists: one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+        if (bk && !bk_lds) {  // bucketed lists: one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
                 const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
@@ -718,7 +774,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         if (bk) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
             for (int key = tid; key < K; key += nt) {
-                uint32_t *w4 = bkc + key * (bk_nb / 2);
+                uint32_t *w4 = bkc + key * (bk_w / 2);
                 uint32_t run = 0, prev = 0, most = 0;  // most: the longest run of three consecutive buckets (what one query can scan)
                 for (int q = 0; q < bk_nb / 2; q++) {
                     const uint32_t v = w4[q], c0 = v & 0xFFFFu, c1 = v >> 16;
@@ -726,6 +782,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     prev = c0 + c1;
                     w4[q] = run | ((run + c0) << 16);
                     run += c0 + c1;
+                }
+                if (bk_lds) {  // ... plus the items that stay until the end
+                    const uint32_t ve = w4[bk_nb / 2];
+                    w4[bk_nb / 2] = run | (ve & 0xFFFF0000u);
+                    most += ve & 0xFFFFu;
                 }
                 if (most > CF_DIRECT) misc[11] = 1;
             }
@@ -770,9 +831,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                                       ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
                 if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
                     const int thi = to_end ? tlast : tlo + span - 1;
-                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                    int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                    if (bk_lds && to_end) b1 = b2 = bk_nb;  // the bucket of the items that stay until the end
                     for (int bb = b1; bb <= b2; bb++) {
-                        const int kb = key * bk_nb + bb;
+                        const int kb = key * bk_w + bb;
                         const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                         csr_items[csr[key] + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
                     }
@@ -808,7 +870,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 X.bk_rel_lds = reinterpret_cast<const uint16_t *>(bkc);
             } else {
                 uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
-                for (int k = tid; k < K * bk_nb / 2; k += nt) g[k] = bkc[k];
+                for (int k = tid; k < K * bk_w / 2; k += nt) g[k] = bkc[k];
                 X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
                 __syncthreads();
             }
@@ -823,8 +885,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (merged) {
-        if (items_in_lds) trees_merged<true, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
-        else trees_merged<false, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist);
+        if (items_in_lds) trees_merged<true, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
+        else trees_merged<false, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);

@@ -85,30 +85,48 @@ __device__ __forceinline__ int pt_of(const ObsCtx &X, bool cu, int handle, int t
     if (PB == 2 && !cu) return (int)((double)tot * X.a_tq2[handle]);
     return cu ? (int)((float)tot * (float)X.a_tq[handle]) : (int)((double)tot * X.a_tq[handle]);
 }
-// items of rail cell r's key a conflict query at predicted time pt has to look at: [lo, hi)
+// Items of rail cell r's key a conflict query at predicted time pt has to look at, as a VIRTUAL range [0, n): the first n1 are
+// the items lo .. lo + n1 - 1 of the index, the rest lo2 .. (plain and duplicated-bucket lists: n1 = n).  Lists grouped by time
+// bucket with LDS-resident offsets (bk_rel_lds) keep the items that stay until the end of the horizon -- the last waypoint of
+// a path, usually a target cell -- in a bucket of their own behind the time buckets: the second piece of every query.
+// TWO = false (kernels that never build such lists): one piece, plain indexing.
+struct ListRange { int lo, n1, lo2, n; };
+template <bool TWO>
+__device__ __forceinline__ int list_index(const ListRange &R, int v) { return (TWO && v >= R.n1) ? R.lo2 + (v - R.n1) : R.lo + v; }
 template <int PB>
-__device__ __forceinline__ void list_range(const ObsCtx &X, bool cu, int r, int pt, int &lo, int &hi) {
+__device__ __forceinline__ ListRange list_range(const ObsCtx &X, bool cu, int r, int pt) {
     const int key = key_of(X, r);
+    ListRange R;
+    R.lo2 = 0;
     if (PB == 2 && !cu) {
-        lo = key > 0 ? X.u_csr_end[key - 1] : 0;
-        hi = X.u_csr_end[key];
-        return;
+        R.lo = key > 0 ? X.u_csr_end[key - 1] : 0;
+        R.n1 = R.n = X.u_csr_end[key] - R.lo;
+        return R;
     }
     const int base = key > 0 ? X.csr_end[key - 1] : 0;
     if (X.bk_rel_lds) {  // (two call sites: each table keeps its address space)
         const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
-        const uint16_t *rel = X.bk_rel_lds + key * X.bk_nb;
-        lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
-        hi = base + (int)rel[b2];
+        // per key: bk_nb time buckets, the to-the-end bucket, and a mask of the time buckets in which such an item starts
+        const uint16_t *rel = X.bk_rel_lds + key * (X.bk_nb + 2);
+        const int o1 = b1 > 0 ? (int)rel[b1 - 1] : 0;
+        R.lo = base + o1;
+        R.n1 = R.n = (int)rel[b2] - o1;
+        if ((uint32_t)rel[X.bk_nb + 1] & ((2u << b2) - 1u)) {  // somebody stays here from a time the query can see
+            const int oe = (int)rel[X.bk_nb - 1];
+            R.lo2 = base + oe;
+            R.n += (int)rel[X.bk_nb] - oe;
+        }
     } else if (X.bk_rel) {
         const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
         const uint16_t *rel = X.bk_rel + (size_t)key * X.bk_nb;
-        lo = base + (b1 > 0 ? (int)rel[b1 - 1] : 0);
-        hi = base + (int)rel[b2];
+        const int o1 = b1 > 0 ? (int)rel[b1 - 1] : 0;
+        R.lo = base + o1;
+        R.n1 = R.n = (int)rel[b2] - o1;
     } else {
-        lo = base;
-        hi = X.csr_end[key];
+        R.lo = base;
+        R.n1 = R.n = X.csr_end[key] - base;
     }
+    return R;
 }
 // successor of a state with exactly one transition (chain interior): one LDS load when the table is resident
 __device__ __forceinline__ uint32_t chain_next(const ObsCtx &X, uint32_t s, uint32_t bits16) {

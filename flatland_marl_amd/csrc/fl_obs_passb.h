@@ -32,11 +32,11 @@ __device__ __forceinline__ void occ_event(const ObsCtx &X, bool CUTILS, int *sc,
 }
 
 // potential conflict at predicted time pt (treeobs.cpp:378-465 / observations.py:329-367); the caller checked
-// Tn > 0, tot < Tn and pt < Tn.  conflict_flags scans items [lo, hi) of the cell's key and returns six bits:
+// Tn > 0, tot < Tn and pt < Tn.  conflict_flags scans the items [v0, v1) of the virtual range R of the cell's key (list_range) and returns six bits:
 // bit k (k = 0, 1, 2 for the times pt, pt - 1, pt + 1): some OTHER agent is predicted there then; bit 3 + k: some agent
 // predicted there then (self included) satisfies the conflict condition.  Flags of sub-ranges of a list simply OR.
-template <int PB, bool ITL>
-__device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS, int handle, int cell, uint32_t d, int pt, int lo, int hi) {
+template <int PB, bool ITL, bool TWO>
+__device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS, int handle, int cell, uint32_t d, int pt, const ListRange &R, int v0, int v1) {
     const uint32_t bits = nibble(cw_bits(X, cell), d);
     const bool second = PB == 2 && !CUTILS;  // the upstream predictor's index
     const int Tn = second ? X.u_Tn : X.Tn;
@@ -64,14 +64,14 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
     // items of a chunk and then tests only those -- 1 to 2 % slower on every workload)
     auto scan = [&](const uint32_t *items, auto nb) __attribute__((always_inline)) {
         constexpr int NB = decltype(nb)::value;
-        for (int e0 = lo; e0 < hi; e0 += NB) {
+        for (int e0 = v0; e0 < v1; e0 += NB) {
             uint32_t itv[NB];
 #pragma unroll
-            for (int q = 0; q < NB; q++) itv[q] = items[min(e0 + q, hi - 1)];
+            for (int q = 0; q < NB; q++) itv[q] = items[list_index<TWO>(R, min(e0 + q, v1 - 1))];
 #pragma unroll
             for (int q = 0; q < NB; q++) {
                 const uint32_t tl = IT_TLO(itv[q]), th = IT_THI(itv[q], tlast);
-                if (e0 + q < hi && th >= t1 && tl <= t2) test_item(itv[q]);
+                if (e0 + q < v1 && th >= t1 && tl <= t2) test_item(itv[q]);
             }
         }
     };
@@ -88,12 +88,11 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
 // the other-agent test takes the first time (pt, pt - 1, pt + 1) at which somebody else is predicted on the cell
 __device__ __forceinline__ bool conflict_hit(uint32_t f) { return (f & 1u) ? (f >> 3) & 1u : ((f & 2u) ? (f >> 4) & 1u : ((f & 4u) ? (f >> 5) & 1u : false)); }
 
-template <int PB, bool ITL>
+template <int PB, bool ITL, bool TWO>
 __device__ __forceinline__ void conflict_event(const ObsCtx &X, bool cu, int *sc, int cap, int node, int handle, int cell, uint32_t d, int tot, int pt) {
-    int lo, hi;
-    list_range<PB>(X, cu, cell, pt, lo, hi);
-    if (hi <= lo) return;
-    if (conflict_hit(conflict_flags<PB, ITL>(X, cu, handle, cell, d, pt, lo, hi))) atomicMin(&nt_w(sc, cap, N_PC, node), tot);
+    const ListRange R = list_range<PB>(X, cu, cell, pt);
+    if (R.n <= 0) return;
+    if (conflict_hit(conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, d, pt, R, 0, R.n))) atomicMin(&nt_w(sc, cap, N_PC, node), tot);
 }
 
 // flag word of a conflict work-list entry (other lanes OR their bits into it)
@@ -233,9 +232,14 @@ __device__ __forceinline__ int *team_table(const ObsCtx &X, int *scr0, int team_
     return scr0 + team * team_words;
 }
 
-template <int PB, int CAP, bool ITL>
+// late(): work that does not depend on the trees (the rest of phase 1: attribute rows, valid actions), handed out through a queue;
+// a wavefront that is done with its share of the work-list step takes some while the others finish theirs.
+struct NoLateWork { __device__ __forceinline__ void operator()() const {} };
+
+// TWO: the lists of the index may come in two pieces (see ListRange)
+template <int PB, int CAP, bool ITL, typename LATE = NoLateWork, bool TWO = false>
 __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int n_teams, int *scr0, int team_words,
-                                          const int *team_meta) {
+                                          const int *team_meta, const LATE &late = LATE()) {
     if (tid == 0) { X.wl_cnt[0] = 0; X.wl_cnt[1] = 0; X.wl_cnt[2] = 0; }
     __syncthreads();
     const int lane = tid & 63;
@@ -437,9 +441,9 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             }
             if (to_cf) {
                 if (i_cf < X.wl_cf_cap) X.wl_cf[i_cf] = entry;
-                else conflict_event<PB, ITL>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);  // list full
+                else conflict_event<PB, ITL, TWO>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);  // list full
             } else if (cand) {
-                conflict_event<PB, ITL>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);
+                conflict_event<PB, ITL, TWO>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);
             }
             if (tgt_hit) atomicMin(&nt_w(sc, e_cap, N_OT, e_node), e_tot);
             if (!more) break;
@@ -479,15 +483,15 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             const int handle = pb_handle<PB>(X, team_meta, team), tot = (int)(w.y & 511u);
             const bool cu = pb_cu<PB>(X, team);
             const int pt = pt_of<PB>(X, cu, handle, tot);
-            int lo, hi;
-            list_range<PB>(X, cu, cell, pt, lo, hi);
-            if (hi > lo && conflict_hit(conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo, hi))) {
+            const ListRange R = list_range<PB>(X, cu, cell, pt);
+            if (R.n > 0 && conflict_hit(conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, R.n))) {
                 constexpr int cap = PB == 2 ? 32 : CAP;
                 int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
             }
         }
         WAVE_MARK(X, 13, 17);
+        late();
         __syncthreads();
         return;
     }
@@ -498,7 +502,8 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     // first entry << 6 (17 bits) | CF_MORE.
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
-        int nch = 0, lo = 0, hi = 0, cell = 0, handle = 0, tot = 0, pt = 0;
+        int nch = 0, cell = 0, handle = 0, tot = 0, pt = 0;
+        ListRange R = {0, 0, 0, 0};
         bool cu = PB == 1;
         uint2 w = make_uint2(0u, 0u);
         if (e < n_cf) {
@@ -509,19 +514,20 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             tot = (int)(w.y & 511u);
             cu = pb_cu<PB>(X, team);
             pt = pt_of<PB>(X, cu, handle, tot);
-            list_range<PB>(X, cu, cell, pt, lo, hi);
-            nch = max(min((hi - lo + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
+            R = list_range<PB>(X, cu, cell, pt);
+            nch = max(min((R.n + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
             X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
         }
         for (int j = 1; __any(j < nch); j++) {
             if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
                 // list full: this chunk is scanned here
-                const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + j * CF_CHUNK, j == 62 ? hi : min(hi, lo + (j + 1) * CF_CHUNK));
+                const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, j * CF_CHUNK, j == 62 ? R.n : min(R.n, (j + 1) * CF_CHUNK));
                 if (f) atomicOr(&X.wl_cf[e].y, f << 15);
             }
         }
     }
     WAVE_MARK(X, 13, 17);
+    late();
     __syncthreads();
     WAVE_MARK(X, 14, -1);
     const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
@@ -536,12 +542,11 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const int handle = pb_handle<PB>(X, team_meta, team);
         const bool cu = pb_cu<PB>(X, team);
         const int pt = pt_of<PB>(X, cu, handle, tot);
-        int lo, hi;
-        list_range<PB>(X, cu, cell, pt, lo, hi);
-        const uint32_t f = conflict_flags<PB, ITL>(X, cu, handle, cell, w.x & 3u, pt, lo + chunk * CF_CHUNK, chunk == 62 ? hi : min(hi, lo + (chunk + 1) * CF_CHUNK));
+        const ListRange R = list_range<PB>(X, cu, cell, pt);
+        const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, chunk * CF_CHUNK, chunk == 62 ? R.n : min(R.n, (chunk + 1) * CF_CHUNK));
 #ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down)
         if (X.dbg && !more) {
-            atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)(hi - lo));
+            atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
             if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
             if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
             if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);

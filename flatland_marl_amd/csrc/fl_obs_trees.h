@@ -408,10 +408,11 @@ __device__ __forceinline__ int merged_upstream_of(int wave, int lane, int nwaves
 }
 
 // MULTI = false: an env of at most 32 agents -- one round, whose pass A ran beside the path walk: no pass A code here.
-template <bool ITL, bool MULTI>
+template <bool ITL, bool MULTI, typename LATE>
 __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane, int nwaves,
                                              int *wave_scr, int *team_meta, const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
-                                             const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot, float max_dist) {
+                                             const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot, float max_dist,
+                                             const LATE &late) {
     constexpr int CT = OBS_CAP_T_COMPACT;
     const int A = X.A;
     const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;   // (nwaves = 16: ct covers 0 .. 31)
@@ -445,7 +446,8 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
             const int id = OBS_MERGED_ROUND + (u < 0 ? 0 : u);
             if (u >= 0 && tl == 0) { team_meta[id] = have_u ? cells : 0; team_meta[64 + id] = have_u ? ns : 1; team_meta[256 + id] = first; }
         }
-        wg_pass_b<2, OBS_CAP_C, ITL>(X, wave * 64 + lane, nwaves * 64, 2 * OBS_MERGED_ROUND, wave_scr, 0, team_meta);
+        wg_pass_b<2, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, 2 * OBS_MERGED_ROUND, wave_scr, 0, team_meta, late);
+        if (base == 0) late();  // (whatever the queue still holds)
         TREE_STAMP(X, 7);
         if (ct < OBS_MERGED_ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
         if (wave_has_u) upstream_rows<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u);
