@@ -467,6 +467,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // the latency-bound rest of the phase (no builder writes a row before the trees phase)
     constexpr int PF_CHUNK = 64 * 16;  // double2 per job
     const int pf_n2 = bg_prefill ? A * P.n_tree_nodes * 6 : 0, n_pf_jobs = (pf_n2 + PF_CHUNK - 1) / PF_CHUNK;
+    // Order: pass A of the upstream trees first (the trees wait for them), then the rest of phase 1, the pre-fill last.  (The
+    // pre-fill first -- streamed by the one free wavefront while hundreds of paths are walked -- doubled the walk at cfg5,
+    // 166 -> 323 us: the walk is a chain of L2 / HBM round trips and the stores fill the same queues.)
     auto drain_jobs = [&]() __attribute__((always_inline)) {
         bool stored = false;
         while (n_up_jobs + n_p1_jobs + n_pf_jobs > 0) {
@@ -474,7 +477,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (lane == 0) j = atomicAdd(&misc[6], 1);
             j = __builtin_amdgcn_readfirstlane(j);
             if (j >= n_up_jobs + n_p1_jobs + n_pf_jobs) break;
-            if (j >= n_up_jobs + n_p1_jobs) {
+            if (j < n_up_jobs) {
+                const int u = 4 * j + (lane >> 4);
+                upstream_pass_a<16, OBS_CAP_T_COMPACT, true, 32>(X, P, b, u, u < A, lane & 15, merged_table_t(wave_scr, min(u, OBS_MERGED_ROUND - 1)), &d.err[b]);
+            } else if (j < n_up_jobs + n_p1_jobs) {
+                const int i = 2 * (j - n_up_jobs) + (lane >> 5);
+                if (i < A) phase1b(i, lane & 31, phase1b_load(i));
+            } else {
                 double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)b * A * P.n_tree_nodes * 12);
                 const double2 ninf = make_double2(-INFINITY, -INFINITY);
                 const int k0 = (j - n_up_jobs - n_p1_jobs) * PF_CHUNK + lane;
@@ -482,12 +491,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 for (int q = 0; q < 16; q++)
                     if (k0 + q * 64 < pf_n2) o2[k0 + q * 64] = ninf;
                 stored = true;
-            } else if (j < n_up_jobs) {
-                const int u = 4 * j + (lane >> 4);
-                upstream_pass_a<16, OBS_CAP_T_COMPACT, true, 32>(X, P, b, u, u < A, lane & 15, merged_table_t(wave_scr, min(u, OBS_MERGED_ROUND - 1)), &d.err[b]);
-            } else {
-                const int i = 2 * (j - n_up_jobs) + (lane >> 5);
-                if (i < A) phase1b(i, lane & 31, phase1b_load(i));
             }
         }
         if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in the L2 before the barrier that ends the phase
@@ -575,9 +578,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             };
             // waypoints that can be occupied within the horizon enter the per-key index: they are counted as they are recorded
             // (bucketed lists count per bucket, below)
-            // (bucketed lists with LDS-resident counters count per bucket right here; the one item whose interval runs to the end of the
-            // horizon -- the last one of the path -- is only known after the walk and is corrected then.  Counters in the node tables'
-            // LDS: a separate pass below)
+            // (bucketed lists with LDS-resident offsets count per bucket right here -- there the walk ends before the pass A beside it
+            // anyway; the one item whose interval runs to the end of the horizon, the last one of the path, is only known after the
+            // walk and is corrected then.  With hundreds of agents the walk IS the critical path and two LDS atomics per hop doubled
+            // it (166 -> 382 us at cfg5): those lists are counted in a pass of their own below, all lanes at once)
             const int hz1 = (bk && !bk_lds) ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
             const int tpc_w = a_tpc[ia], tlast_w = X.Tn - 1;
             uint32_t st_hz = 0;
@@ -686,22 +690,31 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (lane == 0) atomicMax((unsigned long long *)&X.dbg[22], (unsigned long long)wall_clock64());
 #endif
-        if (bk && !bk_lds) {  // bucketed lists: one copy of the item per time bucket its interval touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp))
+        if (bk && !bk_lds) {  // the pass that counts the bucketed lists of large maps: one copy of an item per time bucket its interval
+                              // touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp)); four waypoints per lane a round trip
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
                 const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
                 const int lp = a_lp[i];
                 const int tpc = a_tpc[i], tlast = X.Tn - 1;
-                for (int k = lane; k <= lp; k += 64) {
-                    const int key = key_of(X, (int)(path[k] >> 2));
-                    const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
-                    const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
-                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
-                    for (int bb = b1; bb <= b2; bb++) {
-                        const int kb = key * bk_nb + bb;
-                        atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                for (int k0 = lane; k0 <= lp; k0 += 256) {
+                    uint32_t wv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wv[q] = path[min(k0 + 64 * q, lp)];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int k = k0 + 64 * q;
+                        if (k > lp) break;
+                        const int key = key_of(X, (int)(wv[q] >> 2));
+                        const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
+                        const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
+                        const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                        for (int bb = b1; bb <= b2; bb++) {
+                            const int kb = key * bk_nb + bb;
+                            atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                        }
+                        atomicAdd(&csr[key], b2 - b1 + 1);
                     }
-                    atomicAdd(&csr[key], b2 - b1 + 1);
                 }
             }
         }
@@ -803,9 +816,22 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
-            for (int k = lane; k <= lp; k += 64) {
-                const uint32_t w = path[k];
-                const uint32_t dnext = k < lp ? (path[k + 1] & 3u) : (w & 3u), dprev = k > 0 ? (path[k - 1] & 3u) : (w & 3u);
+            // (the waypoints come from HBM scratch: four of them per lane are requested at once -- 500 waypoints are two round
+            // trips instead of eight)
+            constexpr int FU = 4;
+            for (int k0 = lane; k0 <= lp; k0 += 64 * FU) {
+            uint32_t wv[FU], wnx[FU], wpv[FU];
+#pragma unroll
+            for (int q = 0; q < FU; q++) {
+                const int k = min(k0 + 64 * q, lp);
+                wv[q] = path[k]; wnx[q] = path[min(k + 1, lp)]; wpv[q] = path[max(k - 1, 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < FU; q++) {
+                const int k = k0 + 64 * q;
+                if (k > lp) break;
+                const uint32_t w = wv[q];
+                const uint32_t dnext = k < lp ? (wnx[q] & 3u) : (w & 3u), dprev = k > 0 ? (wpv[q] & 3u) : (w & 3u);
                 // closed time interval during which the agent is predicted on waypoint k
                 int tlo, span;
                 if (CUTILS) {  // w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp) afterwards
@@ -860,6 +886,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
                                     ((uint32_t)(tpc2 - 1) << 6) | (dprev << 4) | (dnext2 << 2) | (w & 3u);
                 }
+            }
             }
         }
         __syncthreads();
