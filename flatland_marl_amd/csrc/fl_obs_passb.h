@@ -495,11 +495,13 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         __syncthreads();
         return;
     }
-    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone: every candidate pushes further
-    // entries for the rest of its list, and ALL chunks are scanned after a barrier, one per lane on densely packed wavefronts
-    // (scanning the first chunk right away measured 4 % slower on 80 agents, where many lists have several chunks).
+    // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone.  Every lane scans the FIRST chunk of
+    // its entry right away (with lists grouped by time bucket that is the whole list of most queries: no second look at the entry,
+    // its offsets and its flag word -- which are HBM round trips on large maps); a longer list pushes an entry per further chunk,
+    // and those are scanned after a barrier, one per lane on densely packed wavefronts.
     // First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) | node << 24; the others: chunk | index of the
     // first entry << 6 (17 bits) | CF_MORE.
+    bool any_multi = false;
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
         int nch = 0, cell = 0, handle = 0, tot = 0, pt = 0;
@@ -516,61 +518,61 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             pt = pt_of<PB>(X, cu, handle, tot);
             R = list_range<PB>(X, cu, cell, pt);
             nch = max(min((R.n + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
-            X.wl_cf[e].y = w.y | ((uint32_t)nch << 9);
+            const uint32_t f = R.n > 0 ? conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, nch == 1 ? R.n : CF_CHUNK) : 0u;
+#ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down; first chunks only)
+            if (X.dbg) {
+                atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
+                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+                if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
+                if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
+                if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
+            }
+#endif
+            if (nch == 1) {
+                if (conflict_hit(f)) {
+                    constexpr int cap = PB == 2 ? 32 : CAP;
+                    int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
+                    atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
+                }
+            } else {
+                X.wl_cf[e].y = w.y | ((uint32_t)nch << 9) | ((f & 63u) << 15);
+                any_multi = true;
+            }
         }
         for (int j = 1; __any(j < nch); j++) {
             if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
                 // list full: this chunk is scanned here
                 const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, j * CF_CHUNK, j == 62 ? R.n : min(R.n, (j + 1) * CF_CHUNK));
-                if (f) atomicOr(&X.wl_cf[e].y, f << 15);
+                if (f & 63u) atomicOr(&X.wl_cf[e].y, (f & 63u) << 15);
             }
         }
     }
+    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
     WAVE_MARK(X, 13, 17);
     late();
     __syncthreads();
     WAVE_MARK(X, 14, -1);
+    if (X.wl_cnt[2] == 0) return;   // (workgroup-uniform) every list fitted one chunk
     const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
-    bool any_multi = false;
-    for (int e = tid; e < n_cf2; e += nt) {
+    for (int e = n_cf + tid; e < n_cf2; e += nt) {  // the further chunks
         const uint2 w = X.wl_cf[e];
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        const bool more = (w.y & CF_MORE) != 0;
-        const int first = more ? (int)((w.y >> 6) & 0x1FFFFu) : e, chunk = more ? (int)(w.y & 63u) : 0;
-        const uint32_t fy = more ? wl_flags(X, &X.wl_cf[first]) : w.y;
-        const int tot = (int)(fy & 511u), nch = (int)((fy >> 9) & 63u);
+        const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u);
+        const uint32_t fy = wl_flags(X, &X.wl_cf[first]);
+        const int tot = (int)(fy & 511u);
         const int handle = pb_handle<PB>(X, team_meta, team);
         const bool cu = pb_cu<PB>(X, team);
         const int pt = pt_of<PB>(X, cu, handle, tot);
         const ListRange R = list_range<PB>(X, cu, cell, pt);
         const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, chunk * CF_CHUNK, chunk == 62 ? R.n : min(R.n, (chunk + 1) * CF_CHUNK));
-#ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down)
-        if (X.dbg && !more) {
-            atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
-            if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
-            if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
-            if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
-            if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
-        }
-#endif
-        if (nch == 1) {
-            if (conflict_hit(f)) {
-                constexpr int cap = PB == 2 ? 32 : CAP;
-                int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
-                atomicMin(&nt_w(sc, cap, N_PC, (int)(fy >> 24)), tot);
-            }
-        } else {
-            if (f) atomicOr(&X.wl_cf[first].y, f << 15);
-            any_multi = true;
-        }
+        if (f & 63u) atomicOr(&X.wl_cf[first].y, (f & 63u) << 15);
     }
-    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
     __syncthreads();
-    if (X.wl_cnt[2]) {  // keys with more than one chunk: the first entry has collected all flags
-        for (int e = tid; e < n_cf2; e += nt) {
+    {  // keys with more than one chunk: the first entry has collected all flags
+        for (int e = tid; e < n_cf; e += nt) {
             uint2 w = X.wl_cf[e];
             w.y = wl_flags(X, &X.wl_cf[e]);
-            if ((w.y & CF_MORE) || ((w.y >> 9) & 63u) == 1u) continue;
+            if (((w.y >> 9) & 63u) <= 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) {
                 constexpr int cap = PB == 2 ? 32 : CAP;
                 int *sc = team_table<PB, CAP>(X, scr0, team_words, (int)(w.x >> 24));
