@@ -805,6 +805,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             __syncthreads();
         }
+#ifdef FL_OBS_TIMING
+        if (STAGE != 2) { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 64 + 56] = (long long)wall_clock64(); }   // keys scanned, bucket offsets done
+#endif
         const bool fit = items_lds != nullptr && misc[2] <= L.items_cap;
         const bool dual_fill = dual && misc[3] <= L.items2_cap;
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
@@ -812,19 +815,37 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
+        // (the waypoints come from HBM scratch: four of them per lane are requested at once -- 500 waypoints are two round trips
+        // instead of eight -- and the first four of the agent the wavefront takes NEXT are requested before the items of this
+        // one are emitted)
+        constexpr int FU = 4;
+        uint32_t pfv[FU] = {0, 0, 0, 0}, pfn[FU] = {0, 0, 0, 0}, pfp[FU] = {0, 0, 0, 0};
+        auto prefetch = [&](int ia) __attribute__((always_inline)) {
+            if (reuse || ia >= A) return;
+            const uint16_t *pth = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            const int lpn = a_lp[ia];
+#pragma unroll
+            for (int q = 0; q < FU; q++) {
+                const int k = min(lane + 64 * q, lpn);
+                pfv[q] = pth[k]; pfn[q] = pth[min(k + 1, lpn)]; pfp[q] = pth[max(k - 1, 0)];
+            }
+        };
+        prefetch(wave);
         for (int i = wave; !reuse && i < A; i += (nt >> 6)) {
             const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
-            // (the waypoints come from HBM scratch: four of them per lane are requested at once -- 500 waypoints are two round
-            // trips instead of eight)
-            constexpr int FU = 4;
-            for (int k0 = lane; k0 <= lp; k0 += 64 * FU) {
             uint32_t wv[FU], wnx[FU], wpv[FU];
 #pragma unroll
-            for (int q = 0; q < FU; q++) {
-                const int k = min(k0 + 64 * q, lp);
-                wv[q] = path[k]; wnx[q] = path[min(k + 1, lp)]; wpv[q] = path[max(k - 1, 0)];
+            for (int q = 0; q < FU; q++) { wv[q] = pfv[q]; wnx[q] = pfn[q]; wpv[q] = pfp[q]; }
+            prefetch(i + (nt >> 6));
+            for (int k0 = lane; k0 <= lp; k0 += 64 * FU) {
+            if (k0 != lane) {
+#pragma unroll
+                for (int q = 0; q < FU; q++) {
+                    const int k = min(k0 + 64 * q, lp);
+                    wv[q] = path[k]; wnx[q] = path[min(k + 1, lp)]; wpv[q] = path[max(k - 1, 0)];
+                }
             }
 #pragma unroll
             for (int q = 0; q < FU; q++) {
@@ -890,6 +911,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
         }
         __syncthreads();
+#ifdef FL_OBS_TIMING
+        if (STAGE != 2 && tid == 0) P.dbg[(size_t)b * 64 + 57] = (long long)wall_clock64();   // items filled
+#endif
         if (bk) {  // the list of key k is [csr[k], csr[k + 1]) now; the bucket ends of every key stay in LDS or go to HBM (the node
                    // tables take their LDS back)
             X.csr_end = csr + 1;

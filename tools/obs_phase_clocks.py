@@ -54,6 +54,8 @@ def report():
     print("  p0 stage %.1f  p1 %.1f  p2a walk|phase1|passA + count %.1f  p2b scan/fill %.1f" % (seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4)))
     print("     since p2a start: deadlock wavefront done %.1f, walkers done %.1f, hoisted pass A done %.1f, rest of phase 1 done %.1f" % (seg(2, 20), seg(2, 21), seg(2, 19), seg(2, 22)))
     print("     hoisted pass A alone: slowest wavefront %.1f" % dur(23))
+    if c[:, :, 56].max() > 0:
+        print("     scan/fill: keys scanned + bucket offsets %.1f, items filled %.1f, rest (offsets to HBM) %.1f" % (seg(3, 56), seg(56, 57), seg(57, 4)))
     print("  trees (sum over rounds): passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f  orders %.1f   stage total %.1f" %
           (dur(6), dur(11), dur(7), dur(8), dur(16), seg(0, 5)))
     print("stage 2 (upstream tree):")
