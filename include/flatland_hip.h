@@ -56,9 +56,10 @@ enum {
 /* Limits of this build (FL_ERR_ARG / FL_ERR_CAPACITY beyond them):
  *   FL_MAX_AGENTS          agents per env (one lane per agent in the step kernel)
  *   FL_MAX_SPEED_COUNT     SpeedCounter.max_count = int(1 / speed) - 1 (4 bits of the packed agent word), i.e. speed >= 1/16
- *   FL_MAX_RAIL_CELLS      rail cells per env: rail states r * 4 + orientation are u16 (0xFFFF reserved); the observation
- *                          kernels keep the env's rail-cell index in LDS, which holds about 6000 cells (the largest Round-2 map,
- *                          158 x 158 / 41 cities, has 2710)
+ *   FL_MAX_RAIL_CELLS      rail cells per env: rail states r * 4 + orientation are u16 (0xFFFF, 0xFFFE reserved).  In practice the
+ *                          LDS sets the limit: the distance-map kernel holds an env's neighbour table, bitmaps and queues
+ *                          (about 11 900 cells; fl_reserve / fl_commit say so), the observation kernels its rail-cell index
+ *                          (about 6 000 cells with 400 agents; the largest Round-2 map, 158 x 158 / 41 cities, has 2 710)
  *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (one 32-lane team per tree; the solution uses 31)
  *   FL_MAX_PRED_DEPTH      predictor depth of either builder (the solution uses 500 / 30)
  *   FL_MAX_TREE_DEPTH      max_depth of the upstream TreeObsForRailEnv (85 nodes at depth 3)

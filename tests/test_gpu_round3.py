@@ -149,3 +149,21 @@ def test_bench_starts_its_own_ranks():
     assert abs(d["value"] - 2 * 8 * A * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 1e-6 * d["value"]     # sum over ranks / max time
     assert "cpu_baseline" not in d and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and "note" in d["roofline"]
+
+
+def test_capacities_are_checked_before_anything_is_allocated():
+    """fl_reserve / fl_commit refuse capacities the table kernels cannot hold (the reverse-BFS kernel keeps the env's neighbour
+    table, visited bitmaps and queues in LDS: about 11 900 rail cells); an env that does not fit a live batch's capacities is
+    FL_ERR_CAPACITY at fl_load_env (tests/test_gpu_reload.py).  The kernel-side FL_ERR_CAPACITY latches (BFS ring, 16-bit
+    distances of a tree walk) cannot be reached below those limits: a BFS level of a map of 11 900 cells has at most ~1 000
+    states (ring of 4 096), a 31-node tree walks at most 4 laps of the longest possible loop (47 600 < 65 535)."""
+    from flatland_marl_amd.hip_backend import BatchedRailEnv, FlatlandHipError
+    fx = util.load("cfg1_uniform")
+    with pytest.raises(FlatlandHipError, match="FL_ERR_ARG.*distance-map kernel's LDS"):
+        BatchedRailEnv([util.static_of(fx)], reserve=(4, 15000))
+    with pytest.raises(FlatlandHipError, match="FL_ERR_ARG.*16383 rail cells"):
+        BatchedRailEnv([util.static_of(fx)], reserve=(4, 20000))
+    env = BatchedRailEnv([util.static_of(fx)], reserve=(8, 11000))      # fits: the batch runs
+    env.step_synth(1, 0, 0, auto_reset=False)
+    env.obs_both(3, 30)
+    env.check()
