@@ -20,7 +20,9 @@
 #define OBS_TSHIFT 1                 // time-bucket width of the per-key masks for long horizons: 1 << OBS_TSHIFT steps
 #endif
 #define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
+#ifndef CF_DIRECT
 #define CF_DIRECT 32                 // when no list of the env is longer, every conflict entry is scanned by its lane alone, in one pass
+#endif
 #define OBS_ITEMS2_CAP 4096          // items of the second (upstream) index built by stage 1 of the fused launch
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)

@@ -58,9 +58,10 @@ def report():
         print("     scan/fill: keys scanned + bucket offsets %.1f, items filled %.1f, rest (offsets to HBM) %.1f" % (seg(3, 56), seg(56, 57), seg(57, 4)))
     print("  trees (sum over rounds): passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f  orders %.1f   stage total %.1f" %
           (dur(6), dur(11), dur(7), dur(8), dur(16), seg(0, 5)))
-    print("stage 2 (upstream tree):")
-    print("  prep %.1f  count %.1f  scan/fill %.1f" % (seg(32, 34), seg(34, 35), seg(35, 36)))
-    print("  trees: passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f   stage total %.1f" % (dur(38), dur(43), dur(39), dur(40), seg(32, 37)))
+    if c[:, :, 32].max() > 0:   # (the kernels with one pass B for both builders have no second stage)
+        print("stage 2 (upstream tree):")
+        print("  prep %.1f  count %.1f  scan/fill %.1f" % (seg(32, 34), seg(34, 35), seg(35, 36)))
+        print("  trees: passA %.1f  B classify %.1f  B work lists %.1f  rows %.1f   stage total %.1f" % (dur(38), dur(43), dur(39), dur(40), seg(32, 37)))
     print("kernel total %.1f us (slowest env %.1f)" % (seg(0, 37), ((c[:, :, 37] - c[:, :, 0]) / 100.0).max(1).mean()))
     pb = c[:, :, 25].astype(np.uint64)
     print("pass B (max over rounds / stages): slowest-lane loop %.1f us, cells/lane %.1f, cells per round %.0f; slowest-lane setup %.1f us (skipped %.1f cells)" %
@@ -72,7 +73,7 @@ def report():
     def rel_min(k, k0):
         return (((1 << 40) - c[:, :, k] - c[:, :, k0]) / 100.0).mean()
 
-    if env.A <= 31 and c[:, :, 50].max() == 0:  # marks of the last round only; meaningful for one round and one pass B
+    if (env.A <= 31 and c[:, :, 50].max() == 0) or os.environ.get("WL_MARKS"):  # marks of the LAST round of trees (of the last stage) only
         print("work-list step, since its start: occupants done %.1f, conflict scan done: earliest wavefront %.1f, latest %.1f" %
               (rel(12, 18), rel_min(17, 18), rel(13, 18)))
     if c[:, :, 27].max() > 0:  # a -DFL_OBS_COUNTS build
