@@ -494,7 +494,7 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
                                                            tree_out_dev, h->stream)
                                       : fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                                              edge_order_dev, valid_actions_dev, props_dev, h->stream);
-    if (rc != FL_OK) { set_err("fl_step_obs: launch failed"); return rc; }
+    if (rc != FL_OK) { set_err("fl_step_obs: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc; }
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -771,7 +771,7 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
     }
     int rc = fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                   edge_order_dev, valid_actions_dev, props_dev, h->stream);
-    if (rc != FL_OK) { set_err("fl_obs_cutils: launch failed"); return rc; }
+    if (rc != FL_OK) { set_err("fl_obs_cutils: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc; }
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -792,7 +792,7 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
     }
     int rc = fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                 edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev, h->stream);
-    if (rc != FL_OK) { set_err("fl_obs_cutils_tree: launch failed"); return rc; }
+    if (rc != FL_OK) { set_err("fl_obs_cutils_tree: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc; }
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -804,7 +804,7 @@ int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
         return FL_ERR_ARG;
     }
     int rc = fl_launch_obs_tree(h->obs, h->d, max_depth, pred_depth, out_dev, h->stream);
-    if (rc != FL_OK) { set_err("fl_obs_tree: launch failed"); return rc; }
+    if (rc != FL_OK) { set_err("fl_obs_tree: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc; }
     HIPCHK(hipGetLastError());
     return FL_OK;
 }

@@ -58,7 +58,7 @@ enum {
  *   FL_MAX_SPEED_COUNT     SpeedCounter.max_count = int(1 / speed) - 1 (4 bits of the packed agent word), i.e. speed >= 1/16
  *   FL_MAX_RAIL_CELLS      rail cells per env: rail states r * 4 + orientation are u16 (0xFFFF, 0xFFFE reserved).  In practice the
  *                          LDS sets the limit: the distance-map kernel holds an env's neighbour table, bitmaps and queues
- *                          (about 11 900 cells; fl_reserve / fl_commit say so), the observation kernels its rail-cell index
+ *                          (about 10 900 cells; fl_reserve / fl_commit say so), the observation kernels its rail-cell index
  *                          (about 6 000 cells with 400 agents; the largest Round-2 map, 158 x 158 / 41 cities, has 2 710)
  *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (one 32-lane team per tree; the solution uses 31)
  *   FL_MAX_PRED_DEPTH      predictor depth of either builder (the solution uses 500 / 30)

@@ -153,17 +153,59 @@ def test_bench_starts_its_own_ranks():
 
 def test_capacities_are_checked_before_anything_is_allocated():
     """fl_reserve / fl_commit refuse capacities the table kernels cannot hold (the reverse-BFS kernel keeps the env's neighbour
-    table, visited bitmaps and queues in LDS: about 11 900 rail cells); an env that does not fit a live batch's capacities is
+    table, visited bitmaps and queues in LDS: about 10 900 rail cells); an env that does not fit a live batch's capacities is
     FL_ERR_CAPACITY at fl_load_env (tests/test_gpu_reload.py).  The kernel-side FL_ERR_CAPACITY latches (BFS ring, 16-bit
-    distances of a tree walk) cannot be reached below those limits: a BFS level of a map of 11 900 cells has at most ~1 000
-    states (ring of 4 096), a 31-node tree walks at most 4 laps of the longest possible loop (47 600 < 65 535)."""
+    distances of a tree walk) cannot be reached below those limits: a BFS level of a map of 10 900 cells has at most ~1 000
+    states (ring of 4 096), a 31-node tree walks at most 4 laps of the longest possible loop (43 600 < 65 535)."""
     from flatland_marl_amd.hip_backend import BatchedRailEnv, FlatlandHipError
     fx = util.load("cfg1_uniform")
     with pytest.raises(FlatlandHipError, match="FL_ERR_ARG.*distance-map kernel's LDS"):
         BatchedRailEnv([util.static_of(fx)], reserve=(4, 15000))
     with pytest.raises(FlatlandHipError, match="FL_ERR_ARG.*16383 rail cells"):
         BatchedRailEnv([util.static_of(fx)], reserve=(4, 20000))
-    env = BatchedRailEnv([util.static_of(fx)], reserve=(8, 11000))      # fits: the batch runs
+    env = BatchedRailEnv([util.static_of(fx)], reserve=(8, 10000))      # fits the table kernels: the batch steps ...
+    env.step_synth(1, 0, 0, auto_reset=False)
+    env.check()
+    with pytest.raises(FlatlandHipError, match="FL_ERR_ARG.*observation kernels' LDS"):   # ... the observation index of 10 000 cells does not fit
+        env.obs_both(3, 30)
+    env = BatchedRailEnv([util.static_of(fx)], reserve=(8, 5000))
     env.step_synth(1, 0, 0, auto_reset=False)
     env.obs_both(3, 30)
+    env.check()
+
+
+THREEWAY = ("threeway_cfg2", "threeway_cfg3")
+
+
+@pytest.mark.parametrize("name", THREEWAY)
+@pytest.mark.parametrize("fused", [False, True])
+def test_grid_with_a_three_way_cell_matches_the_reference(name, fused):
+    """a generated map in which one switch got a third way on for one direction of travel (oracle/refharness/capture_threeway.py ran
+    the real reference on it): no Flatland rail cell type has that, the observation kernels take their DFS-slot node tables for
+    such a batch (max_branch > 2) instead of the compact ones"""
+    import torch
+    fx = util.load(name)
+    env = _env([util.static_of(fx)])
+    dm, slot = env.distance_map(0)
+    np.testing.assert_array_equal(dm, fx["dm_u16"])
+    keys = (("agent_attr", "o_attr"), ("forest", "o_forest"), ("adjacency", "o_adjacency"), ("node_order", "o_node_order"),
+            ("edge_order", "o_edge_order"), ("valid_actions", "o_valid"))
+    for t in range(len(fx["state"])):
+        if t > 0:
+            rew, done, _ = env.step(torch.from_numpy(fx["actions"][t - 1][None, :].copy()).cuda())
+            np.testing.assert_array_equal(rew.cpu().numpy()[0], fx["reward"][t - 1])
+        np.testing.assert_array_equal(env.state()[0][0], fx["state"][t], err_msg=f"t={t}")
+        assert not fx["cutils_raised"][t]
+        if fused:
+            got, tree3 = env.obs_both(3, 30)
+            tree2 = env.obs_tree(2, 30) if t % 10 == 0 else None
+        else:
+            got = env.obs_cutils()
+            tree3 = env.obs_tree(3, 30)
+            tree2 = env.obs_both(2, 30)[1] if t % 10 == 0 else None
+        for g, e in keys:
+            np.testing.assert_array_equal(got[g].cpu().numpy()[0], fx[e][t], err_msg=f"t={t} {g}")
+        np.testing.assert_array_equal(tree3.cpu().numpy()[0], fx["py_d3_p30"][t], err_msg=f"t={t} depth-3 tree")
+        if tree2 is not None:
+            np.testing.assert_array_equal(tree2.cpu().numpy()[0], fx["py_d2_p30"][t], err_msg=f"t={t} depth-2 tree")
     env.check()

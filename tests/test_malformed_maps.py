@@ -62,3 +62,23 @@ def test_kernels_on_malformed_maps(name, fused):
         else:
             env.check()
     env.close()
+
+
+@pytest.mark.parametrize("name", ["threeway_cfg2", "threeway_cfg3"])
+def test_oracle_on_a_grid_with_a_three_way_cell(name):
+    """(oracle/refharness/capture_threeway.py: the real reference on a generated map whose first switch got a third way on)"""
+    from oracle import orc
+    fx = util.load(name)
+    e = orc.OracleEnv(fx)
+    dm, slot = e.distance_map()
+    np.testing.assert_array_equal(dm, fx["dm_u16"])
+    for t in range(len(fx["state"])):
+        if t > 0:
+            e.step(fx["actions"][t - 1])
+        np.testing.assert_array_equal(e.state(), fx["state"][t], err_msg=f"t={t}")
+        o = e.obs_cutils(31, 500)
+        for k in ("attr", "forest", "adjacency", "node_order", "edge_order", "valid"):
+            np.testing.assert_array_equal(o[k], fx["o_" + k][t], err_msg=f"t={t} {k}")
+        if t % 5 == 0:
+            for d in (2, 3):
+                np.testing.assert_array_equal(e.obs_pytree(d, 30), fx["py_d%d_p30" % d][t], err_msg=f"t={t} depth {d}")
