@@ -45,6 +45,7 @@ struct fl_batch {
     std::vector<void *> allocs;
     // host copy of every env's static description (filled by fl_load_env; kept after commit: live map replacement,
     // fl_distance_map's expansion to the dense layout)
+    std::vector<uint32_t> h_gridx;  // the device's copy of the grid: transitions | neighbour-has-rail bits (FlDev::grid)
     std::vector<uint16_t> h_grid, h_ridx, h_rgrid, h_nbr, h_rkey, h_init_r, h_target_r, h_ut_r, h_srank;
     std::vector<int> h_maxbr;  // per env: most transitions of any (cell, direction)
     std::vector<uint32_t> h_rcell;
@@ -102,7 +103,7 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
     h->d.B = B; h->d.A = A; h->d.H = H; h->d.W = W; h->d.Ucap = 0; h->d.Rcap = 0;
     const size_t BA = (size_t)B * A, HW = (size_t)H * W;
     h->reserve_U = 0; h->reserve_R = 0;
-    h->h_grid.assign(B * HW, 0); h->h_ridx.assign(B * HW, FL_R_NONE);
+    h->h_grid.assign(B * HW, 0); h->h_gridx.assign(B * HW, 0); h->h_ridx.assign(B * HW, FL_R_NONE);
     h->h_init_pos.assign(BA, 0); h->h_target.assign(BA, 0); h->h_earliest.assign(BA, 0); h->h_latest.assign(BA, 0);
     h->h_init_r.assign(BA, 0); h->h_target_r.assign(BA, 0); h->h_srank.assign(BA, 0); h->h_maxbr.assign(B, 0);
     h->h_tslot.assign(BA, 0); h->h_spk.assign(BA, 0); h->h_speed.assign(BA, 1.0);
@@ -198,6 +199,18 @@ static void build_rail_tables(fl_batch *h, int b) {
         else ridx[c] = FL_R_NONE;
     }
     for (int r = R; r < Rcap; r++) { rcell[r] = 0; rgrid[r] = 0; }
+    // the step kernel's copy of the grid: one load answers "which transitions" and "does the cell towards m have rail"
+    // (check_valid_action, transition_utils.py:47-82)
+    uint32_t *gridx = &h->h_gridx[b * HW];
+    for (size_t c = 0; c < HW; c++) {
+        const int row = (int)(c / W), col = (int)(c % W);
+        uint32_t v = grid[c];
+        for (int m = 0; m < 4; m++) {
+            const int nr = row + (m == 0 ? -1 : m == 2 ? 1 : 0), nc = col + (m == 1 ? 1 : m == 3 ? -1 : 0);
+            if (nr >= 0 && nr < H && nc >= 0 && nc < W && grid[(size_t)nr * W + nc] != 0) v |= 1u << (16 + m);
+        }
+        gridx[c] = v;
+    }
     for (int r = 0; r < Rcap; r++) {
         const int row = r < R ? (int)(rcell[r] / W) : 0, col = r < R ? (int)(rcell[r] % W) : 0;
         for (int m = 0; m < 4; m++) {
@@ -235,7 +248,7 @@ static int upload_envs(fl_batch *h, int b0, int nb) {
     UPLOAD_RANGE(d.T, h->h_T, b, n); UPLOAD_RANGE(d.mt_pos, h->h_mt_pos, b, n); UPLOAD_RANGE(d.mt, h->h_mt, b * 624, n * 624);
     UPLOAD_RANGE(d.malf_thr, h->h_thr, b, n); UPLOAD_RANGE(d.malf_min, h->h_malf_min, b, n); UPLOAD_RANGE(d.malf_max, h->h_malf_max, b, n);
     UPLOAD_RANGE(d.U, h->h_U, b, n); UPLOAD_RANGE(d.R, h->h_R, b, n); UPLOAD_RANGE(d.K, h->h_K, b, n);
-    UPLOAD_RANGE(d.grid, h->h_grid, b * HW, n * HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, n * HW);
+    UPLOAD_RANGE(d.grid, h->h_gridx, b * HW, n * HW); UPLOAD_RANGE(d.ridx, h->h_ridx, b * HW, n * HW);
     UPLOAD_RANGE(d.rgrid, h->h_rgrid, b * Rcap, n * Rcap); UPLOAD_RANGE(d.rtype, h->h_rtype, b * Rcap, n * Rcap); UPLOAD_RANGE(d.nbr, h->h_nbr, b * Rcap * 4, n * Rcap * 4);
     if (d.rkey) UPLOAD_RANGE(d.rkey, h->h_rkey, b * Rcap, n * Rcap);
     UPLOAD_RANGE(d.ut_r, h->h_ut_r, b * Ucap, n * Ucap);

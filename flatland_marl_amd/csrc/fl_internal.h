@@ -5,7 +5,7 @@
 //                         malf u32 (lo16 down counter, hi16 num_malfunctions), pk u32 (packed small fields, see PK_* below)
 //   static  (40 B/agent): init_pos i32, target i32 (cell ids, read by the step), init_r u16, target_r u16 (rail indices, read by
 //                         the observation kernels), earliest i32, latest i32, spk u32, tslot i32, speed f64
-//   per env: t, T, done_all, mt_pos, mt[624], malf_thr u64, malf_min/max, U, R, K, grid u16[H*W] (step only)
+//   per env: t, T, done_all, mt_pos, mt[624], malf_thr u64, malf_min/max, U, R, K, grid u32[H*W] (step only)
 //
 // RAIL-CELL INDEX SPACE.  Only 12-20 % of the cells of a Flatland map carry rail, so every static table of the observation
 // path is indexed by the env's rail cells in row-major order (rail index r in [0, R)) and by rail states s = r * 4 + o
@@ -82,7 +82,7 @@ struct FlDev {
     int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
     double *score_sums;  // [B][2] running sums over the env's finished episodes: normalized reward 1 + R / (T * A), arrived / A
                          // (flatland/evaluators/service.py:875-879, 900-913)
-    uint16_t *grid;   // [B][H*W] transition bitmap per cell (step kernel)
+    uint32_t *grid;   // [B][H*W] per cell: transition bitmap (lo16) | bit 16 + m: the neighbour towards m is on the map and has rail (step kernel)
     uint16_t *ridx;   // [B][H*W] rail index of a cell, FL_R_NONE = no rail
     uint16_t *rgrid;  // [B][Rcap] transition bitmap per rail cell
     uint8_t *rtype;   // [B][Rcap] flatland_cutils road_type 0..10 of the cell (loader.cpp:122-161: index of the matching basic transition)

@@ -169,16 +169,19 @@ int fl_step_prepare() {
     return FL_OK;
 }
 
+#ifndef STEP_NT_MIN
+#define STEP_NT_MIN 256
+#endif
 size_t fl_step_lds_bytes(int A) {
     int nt = ((A + 63) / 64) * 64;
-    if (nt < 256) nt = 256;
+    if (nt < STEP_NT_MIN) nt = STEP_NT_MIN;
     return step_lds_words(A, nt) * 4;
 }
 
 void fl_launch_step(const FlDev &d, const uint8_t *actions, uint32_t seed, uint32_t stream_base, int synth_kind,
                     int32_t *rewards, uint8_t *dones, uint8_t *done_all, int auto_reset, hipStream_t s) {
     int nt = ((d.A + 63) / 64) * 64;
-    if (nt < 256) nt = 256;
+    if (nt < STEP_NT_MIN) nt = STEP_NT_MIN;
     const StepGeom q = step_geom(d.A);
     const int wcap = q.wcap, S = q.S, sshift = q.sshift;
     const size_t lds = step_lds_words(d.A, nt) * 4;

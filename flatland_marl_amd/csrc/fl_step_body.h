@@ -14,7 +14,10 @@ struct StepLds {
     int *a_cur, *a_nxt;                     // [Apad] node ids (cell, or HW + i for the private off-map node)
     int *misc;                              // [16] block-wide scalars
 };
-enum { M_FIRST = 0, M_CHANGED = 1, M_NOTDONE = 2, M_ERR = 3, M_TWISTS = 4 };
+// M_FIRST3 / M_CH3: three slots used in rotation, so that a loop iteration costs ONE barrier: the slot of iteration k + 1 is
+// cleared during iteration k, when every lane is past the barrier of iteration k - 1 and so past its reads of iteration k - 2
+enum { M_NOTDONE = 2, M_ERR = 3, M_TWISTS = 4, M_REWARD = 5, M_ARRIVED = 6, M_FIRST3 = 7, M_CH3 = 10 };
+#define M_NO_AGENT 0x7fffffff
 
 // one MT19937 block regeneration in LDS: three passes, each lane reads its inputs, barrier, writes.
 __device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid, int nt) {
@@ -72,14 +75,12 @@ __device__ __forceinline__ uint32_t check_action(uint32_t cell, uint32_t action,
     return nd;
 }
 
-// check_valid_action / check_action_on_agent (transition_utils.py:47-82)
-__device__ __forceinline__ bool check_valid_action(const uint16_t *grid, int H, int W, int cellid, uint32_t cell,
-                                                   uint32_t action, uint32_t dir) {
+// check_valid_action / check_action_on_agent (transition_utils.py:47-82); cell: a word of FlDev::grid (transitions | bit 16 + m:
+// the neighbour towards m is on the map and has rail)
+__device__ __forceinline__ bool check_valid_action(uint32_t cell, uint32_t action, uint32_t dir) {
     int tv;
     const uint32_t nd = check_action(cell, action, dir, tv);
-    const int r = cellid / W, c = cellid - r * W;
-    const int nr = r + (nd == 0 ? -1 : nd == 2 ? 1 : 0), nc = c + (nd == 1 ? 1 : nd == 3 ? -1 : 0);
-    const bool cell_ok = nr >= 0 && nc >= 0 && nr < H && nc < W && grid[nr * W + nc] != 0;
+    const bool cell_ok = (cell >> (16u + nd)) & 1u;
     if (tv < 0) tv = (int)tbit(cell, dir, nd);
     return cell_ok && tv;
 }
@@ -98,7 +99,7 @@ __device__ __forceinline__ int hash_insert(int *hkey, int cell, int smask, int s
 
 // MotionCheck (envs/agent_chains.py:19-236) restated on cells.  Nodes: an on-map cell id, or vbase + i for the private
 // virtual node of an off-map agent (:28-32).  Needs the cell hash table of L initialised (hkey -1, hocc -1, hwin INT_MAX,
-// hcnt 0, hblk 0) and misc[M_CHANGED] == 0; all nt lanes of the workgroup call it (lane i = agent i, act = i < A).
+// hcnt 0, hblk 0) and misc[M_CH3 ..] == 0; all nt lanes of the workgroup call it (lane i = agent i, act = i < A).
 // pos / np_pos: current and wanted cell, -1 = off map.  Returns "blocked" (check_motion == false).
 __device__ __forceinline__ bool motion_check_cells(StepLds &L, bool act, int i, int A, int pos, int np_pos, int vbase,
                                                    int smask, int sshift, int tid) {
@@ -137,20 +138,17 @@ __device__ __forceinline__ bool motion_check_cells(StepLds &L, bool act, int i, 
     }
     __syncthreads();
     // predecessors of a blocked cell are blocked, transitively (:125-149, :65-105); agents sharing a cell share its flag
-    while (true) {
+    for (int it = 0;; it = it == 2 ? 0 : it + 1) {
+        if (tid == 0) L.misc[M_CH3 + (it == 2 ? 0 : it + 1)] = 0;
         if (act && !blocked) {
             if ((slot_n >= 0 && L.hblk[slot_n]) || (slot_c >= 0 && L.hblk[slot_c])) {
                 blocked = true;
                 if (slot_c >= 0) L.hblk[slot_c] = 1;
-                L.misc[M_CHANGED] = 1;
+                L.misc[M_CH3 + it] = 1;
             }
         }
         __syncthreads();
-        const int ch = L.misc[M_CHANGED];
-        __syncthreads();
-        if (!ch) break;
-        if (tid == 0) L.misc[M_CHANGED] = 0;
-        __syncthreads();
+        if (!L.misc[M_CH3 + it]) break;
     }
     return blocked;
 }
@@ -181,8 +179,26 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
     L.misc = L.a_nxt + nt;
     const int wmask = wcap - 1, smask = S - 1;
 
+    // everything the step reads from HBM before it knows any of it, in ONE round trip: the env's scalars, the agents' words and
+    // the MT19937 block (the early exit below comes after the loads are on their way)
     int t = d.t[b];
     int was_done = d.done_all[b];
+    const uint32_t *grid = d.grid + (size_t)b * HW;
+    const int T = d.T[b];
+    const int pos0 = d.mt_pos[b];
+    const uint64_t thr = d.malf_thr[b];
+    const int mmin = d.malf_min[b], mmax = d.malf_max[b];
+    int pos = -1, old_pos = -1, arrival = -1, init_pos = 0, target = 0, earliest = 0, latest = 0;
+    uint32_t malfw = 0, pk = 0, spk = 0;
+    if (act) {
+        init_pos = d.init_pos[g]; target = d.target[g]; earliest = d.earliest[g]; latest = d.latest[g];
+        spk = d.spk[g];
+        pos = d.pos[g]; old_pos = d.old_pos[g]; arrival = d.arrival[g]; malfw = d.malf[g]; pk = d.pk[g];
+    }
+    for (int k = tid; k < MT_N; k += nt) L.mtl[k] = d.mt[(size_t)b * MT_N + k];
+    for (int k = tid; k < S; k += nt) { L.hkey[k] = -1; L.hocc[k] = -1; L.hwin[k] = 0x7fffffff; L.hcnt[k] = 0; L.hblk[k] = 0; }
+    if (tid < 16) L.misc[tid] = (tid >= M_FIRST3 && tid < M_FIRST3 + 3) ? M_NO_AGENT : 0;
+
     const bool filter_required = (auto_reset & 2) != 0;  // flags: bit 0 auto reset, bit 1 eval_env.parse_actions filter
     auto_reset &= 1;
     if (was_done && !auto_reset) {
@@ -196,20 +212,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         }
         return false;
     }
-    const uint16_t *grid = d.grid + (size_t)b * HW;
-    const int T = d.T[b];
-    const int pos0 = d.mt_pos[b];
-    const uint64_t thr = d.malf_thr[b];
-    const int mmin = d.malf_min[b], mmax = d.malf_max[b];
 
     // ---- per-agent state into registers
-    int pos = -1, old_pos = -1, arrival = -1, init_pos = 0, target = 0, earliest = 0, latest = 0;
-    uint32_t malfw = 0, pk = 0, spk = 0;
-    if (act) {
-        init_pos = d.init_pos[g]; target = d.target[g]; earliest = d.earliest[g]; latest = d.latest[g];
-        spk = d.spk[g];
-        pos = d.pos[g]; old_pos = d.old_pos[g]; arrival = d.arrival[g]; malfw = d.malf[g]; pk = d.pk[g];
-    }
     const uint32_t init_dir = SPK_INIT_DIR(spk), max_count = SPK_MAX_COUNT(spk);
     uint32_t dir = PK_DIR(pk), old_dir = PK_OLD_DIR(pk), state = PK_STATE(pk), prev = PK_PREV(pk), saved = PK_SAVED(pk),
              scount = PK_SCOUNT(pk), sig = PK_SIGMALF(pk), dead = PK_DEADLOCK(pk), done = PK_DONE(pk);
@@ -220,12 +224,9 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         t = 0;
     }
     t += 1;  // rail_env.py:505
-
-    // ---- LDS init
-    for (int k = tid; k < MT_N; k += nt) L.mtl[k] = d.mt[(size_t)b * MT_N + k];
-    for (int k = tid; k < S; k += nt) { L.hkey[k] = -1; L.hocc[k] = -1; L.hwin[k] = 0x7fffffff; L.hcnt[k] = 0; L.hblk[k] = 0; }
-    if (tid < 16) L.misc[tid] = 0;
-    if (tid == 0) L.misc[M_FIRST] = 0x7fffffff;
+    // the agent's cell: needed after the malfunction draws, asked for now
+    const int pc = pos < 0 ? init_pos : pos;
+    const uint32_t cell = act ? grid[pc] : 0u;
     __syncthreads();
 
     // ---- malfunction draws (handle order, one shared stream): speculative + serial replay of firing agents
@@ -235,19 +236,18 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
     uint32_t rmask = rng_span;
     rmask |= rmask >> 1; rmask |= rmask >> 2; rmask |= rmask >> 4; rmask |= rmask >> 8; rmask |= rmask >> 16;
     rng_ensure(L, pos0, gen_hi, 2 * A, twists, wmask, tid, nt);
-    while (true) {
+    for (int it = 0;; it = it == 2 ? 0 : it + 1) {
         bool fire = false;
         if (act && i >= start) {
             const uint32_t wa = L.words[(2 * i + extra) & wmask], wb = L.words[(2 * i + extra + 1) & wmask];
             const uint64_t u53 = ((uint64_t)(wa >> 5) << 26) | (uint64_t)(wb >> 6);  // RandomState.rand() * 2^53
             fire = u53 < thr;
-            if (fire) atomicMin(&L.misc[M_FIRST], i);
+            if (fire) atomicMin(&L.misc[M_FIRST3 + it], i);
         }
+        if (tid == 0) L.misc[M_FIRST3 + (it == 2 ? 0 : it + 1)] = M_NO_AGENT;
         __syncthreads();
-        const int first = L.misc[M_FIRST];
-        __syncthreads();
-        if (first == 0x7fffffff) break;
-        if (tid == 0) L.misc[M_FIRST] = 0x7fffffff;
+        const int first = L.misc[M_FIRST3 + it];
+        if (first == M_NO_AGENT) break;
         // randint(min, max+1) + 1 for agent `first` (masked rejection on 32-bit words); evaluated by every lane
         int k = 2 * first + extra + 2;
         uint32_t v = 0;
@@ -261,8 +261,7 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         if (i == first) n_broken = (uint32_t)mmin + v + 1u;
         extra = k - (2 * first + 2);
         start = first + 1;
-        rng_ensure(L, pos0, gen_hi, 2 * A + extra, twists, wmask, tid, nt);
-        __syncthreads();
+        rng_ensure(L, pos0, gen_hi, 2 * A + extra, twists, wmask, tid, nt);  // (ends in a barrier whenever it wrote words)
     }
     const int consumed = 2 * A + extra;
     // malfunction_handler.py:35-42
@@ -287,7 +286,7 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
             else if (!is_on_map(state) || pos < 0) raw = ACT_NOTHING;
             else if (h % 100u < 3u) raw = ACT_STOP;
             else {
-                const uint32_t bits = nibble(grid[pos], dir);
+                const uint32_t bits = nibble(cell, dir);
                 raw = ACT_FORWARD;
                 if (__popc(bits) != 1) {
                     const uint16_t *dm_t = d.dm + ((size_t)b * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4);
@@ -311,11 +310,9 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         a = raw;
         if (a == ACT_NOTHING) a = (state == ST_MOVING) ? (uint32_t)ACT_FORWARD : (saved ? saved : (uint32_t)ACT_NOTHING);
         if (state == ST_WAITING) a = ACT_NOTHING;
-        const int pc = pos < 0 ? init_pos : pos;
         const uint32_t pd = pos < 0 ? init_dir : dir;
-        const uint32_t cell = grid[pc];
-        if ((a == ACT_LEFT || a == ACT_RIGHT) && !check_valid_action(grid, H, W, pc, cell, a, pd)) a = ACT_FORWARD;
-        if (a >= ACT_LEFT && a <= ACT_RIGHT && !check_valid_action(grid, H, W, pc, cell, a, pd)) a = ACT_STOP;
+        if ((a == ACT_LEFT || a == ACT_RIGHT) && !check_valid_action(cell, a, pd)) a = ACT_FORWARD;
+        if (a >= ACT_LEFT && a <= ACT_RIGHT && !check_valid_action(cell, a, pd)) a = ACT_STOP;
         if (a >= ACT_LEFT && a <= ACT_RIGHT && !saved && state != ST_DONE) saved = a;  // action_saver.py:16-24
         const bool upd = (scount == max_count) && !(malf > 0) && a != ACT_STOP;        // :535-537
         if (pos < 0 && state != ST_DONE && a == ACT_STOP) saved = 0;                   // :540-542
@@ -387,8 +384,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
             reward = is_off_map(state) ? -travel : (latest - t) - travel;
         }
         done = 1;
-        if (reward != 0) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward); atomicAdd(&L.misc[5], reward); }
-        if (state == ST_DONE) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull); atomicAdd(&L.misc[6], 1); }
+        if (reward != 0) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 0], (unsigned long long)(long long)reward); atomicAdd(&L.misc[M_REWARD], reward); }
+        if (state == ST_DONE) { atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 1], 1ull); atomicAdd(&L.misc[M_ARRIVED], 1); }
     }
 
     __syncthreads();
@@ -413,15 +410,15 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
             d.t[b] = t;
             d.done_all[b] = ended ? 1 : 0;
             done_all_out[b] = ended ? 1 : 0;
-            d.metrics[(size_t)b * 4 + 2] += A;              // only this workgroup touches env b's counters
+            atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 2], (unsigned long long)A);  // (no read to wait for)
             if (ended) {
                 atomicAdd((unsigned long long *)&d.metrics[(size_t)b * 4 + 3], 1ull);
-                d.last_episode[(size_t)b * 2 + 0] = L.misc[5];  // evaluator scoring inputs (service.py:875-879,900-913)
-                d.last_episode[(size_t)b * 2 + 1] = L.misc[6];
+                d.last_episode[(size_t)b * 2 + 0] = L.misc[M_REWARD];  // evaluator scoring inputs (service.py:875-879,900-913)
+                d.last_episode[(size_t)b * 2 + 1] = L.misc[M_ARRIVED];
                 // the evaluator's per-episode terms, summed per env in episode order (service.py:875-879: normalized reward =
                 // cumulative reward / (max_episode_steps * n_agents) + 1; :900-913: complete agents / agents)
-                d.score_sums[(size_t)b * 2 + 0] += 1.0 + (double)L.misc[5] / ((double)T * (double)A);
-                d.score_sums[(size_t)b * 2 + 1] += (double)L.misc[6] / (double)A;
+                d.score_sums[(size_t)b * 2 + 0] += 1.0 + (double)L.misc[M_REWARD] / ((double)T * (double)A);
+                d.score_sums[(size_t)b * 2 + 1] += (double)L.misc[M_ARRIVED] / (double)A;
             }
             if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
         }
