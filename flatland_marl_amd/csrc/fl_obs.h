@@ -16,6 +16,9 @@ struct FlObsScratch {
     uint16_t *bk_rel;  // [B][Rcap * 8] ends of the time buckets inside every key's list (large maps, see OBS_BK_NB)
     uint2 *wl;         // [B][wl_cap] pass B work lists of the large-map kernels
     int wl_cap;
+    uint32_t *cost;    // [B] clock ticks of the env's previous observation launch (its workgroup writes them)
+    int *order;        // [B] env of workgroup k, longest first (k_env_order), or null: env k (batches of at most one env per CU)
+    int n_cu;          // CUs of the device
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);
@@ -27,4 +30,6 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
+// more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
+FlObsScratch fl_obs_env_order(const FlObsScratch &o, const FlDev &d, hipStream_t s);
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[10]);  // diagnostic

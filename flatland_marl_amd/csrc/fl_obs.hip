@@ -25,8 +25,57 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.wl_cap = OBS_WL_HBM_ENTRIES;
     if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
     o.wl = (uint2 *)p; allocs.push_back(p);
-    (void)s;
+    if (hipMalloc(&p, (size_t)d.B * 4) != hipSuccess) return FL_ERR_HIP;
+    o.cost = (uint32_t *)p; allocs.push_back(p);
+    if (hipMemsetAsync(o.cost, 0, (size_t)d.B * 4, s) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * 4) != hipSuccess) return FL_ERR_HIP;
+    o.order = (int *)p; allocs.push_back(p);
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return FL_ERR_HIP;
+    o.n_cu = n_cu;
     return FL_OK;
+}
+
+// The launch is one workgroup per env and a CU holds one workgroup: with more envs than CUs the launch ends when the last CU has
+// worked through its envs, and the envs differ (agents on the map, traffic around them) -- mean 187 us, slowest 315 us at cfg4.
+// Longest first: the workgroups take the envs in descending order of what each took in the previous launch (a counting sort
+// over 1024 bins by ONE workgroup; ties in any order -- the results of an env do not depend on which workgroup builds it).
+__global__ __launch_bounds__(1024) void k_env_order(int B, const uint32_t *__restrict__ cost, int *__restrict__ order) {
+    __shared__ unsigned int hist[1024];
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int cmax;
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) cmax = 1;
+    __syncthreads();
+    unsigned int m = 0;
+    for (int b = tid; b < B; b += 1024) m = max(m, cost[b]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off));
+    if ((tid & 63) == 0) atomicMax(&cmax, m);
+    __syncthreads();
+    const unsigned long long top = cmax;
+    for (int b = tid; b < B; b += 1024) atomicAdd(&hist[1023u - (unsigned int)((unsigned long long)cost[b] * 1023ull / top)], 1u);
+    __syncthreads();
+    // exclusive prefix over the bins (bin 0 = the longest envs)
+    const unsigned int v = hist[tid];
+    unsigned int incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned int u = (unsigned int)__shfl_up((int)incl, off); if ((tid & 63) >= off) incl += u; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+    __syncthreads();
+    hist[tid] = base + incl - v;
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) order[atomicAdd(&hist[1023u - (unsigned int)((unsigned long long)cost[b] * 1023ull / top)], 1u)] = b;
+}
+
+FlObsScratch fl_obs_env_order(const FlObsScratch &o, const FlDev &d, hipStream_t s) {
+    static const bool off = getenv("FL_OBS_NO_ORDER") != nullptr;   // diagnostic: workgroup k builds env k
+    FlObsScratch u = o;
+    if (off || d.B <= o.n_cu) { u.order = nullptr; return u; }
+    hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, s, d.B, o.cost, o.order);
+    return u;
 }
 
 void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
@@ -36,7 +85,7 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
 }
 
 // what a launch may keep in LDS besides the arrays every launch needs
-struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb; };
+struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap; };
 
 // carve the dynamic LDS of a launch: every array the kernel uses, in one place (the kernel follows ObsLayout::off)
 static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &o) {
@@ -52,7 +101,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
     put(L_CELL_TARGET, ((R + 31) / 32) * 4);
     put(L_A_SPEED, A * 8); put(L_A_TQ, A * 8);
-    if (P.merged && o.own_filter) { put(L_A_RAW, A * 32); put(L_RTYPE, R); }
+    if (P.merged && o.raw) { put(L_A_RAW, A * 32); put(L_RTYPE, R); }   // the agents' raw words and the road types (attribute rows)
     put(L_A_VPOS, A * 2); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 2); put(L_A_TARGET, A * 2);
     put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2); put(L_A_SRANK, A * 2);
     put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
@@ -67,7 +116,8 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     }
     put(L_CSR, K1 * 4);
     // one pass B for both builders needs the room for twice the node tables: a tighter first-index copy (128 waypoints an agent)
-    L.items_cap = (P.merged && o.own_filter) ? (int)std::min<size_t>(OBS_ITEMS_LDS_CAP, std::max<size_t>(1024, A * 128)) : OBS_ITEMS_LDS_CAP;
+    const size_t cap1 = o.items_cap ? (size_t)o.items_cap : (size_t)OBS_ITEMS_LDS_CAP;
+    L.items_cap = (P.merged && o.own_filter) ? (int)std::min<size_t>(cap1, std::max<size_t>(1024, A * 128)) : (int)cap1;
     L.items2_cap = (int)std::min<size_t>(OBS_ITEMS2_CAP, A * (size_t)(P.tree_pred + 2));  // an agent has at most tree_pred + 1 of them
     if (o.items) put(L_ITEMS, (size_t)L.items_cap * 4);
     if (o.wl_bytes) put(L_WL, (size_t)o.wl_bytes);       // 0: the work lists live in HBM scratch
@@ -150,18 +200,25 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
             if ((o.fb && no_fb) || !ok(force.wl, o.wl_bytes) || !ok(force.items, o.items) || (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP)) continue;
-            for (o.own_filter = (no_own || !o.items) ? 0 : 1; o.own_filter >= 0; o.own_filter--)  // (the filter's masks are built by the LDS fill)
-                for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
-                    if (!ok(force.nh, o.nh)) continue;
-                    const ObsLayout L = obs_layout(d, P, o);
-                    if (L.total > lds_limit) continue;
-                    P.L = L; P.use_tmask = 1; P.dual_index = 1;
-                    P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
-                    P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
-                    // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
-                    P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
-                    return true;
-                }
+            // the own-path filter of the classify loop (a second set of time masks) before the full-size LDS copy of the items: on
+            // sparse maps a third of the conflict entries are the walking agent's own prediction (cfg4: 34 %), and an env whose
+            // items do not fit the smaller copy scans them in HBM scratch at nearly the same speed
+            static const int caps[2] = {OBS_ITEMS_LDS_CAP, 4096};
+            for (o.own_filter = no_own ? 0 : 1; o.own_filter >= 0; o.own_filter--)
+                for (int ck = 0; ck < (o.items ? 2 : 1); ck++)
+                    for (o.raw = o.own_filter; o.raw >= 0; o.raw--)
+                        for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
+                            if (!ok(force.nh, o.nh)) continue;
+                            o.items_cap = caps[ck];
+                            const ObsLayout L = obs_layout(d, P, o);
+                            if (L.total > lds_limit) continue;
+                            P.L = L; P.use_tmask = 1; P.dual_index = 1;
+                            P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
+                            P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
+                            // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
+                            P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
+                            return true;
+                        }
         }
         P.merged = 0;
     }
@@ -241,7 +298,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     obs_verbose(P);
-    return fl_obs_launch_m0(obs_var(P), d, o, P, s);
+    return fl_obs_launch_m0(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }
 
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -256,7 +313,8 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     obs_verbose(P);
-    return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, o, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, o, P, s) : fl_obs_launch_m2(obs_var(P), d, o, P, s);
+    const FlObsScratch u = fl_obs_env_order(o, d, s);
+    return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
@@ -267,7 +325,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     obs_tree_args(d, P, max_depth, pred_depth, out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     obs_verbose(P);
-    return fl_obs_launch_m1(obs_var(P), d, o, P, s);
+    return fl_obs_launch_m1(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }
 
 // diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth):
@@ -278,8 +336,9 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, nullptr);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    out[0] = P.L.nt; out[1] = (int)P.L.total; out[2] = P.L.tab_lds; out[3] = P.L.off[L_NH] != L_ABSENT; out[4] = P.L.wl_bytes; out[5] = P.use_tmask;
-    out[6] = P.dual_index; out[7] = P.L.off[L_ITEMS] != L_ABSENT;
+    out[0] = P.L.nt; out[1] = (int)P.L.total; out[2] = P.L.tab_lds; out[3] = P.L.off[L_NH] != L_ABSENT; out[4] = P.L.wl_bytes;
+    out[5] = P.use_tmask + 2 * (P.L.off[L_TMASK2] != L_ABSENT);                    // 3: time masks + the own-path filter's second set
+    out[6] = P.dual_index; out[7] = P.L.off[L_ITEMS] != L_ABSENT ? P.L.items_cap : 0;  // entries of the LDS copy of the items
     out[8] = P.merged; out[9] = P.compact_t;
     return FL_OK;
 }

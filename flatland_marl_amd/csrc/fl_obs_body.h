@@ -34,10 +34,13 @@
 // MERGED (its own kernel, MODE 3): stage 1 of the fused launch builds the trees of BOTH builders, one pass B per round
 // (trees_merged); there is no stage 2.  The launcher sizes the LDS copy of the second index for the exact bound on its items, so
 // this mode never has to fall back.
+// workgroup k builds env k, or -- more envs than CUs -- the env the host's ordering kernel put k-th (fl_obs_env_order)
+__device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return S.order ? S.order[blockIdx.x] : (int)blockIdx.x; }
+
 template <bool CUTILS, int VAR, int STAGE, int MERGED = 0>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = obs_env_of_workgroup(S), tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
@@ -960,6 +963,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 // round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents); VAR: see obs_body
 template <int MODE, int VAR>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
+    const long long t_start = S.order ? (long long)wall_clock64() : 0ll;
     if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else if (MODE == 3) obs_body<true, VAR, 1, 1>(d, S, P);
@@ -969,5 +973,6 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         __syncthreads();
         obs_body<false, VAR, 2>(d, S, P);
     }
+    // what this env took: the next launch starts the longest envs first
+    if (S.order && threadIdx.x == 0) S.cost[obs_env_of_workgroup(S)] = (uint32_t)((long long)wall_clock64() - t_start);
 }
-

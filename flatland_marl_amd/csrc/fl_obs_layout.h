@@ -24,7 +24,9 @@
 #define CF_DIRECT 32                 // when no list of the env is longer, every conflict entry is scanned by its lane alone, in one pass
 #endif
 #define OBS_ITEMS2_CAP 4096          // items of the second (upstream) index built by stage 1 of the fused launch
+#ifndef OBS_ITEMS_LDS_CAP
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
+#endif
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
 // Large maps (items in HBM, hundreds of agents): inside a key's list the items are grouped by bucket of 64 time steps, an
 // item sits in every bucket its interval touches, and a conflict query scans only the buckets its three time steps fall in

@@ -484,7 +484,19 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             const bool cu = pb_cu<PB>(X, team);
             const int pt = pt_of<PB>(X, cu, handle, tot);
             const ListRange R = list_range<PB>(X, cu, cell, pt);
+#ifdef FL_OBS_COUNTS
+            const uint32_t f = R.n > 0 ? conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, R.n) : 0u;
+            if (X.dbg) {
+                atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
+                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+                if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
+                if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
+                if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
+            }
+            if (conflict_hit(f)) {
+#else
             if (R.n > 0 && conflict_hit(conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, R.n))) {
+#endif
                 constexpr int cap = PB == 2 ? 32 : CAP;
                 int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);

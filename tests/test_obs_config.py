@@ -30,10 +30,11 @@ def _sizes(workload):
 
 @pytest.mark.parametrize("workload,depth,expect", [
     # depth 2 is the bench default, depth 3 is BASELINE's definition of configs[2] / configs[4].
-    # merged: one pass B for the trees of both builders (1 = one round, 2 = rounds of 32 agents); wl = 0: work lists in HBM scratch
-    ("cfg2", 2, dict(nt=1024, wl=24576, tmask=1, dual=1, items=1, merged=1, compact=1)),
-    ("cfg3", 3, dict(nt=1024, wl=36864, tmask=1, dual=1, items=1, merged=2, compact=1)),
-    ("cfg4", 2, dict(nt=1024, wl=0, tmask=1, dual=1, items=1, merged=2, compact=1)),
+    # merged: one pass B for the trees of both builders (1 = one round, 2 = rounds of 32 agents); wl = 0: work lists in HBM scratch;
+    # tmask 3 = time masks + the second set of the classify loop's own-path filter; items = entries of the LDS copy of the items
+    ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=2560, merged=1, compact=1)),
+    ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1)),
+    ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=4096, merged=2, compact=1)),
     ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),
     ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),   # round 2: 512 threads (85-slot tables)
 ])
