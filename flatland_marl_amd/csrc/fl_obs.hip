@@ -190,8 +190,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         // 0.52 ms); lists grouped by 32-step time buckets where their offsets fit too (cfg4: 0.48 -> 0.45 ms, cfg3 neutral).
         struct Pref { int fb, wl, items; };
         static const Pref one_round[] = {{0, 24 * 1024, 1}, {0, 16 * 1024, 1}, {0, 0, 1}, {0, 24 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
-        static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 1}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
-                                      {1, 0, 0}, {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
+        static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
+                                      {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
         static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
         static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
         const Pref *prefs = P.merged == 1 ? one_round : rounds;
@@ -203,7 +203,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             // the own-path filter of the classify loop (a second set of time masks) before the full-size LDS copy of the items: on
             // sparse maps a third of the conflict entries are the walking agent's own prediction (cfg4: 34 %), and an env whose
             // items do not fit the smaller copy scans them in HBM scratch at nearly the same speed
-            static const int caps[2] = {OBS_ITEMS_LDS_CAP, 4096};
+            static const int caps[2] = {OBS_ITEMS_LDS_CAP, 4096};   // (2048: cfg3 0.86 against 0.77 ms -- most envs' items then sit in HBM)
             for (o.own_filter = no_own ? 0 : 1; o.own_filter >= 0; o.own_filter--)
                 for (int ck = 0; ck < (o.items ? 2 : 1); ck++)
                     for (o.raw = o.own_filter; o.raw >= 0; o.raw--)
@@ -336,6 +336,17 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, nullptr);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    if (getenv("FL_OBS_VERBOSE")) {   // diagnostic: the carving of the LDS, array by array (enum L_* of fl_obs_layout.h)
+        static const char *names[L_COUNT] = {"cellw", "nbr", "snext", "rkey", "slot_agent", "slot_ready", "cell_target", "a_speed", "a_vpos", "a_pos", "a_tslot",
+            "a_target", "a_malf", "a_tpc", "a_tq", "a_tq2", "a_raw", "rtype", "a_lp", "a_n", "a_srank", "a_dir", "a_state", "a_free", "a_dead", "misc", "team_meta", "node_tables",
+            "csr", "items", "wl", "partial", "tmask", "tmask2", "nh", "csr2", "tmaskb", "tmaskb2", "items2", "a_lp2", "a_tpc2", "bkrel", "seg", "dm", "hop8"};
+        for (int k = 0; k < L_COUNT; k++) {
+            if (P.L.off[k] == L_ABSENT) continue;
+            unsigned next = P.L.total;
+            for (int j = 0; j < L_COUNT; j++) if (P.L.off[j] != L_ABSENT && P.L.off[j] > P.L.off[k] && P.L.off[j] < next) next = P.L.off[j];
+            fprintf(stderr, "  %-12s %7u B\n", names[k], next - P.L.off[k]);
+        }
+    }
     out[0] = P.L.nt; out[1] = (int)P.L.total; out[2] = P.L.tab_lds; out[3] = P.L.off[L_NH] != L_ABSENT; out[4] = P.L.wl_bytes;
     out[5] = P.use_tmask + 2 * (P.L.off[L_TMASK2] != L_ABSENT);                    // 3: time masks + the own-path filter's second set
     out[6] = P.dual_index; out[7] = P.L.off[L_ITEMS] != L_ABSENT ? P.L.items_cap : 0;  // entries of the LDS copy of the items

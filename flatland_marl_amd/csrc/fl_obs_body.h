@@ -642,7 +642,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     // (bk_w is even: the count of that bucket is the low half of the key's last word, the high half collects the
                     // time buckets in which such items start)
                     atomicAdd(&bkc[(key * bk_w + bk_nb) >> 1], 1u);
-                    atomicOr(&bkc[(key * bk_w + bk_nb) >> 1], 0x10000u << b1);
+                    atomicOr(&bkc[(key * bk_w + bk_nb) >> 1], 0x10000u << (b1 >> OBS_FB_MSHIFT));
                     if (b2 > b1) atomicSub(&csr[key], b2 - b1);
                 }
             }

@@ -111,7 +111,7 @@ __device__ __forceinline__ ListRange list_range(const ObsCtx &X, bool cu, int r,
         const int o1 = b1 > 0 ? (int)rel[b1 - 1] : 0;
         R.lo = base + o1;
         R.n1 = R.n = (int)rel[b2] - o1;
-        if ((uint32_t)rel[X.bk_nb + 1] & ((2u << b2) - 1u)) {  // somebody stays here from a time the query can see
+        if ((uint32_t)rel[X.bk_nb + 1] & ((2u << (b2 >> OBS_FB_MSHIFT)) - 1u)) {  // somebody stays here from a time the query can see
             const int oe = (int)rel[X.bk_nb - 1];
             R.lo2 = base + oe;
             R.n += (int)rel[X.bk_nb] - oe;

@@ -35,8 +35,11 @@
 #define OBS_BK_SHIFT 6
 // Small maps (index in LDS): sixteen buckets of 32 steps, their offsets in an LDS array of their own -- a query scans the
 // handful of items around its time instead of everybody who ever passes the cell (20 items a query at 80 agents).
+#ifndef OBS_FB_NB
 #define OBS_FB_NB 16
 #define OBS_FB_SHIFT 5
+#endif
+#define OBS_FB_MSHIFT (OBS_FB_NB > 16 ? 1 : 0)   // the 16-bit mask of the buckets in which a stay-to-the-end item starts: bucket >> this
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
