@@ -15,7 +15,7 @@ UNITS=(fl_obs_m2 fl_obs_m4 fl_obs_m3 fl_obs_m0 fl_obs_m1 fl_host fl_step fl_dmap
 # and queue counters); the optimizer's own wave reduction around them only adds instructions and waits (k_step 12.6 -> 12.0 us)
 # -disable-lsr: loop strength reduction turns the loops' index arithmetic into extra induction registers; at the register ceiling
 # that is spills and moves (same-box A/B: cfg2 k_obs 52.3 -> 50.9 us, cfg3 0.777 -> 0.765 ms, cfg4 / cfg5 unchanged)
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -disable-machine-licm -mllvm -disable-lsr
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -disable-machine-licm ${FL_LSR_FLAGS--mllvm -disable-lsr}
        -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-result ${EXTRA_HIPCC_FLAGS:-})
 mkdir -p "$OBJDIR"
 # stamp = hash of everything every unit depends on besides its own source: headers, this script, the flags

@@ -35,7 +35,9 @@
 // (trees_merged); there is no stage 2.  The launcher sizes the LDS copy of the second index for the exact bound on its items, so
 // this mode never has to fall back.
 // workgroup k builds env k, or -- more envs than CUs -- the env the host's ordering kernel put k-th (fl_obs_env_order)
-__device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return S.order ? S.order[blockIdx.x] : (int)blockIdx.x; }
+// (readfirstlane: the compiler cannot prove the load unclobbered, makes it a vector load, and every address derived from the env
+// index would be vector arithmetic -- 29 spilled vector registers in the rounds kernel)
+__device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return __builtin_amdgcn_readfirstlane(S.order ? S.order[blockIdx.x] : (int)blockIdx.x); }
 
 template <bool CUTILS, int VAR, int STAGE, int MERGED = 0>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {

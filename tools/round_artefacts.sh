@@ -1,0 +1,37 @@
+#!/usr/bin/env bash
+# The profiles of record of a round, in one GPU-box call:  tools/round_artefacts.sh TAG   -> gpurun_out/prof_TAG/
+#   kernel traces + PMC traffic of the four workloads (tools/profile_workloads.py), SQ counters of the cfg2 launch (three passes of
+#   tools/pmc_pass.py), phase clocks (build_ab/libfl_timing.so = tools/build_variant.sh timing -DFL_OBS_TIMING), the default bench line
+set -uo pipefail
+tag=$1
+out=gpurun_out/prof_$tag
+mkdir -p $out
+python tools/profile_workloads.py $tag > $out/profile_workloads.log 2>&1 || tail -5 $out/profile_workloads.log
+echo "[artefacts] traces + traffic done"
+A="--no-extra-workloads --steps 100"
+python tools/pmc_pass.py $out/sq1.json "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" $A > /dev/null 2>&1 || echo "sq pass 1 failed"
+python tools/pmc_pass.py $out/sq2.json "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" $A > /dev/null 2>&1 || echo "sq pass 2 failed"
+python tools/pmc_pass.py $out/sq3.json "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM" $A > /dev/null 2>&1 || echo "sq pass 3 failed (counter names)"
+python - $out $tag <<'PY'
+import json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+acc = {}
+for k in (1, 2, 3):
+    p = os.path.join(out, "sq%d.json" % k)
+    if os.path.exists(p):
+        for kern, d in json.load(open(p)).items():
+            acc.setdefault(kern, {}).update(d)
+json.dump(acc, open(os.path.join(out, "%s_sq_counters_cfg2.json" % tag), "w"), indent=1, sort_keys=True)
+PY
+echo "[artefacts] SQ counters done"
+if [ -f build_ab/libfl_timing.so ]; then
+  : > $out/${tag}_phase_clocks.txt
+  for w in "cfg2 2" "cfg3 3" "cfg4 2" "cfg5 3"; do
+    WARM=$([ "$w" = "cfg5 3" ] && echo 60 || echo 200) python tools/obs_phase_clocks.py build_ab/libfl_timing.so $w 2>&1 | grep -v amdgpu.ids >> $out/${tag}_phase_clocks.txt
+    echo >> $out/${tag}_phase_clocks.txt
+  done
+fi
+echo "[artefacts] phase clocks done"
+python bench.py > $out/${tag}_bench_default.json 2> $out/bench_default.err || tail -3 $out/bench_default.err
+python -c "
+import json,sys; d=json.load(open('$out/${tag}_bench_default.json')); print('headline %.2f M' % (d['value']/1e6), d['roofline'], {k: round(v['value']/1e6,1) for k,v in d.get('workloads',{}).items()})"
