@@ -313,7 +313,9 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     obs_verbose(P);
-    const FlObsScratch u = fl_obs_env_order(o, d, s);
+    FlObsScratch u = o;
+    if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
+    else u = fl_obs_env_order(o, d, s);
     return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
 }
 

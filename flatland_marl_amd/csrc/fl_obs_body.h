@@ -42,7 +42,8 @@ __device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { ret
 template <bool CUTILS, int VAR, int STAGE, int MERGED = 0>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
-    const int b = obs_env_of_workgroup(S), tid = threadIdx.x, nt = blockDim.x;
+    // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
+    const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = blockDim.x;
     const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
         for (int c = tid; c < (R + 31) / 32; c += nt) cell_target[c] = 0;
-        if (tid < 64) misc[tid] = 0;
+        if (tid < 62) misc[tid] = 0;   // (62, 63: the launch's env and start clock, see k_obs)
         __syncthreads();
         // location_has_agent* (treeobs.cpp:74-81): the last (highest) handle on a cell wins; ready-to-depart counts (:82-91).
         // Occupied cells get an entry in a small table; the per-cell word only holds the entry index.
@@ -965,7 +966,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 // round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents); VAR: see obs_body
 template <int MODE, int VAR>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
-    const long long t_start = S.order ? (long long)wall_clock64() : 0ll;
+    // what this env takes goes to S.cost: the next launch starts the longest envs first.  Env and start clock wait in two LDS words
+    // (not in registers: the kernel sits at its register ceiling, and every scalar that lives through it costs spills)
+    if (MODE != 3 && S.order && threadIdx.x == 0) {
+        extern __shared__ __align__(16) unsigned char lds[];
+        int *misc = reinterpret_cast<int *>(lds + P.L.off[L_MISC]);
+        misc[62] = obs_env_of_workgroup(S);
+        misc[63] = (int)(uint32_t)wall_clock64();
+    }
     if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else if (MODE == 3) obs_body<true, VAR, 1, 1>(d, S, P);
@@ -975,6 +983,9 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         __syncthreads();
         obs_body<false, VAR, 2>(d, S, P);
     }
-    // what this env took: the next launch starts the longest envs first
-    if (S.order && threadIdx.x == 0) S.cost[obs_env_of_workgroup(S)] = (uint32_t)((long long)wall_clock64() - t_start);
+    if (MODE != 3 && S.order && threadIdx.x == 0) {
+        extern __shared__ __align__(16) unsigned char lds[];
+        const int *misc = reinterpret_cast<const int *>(lds + P.L.off[L_MISC]);
+        S.cost[misc[62]] = (uint32_t)wall_clock64() - (uint32_t)misc[63];
+    }
 }
