@@ -13,7 +13,7 @@ struct FlObsScratch {
     long long *dbg;    // [B][32] phase clocks of diagnostic builds (-DFL_OBS_TIMING)
     uint32_t *cell_items;  // [B][items_cap] prediction items (IT_* packing, fl_obs.hip) when they do not fit LDS
     size_t items_cap;
-    uint16_t *bk_rel;  // [B][Rcap * 8] ends of the time buckets inside every key's list (large maps, see OBS_BK_NB)
+    uint16_t *bk_rel;  // [B][8][Rcap + 1] ends of the keys' items inside every time bucket (large maps: bucket-major items, see OBS_BK_NB)
     uint2 *wl;         // [B][wl_cap] pass B work lists of the large-map kernels
     int wl_cap;
     uint32_t *cost;    // [B] clock ticks of the env's previous observation launch (its workgroup writes them)

@@ -20,7 +20,7 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 64 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * d.Rcap * OBS_BK_NB * 2 + 16) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * (d.Rcap + 1) * OBS_BK_NB * 2 + 16) != hipSuccess) return FL_ERR_HIP;
     o.bk_rel = (uint16_t *)p; allocs.push_back(p);
     o.wl_cap = OBS_WL_HBM_ENTRIES;
     if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
@@ -111,7 +111,7 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
         // borrow this space for the per-(key, time bucket) counters while the bucketed index is built (P.bk): room for those too
         size_t scr = P.merged ? (size_t)32 * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
                               : (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4;
-        if (o.bk_room) scr = std::max(scr, (size_t)d.Rcap * OBS_BK_NB * 2);
+        if (o.bk_room) scr = std::max(scr, (size_t)(d.Rcap + 1) * OBS_BK_NB * 2 + 4);
         put(L_WAVE_SCR, scr);
     }
     put(L_CSR, K1 * 4);
@@ -237,7 +237,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                 if (!ok(force.wl, o.wl_bytes) || !ok(force.tmask, o.tmask) || !ok(force.dual, o.dual) || !ok(force.items, o.items)) continue;
                 // large maps: the cutils index grouped by time bucket, counted in the node tables' LDS (room for the counters)
                 static const bool no_bk = getenv("FL_OBS_NO_BK") != nullptr;
-                const bool want_bk = !no_bk && o.wl_bytes == 0 && !o.items && o.tmask && !o.dual && P.tw_c != 0 && P.pred_depth + 1 > 64;
+                const bool want_bk = !no_bk && o.wl_bytes == 0 && !o.items && o.tmask && !o.dual && P.tw_c != 0 && P.pred_depth + 1 > 64 &&
+                                     d.A * ((1 << OBS_BK_SHIFT) + 2) <= 65535;   // (offsets inside a bucket are 16 bits)
                 for (o.bk_room = want_bk ? 1 : 0; o.bk_room >= 0; o.bk_room--)
                 for (o.snext = 1; o.snext >= 0; o.snext--)
                     for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--)

@@ -248,7 +248,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_vpos = a_vpos; X.a_dir = a_dir; X.a_state = a_state; X.a_malf = a_malf; X.a_speed = a_speed;
     X.a_tpc = a_tpc; X.a_tq = a_tq; X.a_tslot = a_tslot; X.a_target = a_target; X.a_srank = a_srank;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
-    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr; X.bk_rel_lds = nullptr;
+    X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr; X.bk_rel_lds = nullptr; X.bk_base = nullptr; X.bk_k1 = 0;
     X.bk_nb = P.bk_nb; X.bk_shift = P.bk_shift;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
@@ -538,7 +538,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             for (int k = tid; k <= K; k += nt) csr[k] = 0;
             if (tid == 0) misc[11] = 0;
             if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
-            if (bk) for (int k = tid; k < K * bk_w / 2; k += nt) bkc[k] = 0u;
+            if (bk) for (int k = tid; k < (bk_lds ? K * bk_w / 2 : ((K + 1) * bk_nb + 1) / 2); k += nt) bkc[k] = 0u;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
         __syncthreads();
@@ -715,11 +715,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
                         const int thi = (k == lp || tlo + span - 1 >= tlast) ? tlast : tlo + span - 1;
                         const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
-                        for (int bb = b1; bb <= b2; bb++) {
-                            const int kb = key * bk_nb + bb;
+                        for (int bb = b1; bb <= b2; bb++) {  // bucket-major: row bb, entry key + 1 (entry 0 of a row stays 0)
+                            const int kb = bb * (K + 1) + key + 1;
                             atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                         }
-                        atomicAdd(&csr[key], b2 - b1 + 1);
                     }
                 }
             }
@@ -744,7 +743,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         OBS_STAMP(3);
         // exclusive scan over the keys: per-thread chunk sums, wave-0 scan of the partial sums, rescan.  With the second
         // index both counts share the scan, 16 bits each (the launcher guarantees totals below 65536).
-        if (!reuse) {
+        const bool bk_major = bk && !bk_lds;   // large maps: the items laid out bucket-major (see the fill)
+        if (!reuse && !bk_major) {
             const int chunk = (K + 1 + nt - 1) / nt;
             const int lo = min(tid * chunk, K + 1), hi = min(lo + chunk, K + 1);
             int sum = 0;
@@ -785,13 +785,65 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 if (hi == K + 1 && lo < hi) misc[2] = run;                                      // total number of items
             }
         }
+        if (bk_major) {
+            // Per (time bucket, key) counts -> the start of the key's items inside the bucket (16 bits, relative to the bucket's start;
+            // the starts of the buckets: misc[12 ..]); one exclusive scan over the bk_nb rows of K + 1 entries.
+            uint16_t *c16 = reinterpret_cast<uint16_t *>(bkc);
+            const int K1 = K + 1, n = K1 * bk_nb;
+            {   // what one query can scan: a key's items of two neighbouring buckets
+                int most = 0;
+                for (int key = tid; key < K; key += nt) {
+                    int prev = 0;
+                    for (int bb = 0; bb < bk_nb; bb++) { const int c = c16[bb * K1 + key + 1]; most = max(most, prev + c); prev = c; }
+                }
+                if (most > CF_DIRECT) misc[11] = 1;
+            }
+            const int chunk = (n + nt - 1) / nt;
+            const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+            int sum = 0;
+            for (int k = lo; k < hi; k++) sum += c16[k];
+            partial[tid] = sum;
+            __syncthreads();
+            if (wave == 0) {
+                constexpr int PER = OBS_NT / 64;
+                const int per = nt >> 6;
+                int loc[PER], tot = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { loc[q] = q < per ? partial[lane * per + q] : 0; tot += loc[q]; }
+                int incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+                int run = incl - tot;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { if (q < per) partial[lane * per + q] = run; run += loc[q]; }
+            }
+            __syncthreads();
+            {   // starts of the buckets (a lane's range crosses at most a few row starts)
+                int run = partial[tid];
+                for (int k = lo; k < hi; k++) {
+                    if (k % K1 == 0) misc[12 + k / K1] = run;
+                    run += c16[k];
+                }
+                if (hi == n && lo < hi) misc[2] = run;   // total number of items
+            }
+            __syncthreads();
+            {
+                int run = partial[tid], row = lo / K1, rbase = lo < n ? misc[12 + row] : 0, next = (row + 1) * K1;
+                for (int k = lo; k < hi; k++) {
+                    if (k == next) { row++; rbase = misc[12 + row]; next += K1; }
+                    const int c = c16[k];
+                    c16[k] = (uint16_t)(run - rbase);
+                    run += c;
+                }
+            }
+        }
         __syncthreads();
         if (reuse) {  // stage 1 built this index
             csr = csr2; X.csr_end = csr2; X.items_lds = items2;
             X.tmask = P.use_tmask ? tmaskb : nullptr;
             if (!X.tmask) { X.wl_occ_cap = wl_entries; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
-        if (bk) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
+        if (bk_lds) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
             for (int key = tid; key < K; key += nt) {
                 uint32_t *w4 = bkc + key * (bk_w / 2);
                 uint32_t run = 0, prev = 0, most = 0;  // most: the longest run of three consecutive buckets (what one query can scan)
@@ -836,8 +888,86 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 pfv[q] = pth[k]; pfn[q] = pth[min(k + 1, lpn)]; pfp[q] = pth[max(k - 1, 0)];
             }
         };
-        prefetch(wave);
-        for (int i = wave; !reuse && i < A; i += (nt >> 6)) {
+        if (bk_major) {
+            // Large maps: the items go to HBM scratch, hundreds of thousands of scattered 4-byte stores per env.  Laid out and EMITTED
+            // bucket-major -- all items of time bucket 0 (by key), then bucket 1, ... -- the lines a CU has open at a time are one
+            // bucket's share of its items (65 KB at cfg5), which stays in the L2 until the lines are full; key-major the 0.5 MB of an
+            // env did not, and every 4-byte store left the L2 as a 32-byte write.  The waypoints of an agent whose interval touches a
+            // bucket are a contiguous piece of its path (at most 64 / tpc + 2; the last indexed waypoint stays until the end of the
+            // horizon): per bucket the pieces of all agents are laid end to end (a prefix over the agents in the scan scratch) and
+            // split evenly over the lanes of the workgroup; the waypoints of a lane's NEXT item are requested before this one is emitted.
+            const int K1 = K + 1, tlast = X.Tn - 1;
+            uint16_t *pre16 = reinterpret_cast<uint16_t *>(partial);       // [A + 1] start of agent i's piece among the bucket's items
+            uint16_t *klo16 = pre16 + ((A + 2) & ~1);                        // [A] first waypoint of the piece
+            for (int bb = 0; bb < bk_nb; bb++) {
+                const int t0 = bb << bk_shift, t1 = bb == bk_nb - 1 ? tlast : min(t0 + (1 << bk_shift) - 1, tlast);
+                if (t0 > tlast) break;
+                const int gbase = misc[12 + bb];
+                for (int ia = tid; ia < A; ia += nt) {
+                    const int lp = a_lp[ia], tpc = a_tpc[ia];
+                    const int k_lo = min((t0 + tpc - 1) / tpc, lp);              // first waypoint still occupied at t0 (thi = k * tpc)
+                    const int k_hi = min(t1 >= 1 ? (t1 - 1) / tpc + 1 : 0, lp);  // last waypoint entered by t1 (tlo = (k - 1) * tpc + 1)
+                    klo16[ia] = (uint16_t)k_lo;
+                    pre16[ia + 1] = (uint16_t)(k_hi - k_lo + 1);
+                }
+                if (tid == 0) pre16[0] = 0;
+                __syncthreads();
+                if (wave == 0) {  // inclusive prefix over the agents' piece lengths (A <= 992: at most 16 a lane)
+                    const int per = (A + 63) >> 6, a_lo = min(lane * per, A), a_hi = min(a_lo + per, A);
+                    int sum = 0;
+                    for (int ia = a_lo; ia < a_hi; ia++) sum += pre16[ia + 1];
+                    int incl = sum;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+                    int run = incl - sum;
+                    for (int ia = a_lo; ia < a_hi; ia++) { run += pre16[ia + 1]; pre16[ia + 1] = (uint16_t)run; }
+                }
+                __syncthreads();
+                const int total = pre16[A];
+                // item t of the bucket -> (agent, waypoint): the last agent whose piece starts at or before t
+                uint32_t nv = 0, nn = 0, np = 0;
+                int n_i = 0, n_k = 0;
+                auto request = [&](int t) __attribute__((always_inline)) {
+                    if (t >= total) return;
+                    int lo_a = 0, hi_a = A - 1;
+                    while (lo_a < hi_a) {
+                        const int mid = (lo_a + hi_a + 1) >> 1;
+                        if ((int)pre16[mid] <= t) lo_a = mid; else hi_a = mid - 1;
+                    }
+                    n_i = lo_a;
+                    n_k = (int)klo16[lo_a] + (t - (int)pre16[lo_a]);
+                    const uint16_t *pth = S.path + ((size_t)b * A + lo_a) * S.pred_cap;
+                    const int lp = a_lp[lo_a];
+                    nv = pth[n_k]; nn = pth[min(n_k + 1, lp)]; np = pth[max(n_k - 1, 0)];
+                };
+                request(tid);
+                for (int t = tid; t < total; t += nt) {
+                    const int i = n_i, k = n_k;
+                    const uint32_t w = nv, wnx = nn, wpv = np;
+                    request(t + nt);
+                    const int lp = a_lp[i], tpc = a_tpc[i];
+                    const int tlo = k == 0 ? 0 : (k - 1) * tpc + 1, span = k == 0 ? 1 : tpc;
+                    const bool to_end = k == lp || tlo + span - 1 >= tlast;
+                    const int thi = to_end ? tlast : tlo + span - 1;
+                    const int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
+                    if (bb < b1 || bb > b2) continue;
+                    const int key = key_of(X, (int)(w >> 2));
+                    if (X.tmask && bb == b1) {  // time-mask buckets this item covers (once per item)
+                        const int m1 = min(tlo >> X.tshift, 63), m2 = min(thi >> X.tshift, 63);
+                        atomicOr(&tmask[key], ((2ull << m2) - 1ull) & ~((1ull << m1) - 1ull));
+                    }
+                    const uint32_t dnext = k < lp ? (wnx & 3u) : (w & 3u), dprev = k > 0 ? (wpv & 3u) : (w & 3u);
+                    const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
+                                          ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                    const int kb = bb * K1 + key + 1;
+                    const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
+                    csr_items[gbase + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
+                }
+                __syncthreads();   // (the next bucket's prefix goes to the same scratch)
+            }
+        }
+        prefetch(bk_major ? A : wave);
+        for (int i = wave; !reuse && !bk_major && i < A; i += (nt >> 6)) {
             const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
@@ -920,15 +1050,17 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (STAGE != 2 && tid == 0) P.dbg[(size_t)b * 64 + 57] = (long long)wall_clock64();   // items filled
 #endif
-        if (bk) {  // the list of key k is [csr[k], csr[k + 1]) now; the bucket ends of every key stay in LDS or go to HBM (the node
-                   // tables take their LDS back)
-            X.csr_end = csr + 1;
+        if (bk) {  // LDS-resident offsets: the list of key k is [csr[k], csr[k + 1]) now and its bucket ends stay in LDS; bucket-major
+                   // (large maps): the ends of the keys inside every bucket go to HBM (the node tables take their LDS back)
             if (bk_lds) {
+                X.csr_end = csr + 1;
                 X.bk_rel_lds = reinterpret_cast<const uint16_t *>(bkc);
             } else {
-                uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB);
-                for (int k = tid; k < K * bk_w / 2; k += nt) g[k] = bkc[k];
-                X.bk_rel = S.bk_rel + (size_t)b * d.Rcap * OBS_BK_NB;
+                uint32_t *g = reinterpret_cast<uint32_t *>(S.bk_rel + (size_t)b * (d.Rcap + 1) * OBS_BK_NB);
+                for (int k = tid; k < ((K + 1) * bk_nb + 1) / 2; k += nt) g[k] = bkc[k];
+                X.bk_rel = S.bk_rel + (size_t)b * (d.Rcap + 1) * OBS_BK_NB;
+                X.bk_base = misc + 12;
+                X.bk_k1 = K + 1;
                 __syncthreads();
             }
         }

@@ -32,8 +32,10 @@ struct ObsCtx {
     const uint32_t *items_glb;    // ... else in HBM scratch (two members so that each keeps a static address space)
     const uint16_t *bk_rel_lds;   // the same table in LDS (small maps: finer buckets, see obs_body); at most one of the two is set
     int bk_nb, bk_shift;          // number of time buckets of a list and log2 of their width in steps
-    const uint16_t *bk_rel;       // HBM [K * bk_nb]: end of time bucket b inside key k's list, relative to the list's start;
-                                  // nullptr = lists not bucketed
+    const uint16_t *bk_rel;       // HBM [bk_nb][bk_k1] (large maps: the items are laid out BUCKET-major): row b, entry k + 1 = end of key
+                                  // k's items inside time bucket b, relative to the bucket's start bk_base[b]; entry 0 of a row = 0
+    const int *bk_base;           // LDS [bk_nb]: start of every time bucket's items
+    int bk_k1;                    // entries of a row of bk_rel (keys + 1)
     int Tn;                       // number of predicted time entries (0 = no predictor)
     const uint16_t *dm;           // env base [U][SS] distance map (LDS copy when TAB_LDS, else HBM)
     const uint4 *seg;             // env base [S] static branch-walk table (LDS copy when TAB_LDS, else HBM)
@@ -103,8 +105,8 @@ __device__ __forceinline__ ListRange list_range(const ObsCtx &X, bool cu, int r,
         R.n1 = R.n = X.u_csr_end[key] - R.lo;
         return R;
     }
-    const int base = key > 0 ? X.csr_end[key - 1] : 0;
     if (X.bk_rel_lds) {  // (two call sites: each table keeps its address space)
+        const int base = key > 0 ? X.csr_end[key - 1] : 0;
         const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
         // per key: bk_nb time buckets, the to-the-end bucket, and a mask of the time buckets in which such an item starts
         const uint16_t *rel = X.bk_rel_lds + key * (X.bk_nb + 2);
@@ -117,12 +119,20 @@ __device__ __forceinline__ ListRange list_range(const ObsCtx &X, bool cu, int r,
             R.n += (int)rel[X.bk_nb] - oe;
         }
     } else if (X.bk_rel) {
+        // bucket-major items: the key's items of the one or two time buckets the three queried times fall in -- two pieces
         const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
-        const uint16_t *rel = X.bk_rel + (size_t)key * X.bk_nb;
-        const int o1 = b1 > 0 ? (int)rel[b1 - 1] : 0;
-        R.lo = base + o1;
-        R.n1 = R.n = (int)rel[b2] - o1;
+        const uint16_t *r1 = X.bk_rel + b1 * X.bk_k1 + key;
+        const int s1 = (int)r1[0], e1 = (int)r1[1];
+        R.lo = X.bk_base[b1] + s1;
+        R.n1 = R.n = e1 - s1;
+        if (b2 != b1) {
+            const uint16_t *r2 = X.bk_rel + b2 * X.bk_k1 + key;
+            const int s2 = (int)r2[0], e2 = (int)r2[1];
+            R.lo2 = X.bk_base[b2] + s2;
+            R.n += e2 - s2;
+        }
     } else {
+        const int base = key > 0 ? X.csr_end[key - 1] : 0;
         R.lo = base;
         R.n1 = R.n = X.csr_end[key] - base;
     }

@@ -383,7 +383,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
             const int team_id = wave * 2 + grp;
             if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; team_meta[256 + team_id] = first; }
         }
-        wg_pass_b<1, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, TW, team_meta);
+        wg_pass_b<1, CAP, ITL, NoLateWork, !ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, TW, team_meta);   // (items in HBM: a query may be two pieces)
         TREE_STAMP(X, 7);
         cutils_rows_orders(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
         team_sync();
