@@ -131,6 +131,40 @@ def test_distinct_generated_maps_in_one_batch_match_the_oracle():
     env.check()
 
 
+def test_two_hundred_agents_on_a_tall_map_match_the_oracle():
+    """hundreds of agents on a map taller than wide: the prediction keys collide (flatland_cutils keys its maps by col * W + row,
+    tool.h:391-398) AND the items live in HBM scratch, laid out bucket-major with two-piece conflict queries (the launch
+    configuration of cfg5) -- the committed goldens have tall maps of three agents and large maps that are square"""
+    from flatland_marl_amd import generators as gen, synth
+    from oracle import orc
+    rg = gen.sparse_rail_generator(max_num_cities=8, grid_mode=False, max_rails_between_cities=2, max_rail_pairs_in_city=2)
+    lg = gen.sparse_line_generator({1.0: 0.25, 0.5: 0.25, 1.0 / 3.0: 0.25, 0.25: 0.25})
+    envs = []
+    for seed in (7, 8):
+        st = gen.np_random(seed).get_state()
+        envs.append(gen.generate_env(40, 76, 200, rg, lg, st[1], st[2], 1.0 / 200, 20, 50))
+    assert envs[0]["grid"].shape == (76, 40)
+    env = _env(envs)
+    oracles = [orc.OracleEnv(e) for e in envs]
+    keys = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("node_order", "node_order"),
+            ("edge_order", "edge_order"), ("valid_actions", "valid"))
+    for t in range(64):
+        env.step_synth(11, 0, 1, auto_reset=False)
+        st, _ = env.state()
+        for b, o in enumerate(oracles):
+            o.step(synth.forward_biased_actions(11, b, t, env.A))
+            np.testing.assert_array_equal(st[b], o.state(), err_msg=f"env {b} step {t}")
+        got, tree = env.obs_both(3, 30) if t % 2 else (env.obs_cutils(), env.obs_tree(3, 30))
+        for b, o in enumerate(oracles):
+            exp = o.obs_cutils(31, 500)          # (every step: keeps the oracle's sticky deadlock flags in step)
+            if t % 4 < 2:
+                for g, e in keys:
+                    np.testing.assert_array_equal(got[g].cpu().numpy()[b], exp[e], err_msg=f"env {b} step {t} {g}")
+                np.testing.assert_array_equal(tree.cpu().numpy()[b], o.obs_pytree(3, 30), err_msg=f"env {b} step {t} tree")
+    assert (env.state()[0][:, :, 0] >= 0).sum() > 10      # trains are on the map
+    env.check()
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: the parent starts two ranks before any GPU call and relays rank 0's line
     (here both ranks share the one GPU of the box: FL_DIST_BACKEND=gloo)"""
