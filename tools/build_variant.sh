@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # A/B builds of the C-ABI library beside the in-tree one:  tools/build_variant.sh NAME [extra hipcc flags...]
-#   -> build_ab/libfl_NAME.so (objects in build_ab/obj_NAME; build_ab/ is git-ignored and is removed before a round ends)
+#   -> build_ab/libfl_NAME.so (objects in build_ab/obj_NAME; build_ab/ is git-ignored, removed before a round ends and listed in
+#      .gpurunignore then: take that line out again to ship A/B libraries to the GPU box)
 #   tools/build_variant.sh timing -DFL_OBS_TIMING          (phase clocks: tools/obs_phase_clocks.py)
 #   tools/build_variant.sh base                            (a copy of the current sources as the baseline of an A/B run)
 set -euo pipefail
