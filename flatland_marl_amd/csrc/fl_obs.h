@@ -19,6 +19,7 @@ struct FlObsScratch {
     uint32_t *cost;    // [B] clock ticks of the env's previous observation launch (its workgroup writes them)
     int *order;        // [B] env of workgroup k, longest first (k_env_order), or null: env k (batches of at most one env per CU)
     int n_cu;          // CUs of the device
+    unsigned order_age;  // ordered launches so far: the order is recomputed every OBS_ORDER_EVERY-th (host side)
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);
@@ -31,5 +32,5 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
 // more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
-FlObsScratch fl_obs_env_order(const FlObsScratch &o, const FlDev &d, hipStream_t s);
+FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s);
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[10]);  // diagnostic

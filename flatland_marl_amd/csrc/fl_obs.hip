@@ -33,6 +33,7 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return FL_ERR_HIP;
     o.n_cu = n_cu;
+    o.order_age = 0;
     return FL_OK;
 }
 
@@ -70,11 +71,14 @@ __global__ __launch_bounds__(1024) void k_env_order(int B, const uint32_t *__res
     for (int b = tid; b < B; b += 1024) order[atomicAdd(&hist[1023u - (unsigned int)((unsigned long long)cost[b] * 1023ull / top)], 1u)] = b;
 }
 
-FlObsScratch fl_obs_env_order(const FlObsScratch &o, const FlDev &d, hipStream_t s) {
+#ifndef OBS_ORDER_EVERY
+#define OBS_ORDER_EVERY 4   // what an env takes changes slowly from step to step: the order of every fourth launch serves the next three
+#endif
+FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s) {
     static const bool off = getenv("FL_OBS_NO_ORDER") != nullptr;   // diagnostic: workgroup k builds env k
     FlObsScratch u = o;
     if (off || d.B <= o.n_cu) { u.order = nullptr; return u; }
-    hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, s, d.B, o.cost, o.order);
+    if (o.order_age++ % OBS_ORDER_EVERY == 0) hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, s, d.B, o.cost, o.order);
     return u;
 }
 
