@@ -28,9 +28,10 @@
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 #endif
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
-// Large maps (items in HBM, hundreds of agents): inside a key's list the items are grouped by bucket of 64 time steps, an
-// item sits in every bucket its interval touches, and a conflict query scans only the buckets its three time steps fall in
-// (an eighth of a busy cell's list instead of all of it).
+// Large maps (items in HBM, hundreds of agents): the items are grouped by bucket of 64 time steps and laid out BUCKET-major (all
+// items of bucket 0 by key, then bucket 1, ...: a bucket's share of an env's items stays in the L2 while it is written), an item
+// sits in every bucket its interval touches, and a conflict query reads the key's items of the one or two buckets its three time
+// steps fall in (an eighth of a busy cell's list instead of all of it).
 #define OBS_BK_NB 8
 #define OBS_BK_SHIFT 6
 // Small maps (index in LDS): sixteen buckets of 32 steps, their offsets in an LDS array of their own -- a query scans the
