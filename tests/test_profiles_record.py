@@ -1,0 +1,48 @@
+"""CPU: the profiles of record under profiles/ are complete and consistent with each other -- every workload has its rocprofv3
+kernel summary, its bench line and its PMC traffic entry from ONE build (the same kernel-source stamp), and the default bench
+line carries what the measurement contract asks for.  (Whether the stamp still matches the sources in the tree is for bench.py to
+say at run time: `roofline.traffic` is null when it does not.)"""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3")
+TAG = "r03"
+
+
+def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
+    traffic = json.load(open(os.path.join(P, "pmc_traffic.json")))
+    stamps = set()
+    for w in WORKLOADS:
+        rows = list(csv.DictReader(open(os.path.join(P, f"{TAG}_{w}_kernel_stats.csv"))))
+        obs = [r for r in rows if "k_obs" in r["Name"]]
+        assert len(obs) == 1 and int(obs[0]["Calls"]) >= 100 and float(obs[0]["AverageNs"]) > 0
+        line = json.load(open(os.path.join(P, f"{TAG}_{w}_bench.json")))
+        assert line["metric"] == "agent_steps_per_sec" or "agent" in line["metric"]
+        assert line["roofline"]["algorithmic_bytes_per_launch"] > 0
+        # the event-timed launch of the bench line and the trace average of the same run agree (events add a few microseconds)
+        ev_ms, tr_ms = line["roofline"]["kernel_ms"], float(obs[0]["AverageNs"]) / 1e6
+        assert 0.9 * tr_ms < ev_ms < 1.15 * tr_ms + 0.005, (w, ev_ms, tr_ms)
+        t = traffic[w]["k_obs<cutils+tree>"]
+        assert t["tag"] == TAG and t["fetch_size_kib"] > 0 and t["write_size_kib"] > 0
+        # the kernel writes at least its outputs
+        assert t["write_size_kib"] * 1024 > 0.9 * line["roofline"]["algorithmic_bytes_per_launch"]
+        stamps.add(t["kernel_source_sha"])
+    assert len(stamps) == 1, stamps
+
+
+def test_default_bench_line_of_record_keeps_the_contract():
+    d = json.load(open(os.path.join(P, f"{TAG}_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("cfg2") and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is not None and r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["cpu_model"] and c["sample"]
+    # whole-job throughput and time per step belong together: B * A agent-steps per step
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 256 * 20) < 1.0
