@@ -20,15 +20,28 @@ def _malfunction_parameters(env):
     return float(mfp.malfunction_rate), int(mfp.min_duration), int(mfp.max_duration)
 
 
-def from_reference_env(env):
-    """static description (dict of numpy arrays, keys STATIC_KEYS) of a reference RailEnv after reset()."""
-    st = env.np_random.get_state()
+def _rng_state_of(env, required):
+    rs = getattr(env, "np_random", None)
+    if rs is None or not hasattr(rs, "get_state"):
+        if required:
+            raise ValueError("env.np_random must be a numpy RandomState (MT19937)")
+        return np.zeros(624, dtype=np.uint32), 624       # observation-only use: the stream is never drawn from
+    st = rs.get_state()
     if st[0] != "MT19937" or st[3] != 0:
         raise ValueError("env.np_random must be a numpy RandomState (MT19937) without a cached gaussian")
+    return np.asarray(st[1], dtype=np.uint32), int(st[2])
+
+
+def static_of_env(env, require_rng=False):
+    """static description (dict of numpy arrays, keys STATIC_KEYS) of any env object that has what flatland_cutils reads from
+    it at reset() (loader.cpp:207-219, 329-333) and per agent (loader.cpp:19-73): `rail.grid`, `_max_episode_steps`, `agents`
+    with initial_position / initial_direction / target / speed_counter.speed / earliest_departure / latest_arrival.  The
+    malfunction parameters and the MT19937 state matter to step() only; without require_rng an env that has none is accepted."""
     agents = env.agents
     rate, mn, mx = _malfunction_parameters(env)
     if any(a.initial_position is None or a.target is None for a in agents):
         raise ValueError("the env has to be reset() first (agents without initial position / target)")
+    key, pos = _rng_state_of(env, require_rng)
     return dict(
         grid=np.asarray(env.rail.grid, dtype=np.uint16),
         init_pos=np.array([a.initial_position for a in agents], dtype=np.int32).reshape(len(agents), 2),
@@ -39,8 +52,50 @@ def from_reference_env(env):
         latest=np.array([a.latest_arrival for a in agents], dtype=np.int32),
         T=np.int32(env._max_episode_steps),
         malf_rate=np.float64(rate), malf_min=np.int32(mn), malf_max=np.int32(mx),
-        mt_key=np.asarray(st[1], dtype=np.uint32), mt_pos=np.int32(st[2]),
+        mt_key=key, mt_pos=np.int32(pos),
     )
+
+
+def from_reference_env(env):
+    """static description of a reference RailEnv after reset(), MT19937 state of `env.np_random` included (step() needs it)."""
+    return static_of_env(env, require_rng=True)
+
+
+_STATE_BY_NAME = {"WAITING": 0, "READY_TO_DEPART": 1, "MALFUNCTION_OFF_MAP": 2, "MOVING": 3, "STOPPED": 4, "MALFUNCTION": 5, "DONE": 6}
+
+
+def _state_code(s):
+    """TrainState as an int; flatland_cutils parses str(agent.state) = "TrainState.MOVING" (loader.cpp:10, tool.h:219-228)"""
+    try:
+        return int(s)
+    except (TypeError, ValueError):
+        return _STATE_BY_NAME[str(s).rsplit(".", 1)[-1]]
+
+
+def dynamic_state_of_env(env):
+    """(state int32[A, 12], aux int32[A, 4], elapsed) of any env object mid-episode, reading exactly what Agent::Agent reads per
+    call (loader.cpp:8-73) -- attributes flatland_cutils does not read (saved action, previous state, dones) are optional."""
+    A = len(env.agents)
+    state = np.zeros((A, 12), dtype=np.int32)
+    aux = np.zeros((A, 4), dtype=np.int32)
+    dones = getattr(env, "dones", None)
+    for i, a in enumerate(env.agents):
+        r, c = a.position if a.position is not None else (-1, -1)
+        orow, ocol = a.old_position if a.old_position is not None else (-1, -1)
+        code = _state_code(a.state)
+        saved = getattr(getattr(a, "action_saver", None), "saved_action", None)
+        mh = a.malfunction_handler
+        state[i] = (r, c, int(a.direction), code, int(mh.malfunction_down_counter), int(mh.num_malfunctions),
+                    int(a.speed_counter.counter), 0 if saved is None else int(saved),
+                    -1 if a.arrival_time is None else int(a.arrival_time), orow, ocol,
+                    -1 if a.old_direction is None else int(a.old_direction))
+        sm = getattr(a, "state_machine", None)
+        prev = getattr(sm, "previous_state", None)
+        sig = getattr(getattr(sm, "st_signals", None), "in_malfunction", None)
+        done = dones[i] if dones is not None and i in dones else code == 6
+        aux[i] = (-1 if prev is None else _state_code(prev), int(bool(mh.malfunction_down_counter > 0 if sig is None else sig)), 0,
+                  int(bool(done)))
+    return state, aux, int(env._elapsed_steps)
 
 
 def dynamic_state_of_reference_env(env):

@@ -7,7 +7,9 @@ Nothing of the reference is copied: the fixtures hold inputs (grid, agents, MT19
 state after reset, action streams) and expected outputs (per-step agent state, rewards,
 dones, distance map, cutils observation tensors, upstream TreeObs tensors).
 
-Usage:  python oracle/refharness/capture_golden.py [--only NAME]
+Usage:  python oracle/refharness/capture_golden.py [--only NAME ...]
+        python oracle/refharness/capture_golden.py --check [NAME ...]     re-capture into a temporary directory and compare
+                                                                          every array with the committed fixture (the pin, verified)
 """
 import argparse
 import os
@@ -451,10 +453,56 @@ for lv in range(1, 4):
     JOBS[f"base_cfg3_L{lv}"] = (lambda lv=lv: static_only(f"base_cfg3_L{lv}", "Test_4", f"Level_{lv}"))
 
 
+def check(names=None, verbose=True):
+    """Re-run the capture jobs `names` (default: all) on the real reference into a temporary directory and compare every array,
+    key by key and bit for bit, with the committed fixtures under tests/golden/.  Returns the list of differences (empty = the
+    committed fixtures ARE what the reference produces here)."""
+    import glob
+    import shutil
+    import tempfile
+    global GOLD
+    committed, tmp = GOLD, tempfile.mkdtemp(prefix="golden_check_")
+    problems = []
+    try:
+        GOLD = tmp
+        for name, job in JOBS.items():
+            if names and name not in names:
+                continue
+            job()
+        for path in sorted(glob.glob(os.path.join(tmp, "*.npz"))):
+            fn = os.path.basename(path)
+            ref_path = os.path.join(committed, fn)
+            if not os.path.exists(ref_path):
+                problems.append(f"{fn}: no committed fixture")
+                continue
+            new, old = np.load(path), np.load(ref_path)
+            for k in sorted(set(new.files) | set(old.files)):
+                if k not in old.files:
+                    problems.append(f"{fn}: key {k} is missing from the committed fixture (stale: re-capture it)")
+                elif k not in new.files:
+                    problems.append(f"{fn}: committed key {k} is no longer captured")
+                elif new[k].dtype != old[k].dtype or new[k].shape != old[k].shape or new[k].tobytes() != old[k].tobytes():
+                    problems.append(f"{fn}: {k} differs from the reference's output")
+            if verbose:
+                print(f"checked {fn}: {len(new.files)} arrays")
+    finally:
+        GOLD = committed
+        shutil.rmtree(tmp, ignore_errors=True)
+    return problems
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--check", nargs="*", default=None, metavar="NAME",
+                    help="re-capture (all jobs, or the named ones) into a temporary directory and diff against tests/golden/")
     args = ap.parse_args()
+    if args.check is not None:
+        bad = check(args.check or None)
+        for line in bad:
+            print("MISMATCH", line)
+        print("golden check:", "OK" if not bad else f"{len(bad)} difference(s)")
+        sys.exit(1 if bad else 0)
     os.makedirs(GOLD, exist_ok=True)
     for name, job in JOBS.items():
         if args.only and name not in args.only:

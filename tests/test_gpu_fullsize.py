@@ -1,5 +1,6 @@
-"""GPU, BASELINE.json full sizes of the depth-3 configs: cfg3 (1024 envs x 35x30 x 80 agents, depth-3 tree) and the per-GPU
-shard of cfg5 (256 envs x 150x150 x 400 agents, depth-3 tree + masked distance-map rebuild of the envs that just reset) --
+"""GPU, BASELINE.json full sizes: cfg3 (1024 envs x 35x30 x 80 agents, depth-3 tree), the per-GPU shard of cfg4 (512 envs x
+60x60 x 80 agents, depth-2 tree: HBM work lists + longest-first workgroup order) and the per-GPU shard of cfg5 (256 envs x
+150x150 x 400 agents, depth-3 tree + masked distance-map rebuild of the envs that just reset) --
 the batch sizes at which the per-env HBM scratch strides (predicted paths, prediction items, bucket offsets, work lists) are
 actually exercised.  Size-independent properties: replica independence (an env inside the full batch == the same env stepped
 alone, observations included) on picked replicas, and two replicas shadowed by the CPU oracle step by step."""
@@ -19,12 +20,15 @@ def _same(got, exp, msg):
         raise AssertionError(f"{msg}: {len(bad)} mismatches, first {bad[0].tolist()}: {got[tuple(bad[0])]} vs {exp[tuple(bad[0])]}")
 
 
-@pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct", [
+@pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct,depth", [
     # (replicas with b % 7 == 3 have short episodes: 3, 766, 1018 / 3, 255 restart inside the window)
-    ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10),
-    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2),
+    ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10, 3),
+    # the per-GPU shard of cfg4 as the bench runs it: rounds of 32 agents, pass-B work lists in HBM scratch (per-env stride) AND
+    # the longest-first workgroup order of k_env_order (more envs than CUs)
+    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2),
+    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3),
 ])
-def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct):
+def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct, depth):
     from flatland_marl_amd import synth, workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
     from oracle import orc
@@ -42,7 +46,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
     tc = {b: 0 for b in shadow}
     for t in range(steps):
         rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=True)
-        o, tree = env.obs_both(3, 30)
+        o, tree = env.obs_both(depth, 30)
         if rebuild:
             env.rebuild_distance_maps(env.done_all)
         st, el = env.state()
@@ -51,7 +55,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         tr = tree.cpu().numpy() if check_obs else None
         for b, s_env in solo.items():
             s_rew, _, s_da = s_env.step_synth(seed, b, 0, auto_reset=True)
-            s_o, s_tree = s_env.obs_both(3, 30)
+            s_o, s_tree = s_env.obs_both(depth, 30)
             if rebuild:
                 s_env.rebuild_distance_maps(s_env.done_all)
             _same(s_env.state()[0][0], st[b], f"replica {b} step {t} state")
@@ -59,7 +63,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
             if check_obs:
                 for key, _ in CUTILS:
                     _same(s_o[key].cpu().numpy()[0], ob[key][b], f"replica {b} step {t} {key}")
-                _same(s_tree.cpu().numpy()[0], tr[b], f"replica {b} step {t} depth-3 tree")
+                _same(s_tree.cpu().numpy()[0], tr[b], f"replica {b} step {t} depth-{depth} tree")
         for b, orc_env in oracles.items():
             r_o, d_o, da = orc_env.step(synth.uniform_actions(seed, b, tc[b], A))
             tc[b] += 1
@@ -69,7 +73,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
             if check_obs:
                 for key, okey in CUTILS:
                     _same(ob[key][b], exp[okey], f"oracle replica {b} step {t} {key}")
-                _same(tr[b], orc_env.obs_pytree(3, 30), f"oracle replica {b} step {t} depth-3 tree")
+                _same(tr[b], orc_env.obs_pytree(depth, 30), f"oracle replica {b} step {t} depth-{depth} tree")
             if da:
                 key, pos = orc_env.get_rng()
                 oracles[b] = orc.OracleEnv(envs[b])
@@ -80,3 +84,41 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
     assert m[2] == B * A * steps and m[3] >= B // 7       # the short episodes ended (and restarted) inside the window
     for s_env in solo.values():
         s_env.check()
+
+
+def _cfg4_digest(steps=24):
+    """sha256 over the state, rewards and both observations of every step of the full cfg4 shard"""
+    import hashlib
+    from flatland_marl_amd import workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    envs, seed = wl.make_envs("cfg4", B=512, distinct=4)
+    env = BatchedRailEnv(envs)
+    h = hashlib.sha256()
+    for t in range(steps):
+        rew, done, done_all = env.step_synth(seed, 0, 2, auto_reset=True)      # dense traffic: envs of very different cost
+        o, tree = env.obs_both(2, 30)
+        h.update(env.state()[0].tobytes())
+        h.update(rew.cpu().numpy().tobytes())
+        for k in sorted(o):
+            h.update(o[k].cpu().numpy().tobytes())
+        h.update(tree.cpu().numpy().tobytes())
+    env.check()
+    return h.hexdigest()
+
+
+def test_workgroup_order_does_not_change_the_results_at_cfg4():
+    """k_env_order hands the envs to the workgroups longest first (B > CUs); FL_OBS_NO_ORDER (read once per process, hence the
+    child) makes workgroup k build env k.  Same bytes either way."""
+    import os
+    import subprocess
+    import sys
+    from tests import util
+    child = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, FL_OBS_NO_ORDER="1", PYTHONPATH=util.ROOT),
+                           capture_output=True, text=True, timeout=900)
+    assert child.returncode == 0, child.stderr[-2000:]
+    plain = [ln for ln in child.stdout.splitlines() if ln.startswith("DIGEST ")][-1].split()[1]
+    assert _cfg4_digest() == plain
+
+
+if __name__ == "__main__":
+    print("DIGEST", _cfg4_digest())

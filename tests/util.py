@@ -43,3 +43,67 @@ def actions_of(fx):
         a = a.copy()
         a[np.asarray(fx["action_required"]) == 0] = 255
     return a
+
+
+# ---- a duck-typed env that replays a golden episode's per-step agent states: the attribute surface flatland_cutils reads from a
+# caller-owned env (flatland_cutils/src/loader.cpp:8-120, 207-219, 329-333) and nothing else of flatland
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+STATE_STR = ("TrainState.WAITING", "TrainState.READY_TO_DEPART", "TrainState.MALFUNCTION_OFF_MAP", "TrainState.MOVING",
+             "TrainState.STOPPED", "TrainState.MALFUNCTION", "TrainState.DONE")
+
+
+class DuckEnv:
+    def __init__(self, fx, string_states=False):
+        self.fx = fx
+        self.string_states = string_states
+        grid = np.array(fx["grid"], dtype=np.uint16)
+        self.rail = _NS(grid=grid)
+        self.height, self.width = grid.shape
+        self._max_episode_steps = int(fx["T"])
+        A = len(fx["init_dir"])
+        self.agents = []
+        for i in range(A):
+            speed = float(fx["speed"][i])
+            self.agents.append(_NS(
+                handle=i, initial_position=tuple(int(v) for v in fx["init_pos"][i]), initial_direction=int(fx["init_dir"][i]),
+                target=tuple(int(v) for v in fx["target"][i]), earliest_departure=int(fx["earliest"][i]),
+                latest_arrival=int(fx["latest"][i]), moving=False,
+                speed_counter=_NS(speed=speed, max_count=int(1 / speed) - 1, counter=0),
+                malfunction_handler=_NS(malfunction_down_counter=0, num_malfunctions=0),
+                state_machine=_NS(st_signals=_NS(in_malfunction=False))))
+        self.goto(0)
+
+    def get_num_agents(self):
+        return len(self.agents)
+
+    def goto(self, T):
+        """the agents as they are after T steps (T = 0: after reset())"""
+        fx = self.fx
+        if T == 0:
+            # snap0: the agents after reset(), one row per field in the alphabetical order of the field names
+            order = sorted(STATE_NAMES)
+            rows = np.stack([fx["snap0"][order.index(k)] for k in STATE_NAMES], axis=1) if "snap0" in fx.files else None
+        else:
+            rows = golden_state(fx, T - 1)
+        malf_before = fx["s_malf"][T - 2] if T >= 2 else np.zeros(len(self.agents), dtype=np.int32)
+        for i, a in enumerate(self.agents):
+            if rows is None:
+                r = (-1, -1, a.initial_direction, 0, 0, 0, 0, 0, -1, -1, -1, -1)
+            else:
+                r = [int(v) for v in rows[i]]
+            a.position = None if r[0] < 0 else (r[0], r[1])
+            a.direction = r[2]
+            a.state = STATE_STR[r[3]] if self.string_states else r[3]
+            a.malfunction_handler.malfunction_down_counter = r[4]
+            a.malfunction_handler.num_malfunctions = r[5]
+            a.speed_counter.counter = r[6]
+            a.arrival_time = None if r[8] < 0 else r[8]
+            a.old_position = None if r[9] < 0 else (r[9], r[10])
+            a.old_direction = None if r[11] < 0 else r[11]
+            # st_signals.in_malfunction was evaluated before the counter ticked down (rail_env.py:369-395, 622-624)
+            a.state_machine.st_signals.in_malfunction = bool(r[4] > 0 or (T >= 1 and malf_before[i] == 1))
+        self._elapsed_steps = T
