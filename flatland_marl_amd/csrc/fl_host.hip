@@ -368,7 +368,7 @@ int fl_commit(fl_batch *h) {
         if (h->H > h->W) h->h_rkey.assign((size_t)B * Rcap, 0);
         DALLOC(d.t, B); DALLOC(d.T, B); DALLOC(d.done_all, B); DALLOC(d.mt_pos, B); DALLOC(d.mt, (size_t)B * 624);
         DALLOC(d.malf_thr, B); DALLOC(d.malf_min, B); DALLOC(d.malf_max, B); DALLOC(d.U, B); DALLOC(d.R, B); DALLOC(d.K, B);
-        DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2); DALLOC(d.score_sums, (size_t)B * 2);
+        DALLOC(d.err, B); DALLOC(d.env_list, B + 1); DALLOC(d.metrics, (size_t)B * 4); DALLOC(d.last_episode, (size_t)B * 2); DALLOC(d.score_sums, (size_t)B * 3);
         DALLOC(d.grid, B * HW); DALLOC(d.ridx, B * HW);
         DALLOC(d.rgrid, (size_t)B * Rcap); DALLOC(d.rtype, (size_t)B * Rcap); DALLOC(d.nbr, (size_t)B * Scap); DALLOC(d.snext, (size_t)B * Scap);
         d.rkey = nullptr;

@@ -80,7 +80,7 @@ struct FlDev {
     int *env_list;  // [B + 1] scratch of the table (re)builds: the envs being rebuilt, their number at [B] (k_env_list)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
     int *last_episode;   // [B][2] sum of rewards and arrived agents of the env's last finished episode
-    double *score_sums;  // [B][2] running sums over the env's finished episodes: normalized reward 1 + R / (T * A), arrived / A
+    double *score_sums;  // [B][3] running sums over the env's finished episodes: normalized reward 1 + R / (T * A), arrived / A, their number
                          // (flatland/evaluators/service.py:875-879, 900-913)
     uint32_t *grid;   // [B][H*W] per cell: transition bitmap (lo16) | bit 16 + m: the neighbour towards m is on the map and has rail (step kernel)
     uint16_t *ridx;   // [B][H*W] rail index of a cell, FL_R_NONE = no rail

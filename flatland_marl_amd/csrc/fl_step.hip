@@ -64,15 +64,16 @@ void fl_launch_metrics(const FlDev &d, long long *out4, int reset, hipStream_t s
 // sums of the evaluator's per-episode scores over the envs, in env order (one thread: a fixed order of additions)
 __global__ void k_scores(FlDev d, double *out3, int reset) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s0 = 0.0, s1 = 0.0;
-    long long ep = 0;
+    // (the episode count is the scores' OWN counter, incremented where the sums are and reset with them: a caller that resets
+    // fl_metrics and fl_scores at different times still gets sums and a count of the same window)
+    double s0 = 0.0, s1 = 0.0, ep = 0.0;
     for (int b = 0; b < d.B; b++) {
-        s0 += d.score_sums[(size_t)b * 2 + 0];
-        s1 += d.score_sums[(size_t)b * 2 + 1];
-        ep += d.metrics[(size_t)b * 4 + 3];
-        if (reset) { d.score_sums[(size_t)b * 2 + 0] = 0.0; d.score_sums[(size_t)b * 2 + 1] = 0.0; }
+        s0 += d.score_sums[(size_t)b * 3 + 0];
+        s1 += d.score_sums[(size_t)b * 3 + 1];
+        ep += d.score_sums[(size_t)b * 3 + 2];
+        if (reset) { d.score_sums[(size_t)b * 3 + 0] = 0.0; d.score_sums[(size_t)b * 3 + 1] = 0.0; d.score_sums[(size_t)b * 3 + 2] = 0.0; }
     }
-    out3[0] = s0; out3[1] = s1; out3[2] = (double)ep;
+    out3[0] = s0; out3[1] = s1; out3[2] = ep;
 }
 
 void fl_launch_scores(const FlDev &d, double *out3, int reset, hipStream_t s) {

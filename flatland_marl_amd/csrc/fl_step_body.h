@@ -294,7 +294,9 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
                     uint32_t best = 0xFFFFFFFFu;
                     for (uint32_t act3 = ACT_LEFT; act3 <= ACT_RIGHT; act3++) {
                         const uint32_t nd = (dir + act3 + 2u) & 3u;
-                        if (!((bits >> (3u - nd)) & 1u)) continue;
+                        // bit 16 + nd of the grid word: the neighbour towards nd is on the map and has rail (a transition of a
+                        // malformed map may point off the grid: no index is formed for it)
+                        if (!((bits >> (3u - nd)) & 1u) || !((cell >> (16u + nd)) & 1u)) continue;
                         const uint32_t nr = ridx[step_cell(pos, nd, W)];
                         if (nr == FL_R_NONE) continue;
                         const uint32_t v = dm_t[nr * 4u + nd];
@@ -417,8 +419,9 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
                 d.last_episode[(size_t)b * 2 + 1] = L.misc[M_ARRIVED];
                 // the evaluator's per-episode terms, summed per env in episode order (service.py:875-879: normalized reward =
                 // cumulative reward / (max_episode_steps * n_agents) + 1; :900-913: complete agents / agents)
-                d.score_sums[(size_t)b * 2 + 0] += 1.0 + (double)L.misc[M_REWARD] / ((double)T * (double)A);
-                d.score_sums[(size_t)b * 2 + 1] += (double)L.misc[M_ARRIVED] / (double)A;
+                d.score_sums[(size_t)b * 3 + 0] += 1.0 + (double)L.misc[M_REWARD] / ((double)T * (double)A);
+                d.score_sums[(size_t)b * 3 + 1] += (double)L.misc[M_ARRIVED] / (double)A;
+                d.score_sums[(size_t)b * 3 + 2] += 1.0;
             }
             if (L.misc[M_ERR]) atomicCAS(&d.err[b], 0, L.misc[M_ERR]);
         }

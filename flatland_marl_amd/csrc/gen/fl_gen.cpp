@@ -615,13 +615,53 @@ double pairwise_sum(const double *a, size_t n) {
     return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
 }
 
+// timetable_generator (timetable_generators.py:21-96) on a finished rail and line; n_cities = len(agents_hints['city_positions']),
+// or 2 when the caller has no hints (a rail loaded from a file: rail_generators.py:131-143 returns none)
+int make_timetable(const Grid &G, int n_agents, int n_cities, const int32_t *init_pos, const int32_t *init_dir, const int32_t *target,
+                   const double *speed, Rng &rng, int32_t *earliest, int32_t *latest, int32_t *max_episode_steps) {
+    const int width = G.W, height = G.H;
+    std::vector<double> times(n_agents);
+    {
+        std::vector<Cell> targets;
+        std::vector<std::vector<uint16_t>> dms;
+        for (int a = 0; a < n_agents; a++) {
+            const Cell t(target[2 * a], target[2 * a + 1]);
+            size_t u = 0;
+            for (; u < targets.size(); u++)
+                if (targets[u] == t) break;
+            if (u == targets.size()) { targets.push_back(t); dms.push_back(std::vector<uint16_t>()); distance_map_bfs(G, t, dms.back()); }
+            const uint16_t dv = dms[u][((size_t)init_pos[2 * a] * width + init_pos[2 * a + 1]) * 4 + init_dir[a]];
+            const int len = dv == 0xFFFF ? 0 : (int)dv + 1;  // len(shortest path), None -> 0
+            times[a] = (double)len / speed[a];
+        }
+    }
+    int T = (int)(4 * 2 * ((double)(width + height) + ((double)n_agents / (double)n_cities)));
+    const double mean_time = pairwise_sum(times.data(), times.size()) / (double)n_agents;
+    double longest = times[0];
+    for (int a = 1; a < n_agents; a++) longest = times[a] > longest ? times[a] : longest;
+    const double mean_path_delay = mean_time * 0.2;
+    const int T_new = (int)(ceil(longest * 1.5) + mean_path_delay);
+    const int T_old = (int)(T * 3.0);
+    T = std::min(T_new, T_old);
+    const int end_buffer = (int)(T * 0.05);
+    const int latest_arrival_max = T - end_buffer;
+    for (int a = 0; a < n_agents; a++) {
+        const int travel_max = (int)(ceil((times[a] * 1.3) + mean_path_delay));
+        const int window = std::max(latest_arrival_max - travel_max, 1);
+        const int e = (int)rng.randint(0, window);
+        earliest[a] = e;
+        latest[a] = e + travel_max;
+    }
+    *max_episode_steps = T;
+    return FLG_OK;
+}
+
 // SparseLineGen.generate + timetable_generator on a finished rail (what reset(regenerate_schedule=True) redoes)
 int make_schedule(const Grid &G, int n_agents, int n_cities, const std::vector<int> &orientations,
                   const std::vector<std::vector<std::pair<Cell, int>>> &stations, int n_speeds, const double *speed_values,
                   const double *speed_probs, Rng &rng, int32_t *init_pos, int32_t *init_dir, int32_t *target, double *speed,
                   int32_t *earliest, int32_t *latest, int32_t *max_episode_steps) {
-    const int width = G.W, height = G.H;
-    struct { const std::vector<int> &orientations; const std::vector<std::vector<std::pair<Cell, int>>> &stations; } R = {orientations, stations};
+        struct { const std::vector<int> &orientations; const std::vector<std::vector<std::pair<Cell, int>>> &stations; } R = {orientations, stations};
     // ---- SparseLineGen.generate (line_generators.py:82-165)
     int city1 = 0, city2 = 0;
     for (int a = 0; a < n_agents; a++) {
@@ -665,41 +705,7 @@ int make_schedule(const Grid &G, int n_agents, int n_cities, const std::vector<i
     } else {
         for (int a = 0; a < n_agents; a++) speed[a] = 1.0;
     }
-    // ---- timetable_generator (timetable_generators.py:21-96)
-    std::vector<double> times(n_agents);
-    {
-        std::vector<Cell> targets;
-        std::vector<std::vector<uint16_t>> dms;
-        for (int a = 0; a < n_agents; a++) {
-            const Cell t(target[2 * a], target[2 * a + 1]);
-            size_t u = 0;
-            for (; u < targets.size(); u++)
-                if (targets[u] == t) break;
-            if (u == targets.size()) { targets.push_back(t); dms.push_back(std::vector<uint16_t>()); distance_map_bfs(G, t, dms.back()); }
-            const uint16_t dv = dms[u][((size_t)init_pos[2 * a] * width + init_pos[2 * a + 1]) * 4 + init_dir[a]];
-            const int len = dv == 0xFFFF ? 0 : (int)dv + 1;  // len(shortest path), None -> 0
-            times[a] = (double)len / speed[a];
-        }
-    }
-    int T = (int)(4 * 2 * ((double)(width + height) + ((double)n_agents / (double)n_cities)));
-    const double mean_time = pairwise_sum(times.data(), times.size()) / (double)n_agents;
-    double longest = times[0];
-    for (int a = 1; a < n_agents; a++) longest = times[a] > longest ? times[a] : longest;
-    const double mean_path_delay = mean_time * 0.2;
-    const int T_new = (int)(ceil(longest * 1.5) + mean_path_delay);
-    const int T_old = (int)(T * 3.0);
-    T = std::min(T_new, T_old);
-    const int end_buffer = (int)(T * 0.05);
-    const int latest_arrival_max = T - end_buffer;
-    for (int a = 0; a < n_agents; a++) {
-        const int travel_max = (int)(ceil((times[a] * 1.3) + mean_path_delay));
-        const int window = std::max(latest_arrival_max - travel_max, 1);
-        const int e = (int)rng.randint(0, window);
-        earliest[a] = e;
-        latest[a] = e + travel_max;
-    }
-    *max_episode_steps = T;
-    return FLG_OK;
+    return make_timetable(G, n_agents, n_cities, init_pos, init_dir, target, speed, rng, earliest, latest, max_episode_steps);
 }
 
 Rng load_rng(const uint32_t *key, int pos) {
@@ -787,6 +793,25 @@ int flg_generate_seeded_rail(int width, int height, int n_agents, int grid_mode,
     }
     rc = make_schedule(G, n_agents, n_cities, R.orientations, R.stations, n_speeds, speed_values, speed_probs, rng, init_pos, init_dir,
                        target, speed, earliest, latest, max_episode_steps);
+    if (rc != FLG_OK) return rc;
+    store_rng(rng, mt_key, mt_pos);
+    return FLG_OK;
+}
+
+int flg_timetable(int width, int height, const uint16_t *grid, int n_agents, int n_cities, const int32_t *init_pos, const int32_t *init_dir,
+                  const int32_t *target, const double *speed, uint32_t *mt_key, int *mt_pos, int32_t *earliest, int32_t *latest,
+                  int32_t *max_episode_steps) {
+    if (!grid || !init_pos || !init_dir || !target || !speed || !mt_key || !mt_pos || !earliest || !latest || !max_episode_steps ||
+        width <= 0 || height <= 0 || n_agents <= 0 || n_cities <= 0 || *mt_pos < 0 || *mt_pos > 624) { set_err("flg_timetable: bad argument"); return FLG_ERR_ARG; }
+    Grid G;
+    G.H = height; G.W = width;
+    G.g.assign(grid, grid + (size_t)width * height);
+    for (int a = 0; a < n_agents; a++) {
+        if (!G.inside(init_pos[2 * a], init_pos[2 * a + 1]) || !G.inside(target[2 * a], target[2 * a + 1]) || init_dir[a] < 0 || init_dir[a] > 3 ||
+            !(speed[a] > 0.0)) { set_err("flg_timetable: agent %d: position / direction / speed out of range", a); return FLG_ERR_ARG; }
+    }
+    Rng rng = load_rng(mt_key, *mt_pos);
+    const int rc = make_timetable(G, n_agents, n_cities, init_pos, init_dir, target, speed, rng, earliest, latest, max_episode_steps);
     if (rc != FLG_OK) return rc;
     store_rng(rng, mt_key, mt_pos);
     return FLG_OK;

@@ -1,5 +1,5 @@
 """Multi-GPU harness pieces: one process per GPU, envs sharded contiguously across ranks (no data-path
-collective: envs are independent), one all-reduce(SUM) of the int64[4] episode metrics and one
+collective: envs are independent), one all-reduce(SUM) of the int64[7] episode metrics + evaluator score sums and one
 all-reduce(MAX) of the timed region per measurement window.  backend "nccl" is RCCL on ROCm; the
 same code runs on "gloo"/CPU tensors in the tests."""
 import os
@@ -43,20 +43,25 @@ SCORE_SCALE = float(2 ** 32)   # fixed point of the evaluator's score sums insid
 
 
 def reduce_metrics(metrics, scores=None):
-    """ONE all-reduce(SUM) of the int64 metrics vector (sum reward, arrived, agent-steps, episodes).  With `scores` (the
-    float64[3] tensor of BatchedRailEnv.scores(): sum of normalized rewards, sum of completion ratios, episodes) the two score
-    sums ride in the same vector as 2**-32 fixed point -- integer sums do not depend on the order the ranks are added in -- and
-    the call returns (metrics int64[4], scores float64[2]) of the whole job (flatland/evaluators/service.py:900-913 divides
-    them by the number of episodes)."""
+    """ONE all-reduce(SUM) of the int64 metrics vector (sum reward, arrived, agent-steps, episodes); `metrics` holds the job's
+    totals afterwards (in place, with or without `scores`).  With `scores` (the float64[3] tensor of BatchedRailEnv.scores(): sum
+    of normalized rewards, sum of completion ratios, their own episode count) the two score sums ride in the same vector as
+    2**-32 fixed point -- integer sums do not depend on the order the ranks are added in, at the price of rounding every rank's
+    sum to a multiple of 2**-32 (the job-level means are therefore within world_size * 2**-33 / episodes of the float64 sums
+    fl_scores documents, not bit-equal to them) -- together with the scores' episode count, and the call returns
+    (metrics int64[4], scores float64[3]) of the whole job (flatland/evaluators/service.py:900-913 divides the sums by the
+    number of episodes: scores[0] / scores[2], scores[1] / scores[2])."""
     if scores is None:
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
         return metrics
-    fixed = torch.round(scores[:2].to(torch.float64) * SCORE_SCALE).to(torch.int64).to(metrics.device)
-    vec = torch.cat([metrics.to(torch.int64), fixed])
+    sc = scores.to(torch.float64).to(metrics.device)
+    fixed = torch.round(sc[:2] * SCORE_SCALE).to(torch.int64)
+    vec = torch.cat([metrics.to(torch.int64), fixed, torch.round(sc[2:3]).to(torch.int64)])
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-    return vec[:4], vec[4:6].to(torch.float64) / SCORE_SCALE
+    metrics.copy_(vec[:4])
+    return metrics, torch.cat([vec[4:6].to(torch.float64) / SCORE_SCALE, vec[6:7].to(torch.float64)])
 
 
 def gather_agent_steps(metrics, device=None):

@@ -17,7 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "gen", "libflatland_gen.so")
-SYMBOLS = ("flg_last_error", "flg_city_positions", "flg_generate", "flg_generate_seeded_rail")
+SYMBOLS = ("flg_last_error", "flg_city_positions", "flg_generate", "flg_generate_seeded_rail", "flg_timetable")
 _lib = None
 
 
@@ -41,6 +41,7 @@ def lib():
         L.flg_generate.argtypes = [i32] * 7 + [vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
         L.flg_generate_seeded_rail.argtypes = [i32] * 7 + [vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, C.POINTER(i32), vp, vp, vp, vp, i32, vp, vp, vp,
                                                vp, vp, vp, C.POINTER(i32)]
+        L.flg_timetable.argtypes = [i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32), vp, vp, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -151,3 +152,27 @@ def generate_env(width, height, number_of_agents, rail_generator, line_generator
                 malf_rate=np.float64(malf_rate), malf_min=np.int32(malf_min), malf_max=np.int32(malf_max),
                 mt_key=key, mt_pos=np.int32(pos.value))
 
+
+
+def redraw_timetable(static, mt_key, mt_pos, num_cities=2):
+    """timetable_generator alone (timetable_generators.py:21-96) for a finished rail and line, on the MT19937 stream
+    (mt_key, mt_pos): what RailEnv.reset() does to an env loaded from a file -- rail_from_file / line_from_file hand the same
+    rail and line back (rail_generators.py:116-145, line_generators.py:168-206), earliest_departure / latest_arrival /
+    max_episode_steps are drawn again, with num_cities = 2 because a file carries no agents_hints (timetable_generators.py:36-40).
+    Returns a new static description with the new timetable and the advanced stream."""
+    grid = np.ascontiguousarray(static["grid"], dtype=np.uint16)
+    H, W = grid.shape
+    ip = np.ascontiguousarray(static["init_pos"], dtype=np.int32)
+    idr = np.ascontiguousarray(static["init_dir"], dtype=np.int32)
+    tg = np.ascontiguousarray(static["target"], dtype=np.int32)
+    sp = np.ascontiguousarray(static["speed"], dtype=np.float64)
+    A = len(idr)
+    key = np.ascontiguousarray(mt_key, dtype=np.uint32).copy()
+    pos = C.c_int(int(mt_pos))
+    ea, la = np.zeros(A, dtype=np.int32), np.zeros(A, dtype=np.int32)
+    T = C.c_int(0)
+    _chk(lib().flg_timetable(W, H, _p(grid), A, int(num_cities), _p(ip), _p(idr), _p(tg), _p(sp), _p(key), C.byref(pos), _p(ea), _p(la),
+                             C.byref(T)))
+    out = dict(static)
+    out.update(earliest=ea, latest=la, T=np.int32(T.value), mt_key=key, mt_pos=np.int32(pos.value))
+    return out

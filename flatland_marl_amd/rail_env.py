@@ -185,8 +185,9 @@ class TreeObsForRailEnv(ObservationBuilder):
 
     def set_env(self, env):
         self.env = env
-        env._batch.max_nodes, env._batch.pred_depth = self.max_nodes, self.max_pred_depth
-        env._batch._obs = None
+        if env._batch is not None:            # (before the env's first reset() there is nothing to configure yet: reset() binds again)
+            env._batch.max_nodes, env._batch.pred_depth = self.max_nodes, self.max_pred_depth
+            env._batch._obs = None
 
     def get_many(self, handles):
         """-> (agent_attr [A][83], (nodes [A][N][12], adjacency [A][N-1][3], node_order [A][N], edge_order [A][N-1]))
@@ -284,6 +285,18 @@ class TreeObsUpstream(ObservationBuilder):
         return {h: nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}
 
 
+class _FromDescription:
+    """what `env.rail_generator` / `env.line_generator` are on an env made from a description or a file (the reference:
+    rail_from_file / line_from_file closures, rail_generators.py:116-145, line_generators.py:168-206): hands the env's own rail /
+    line back"""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __repr__(self):
+        return "<%s of the loaded description>" % self.what
+
+
 class RailEnv:
     """B = 1 view with the reference's constructor, attribute and method surface (rail_env.py:35-777)."""
 
@@ -312,7 +325,7 @@ class RailEnv:
             self._seed(random_seed)
         self.num_resets = 0
         self._static, self._hints, self._batch = None, None, None
-        self._from_static = False
+        self._from_static = self._from_file = False
         self.rail, self.agents, self.distance_map = None, [], None
         self._max_episode_steps = None
         self._elapsed_steps = 0
@@ -321,16 +334,19 @@ class RailEnv:
         self.obs_dict = None
 
     @classmethod
-    def from_static(cls, static, obs_builder_object=None, device=0):
-        """an env from the static description a (reference) env has after reset(): no generators involved"""
+    def from_static(cls, static, obs_builder_object=None, device=0, from_file=False):
+        """an env from the static description a (reference) env has after reset(): no generators involved.
+        from_file: the description comes from an env FILE (RailEnvPersister.load_new, persistence.py:105-129): reset() with
+        regenerate_rail or regenerate_schedule then behaves like the reference's rail_from_file / line_from_file env -- the same
+        rail and line, the timetable drawn again from the env's MT19937 stream (see generators.redraw_timetable)."""
         H, W = np.asarray(static["grid"]).shape
         mfp = MalfunctionParameters(float(static["malf_rate"]), int(static["malf_min"]), int(static["malf_max"]))
         env = cls(W, H, number_of_agents=len(static["init_dir"]), obs_builder_object=obs_builder_object,
                   malfunction_generator=ParamMalfunctionGen(mfp), device=device)
-        # no generators: like the reference's rail_from_file / line_from_file / timetable from a file, reset() re-adopts this
-        # same description (solution/eval_env.py:102 calls env.reset() on such an env)
-        env.rail_generator = env.line_generator = None
+        # no generators to run: reset() re-adopts this same rail and line (solution/eval_env.py:102 calls env.reset() on such an env)
+        env.rail_generator, env.line_generator = _FromDescription("rail"), _FromDescription("line")
         env._from_static = True
+        env._from_file = bool(from_file)
         env._adopt(static)
         return env
 
@@ -403,10 +419,15 @@ class RailEnv:
                 st = self.np_random.get_state()
                 self._batch.set_rng_state(np.asarray(st[1], dtype=np.uint32)[None], np.array([st[2]], dtype=np.int32))
         mfp = self.malfunction_generator.MFP
-        if self._from_static:
-            # an env loaded from a description (the reference: rail_from_file + line_from_file): the same map, the same lines and
-            # timetable again; regenerate_schedule makes fresh agents (EnvAgent.from_line, rail_env.py:315-317), without it
-            # EnvAgent.reset() keeps arrival_time (agent_utils.py:90-105).  The MT19937 stream runs on.
+        if self._from_static and self._from_file and (regenerate_rail or regenerate_schedule):
+            # an env loaded from a FILE (rail_from_file + line_from_file): the same rail and line come back, the agents are fresh
+            # (EnvAgent.from_line, rail_env.py:315-317) and timetable_generator draws earliest_departure / latest_arrival /
+            # max_episode_steps AGAIN from the env's stream, without agents_hints (rail_env.py:310-331)
+            key, pos = self._rng_state()
+            self._adopt(generators.redraw_timetable(self._static, key, pos, num_cities=2))
+        elif self._from_static:
+            # an env made from a description: the same map, lines and timetable again; regenerate_schedule makes fresh agents,
+            # without it EnvAgent.reset() keeps arrival_time (agent_utils.py:90-105).  The MT19937 stream runs on.
             self._batch.reset(fresh=bool(regenerate_rail or regenerate_schedule))
         elif regenerate_rail or self._static is None:
             key, pos = self._rng_state()

@@ -16,5 +16,6 @@ class RailEnvPersister:
     def load_new(cls, filename, load_from_package=None):
         env_dict = cls.load_env_dict(filename, load_from_package)
         st = np.random.RandomState().get_state()       # the format carries no RNG state; the reference re-seeds at load too
-        env = RailEnv.from_static(_p.static_from_env_dict(env_dict, st[1], st[2]))
+        # reset() on this env draws the timetable again, like the reference's rail_from_file / line_from_file env does
+        env = RailEnv.from_static(_p.static_from_env_dict(env_dict, st[1], st[2]), from_file=True)
         return env, env_dict

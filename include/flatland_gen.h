@@ -54,6 +54,14 @@ int flg_generate_seeded_rail(int width, int height, int n_agents, int grid_mode,
                              int32_t *stations, int max_stations, int32_t *init_pos, int32_t *init_dir, int32_t *target,
                              double *speed, int32_t *earliest, int32_t *latest, int32_t *max_episode_steps);
 
+/* timetable_generator alone (envs/timetable_generators.py:21-96) on a finished rail and line: what RailEnv.reset() redoes for an
+ * env loaded from a file (rail_from_file / line_from_file, rail_generators.py:116-145, line_generators.py:168-206: the rail and
+ * the line come back unchanged, earliest_departure / latest_arrival / max_episode_steps are DRAWN AGAIN from env.np_random).
+ * n_cities: len(agents_hints['city_positions']), or 2 without hints (rail_from_file gives none).  grid u16[height][width]. */
+int flg_timetable(int width, int height, const uint16_t *grid, int n_agents, int n_cities, const int32_t *init_pos, const int32_t *init_dir,
+                  const int32_t *target, const double *speed, uint32_t *mt_key, int *mt_pos, int32_t *earliest, int32_t *latest,
+                  int32_t *max_episode_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N > 1 harness path -- contiguous env sharding, the int64[4] metrics
+"""CPU, world_size 2, gloo: the N > 1 harness path -- contiguous env sharding, the int64 metrics (+ score sums)
 all-reduce(SUM) and the max-over-ranks timing -- plus the per-replica seeding of the workload."""
 import os
 import socket
@@ -27,10 +27,15 @@ def _worker(rank, world, port, out):
     metrics = torch.tensor([-(rank + 1) * 10, rank + 1, (hi - lo) * 20, 1], dtype=torch.int64)
     dist_utils.barrier()
     red = dist_utils.reduce_metrics(metrics.clone())
+    # with the evaluator's score sums in the same all-reduce: `metrics` is reduced IN PLACE on this path too
+    m2 = metrics.clone()
+    scores = torch.tensor([0.25 + rank, 0.5 * (rank + 1), float(rank + 1)], dtype=torch.float64)
+    m2_ret, sc = dist_utils.reduce_metrics(m2, scores)
+    assert m2_ret is m2
     tmax = dist_utils.max_over_ranks(1.0 + rank)
     per_rank = dist_utils.gather_agent_steps(metrics)
     envs, seed = wl.make_envs("cfg2", B=3, rank=rank)
-    out[rank] = dict(shard=(lo, hi), red=red.tolist(), tmax=tmax, per_rank=per_rank, keys=[int(e["mt_key"][1]) for e in envs], seed=seed)
+    out[rank] = dict(shard=(lo, hi), red=red.tolist(), red2=m2.tolist(), sc=sc.tolist(), tmax=tmax, per_rank=per_rank, keys=[int(e["mt_key"][1]) for e in envs], seed=seed)
     dist_utils.shutdown()
 
 
@@ -41,6 +46,8 @@ def test_metrics_allreduce_and_sharding_world2():
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0]["shard"] == (0, 6) and out[1]["shard"] == (6, 11)
     assert out[0]["red"] == out[1]["red"] == [-30, 3, 11 * 20, 2]
+    assert out[0]["red2"] == out[1]["red2"] == [-30, 3, 11 * 20, 2]
+    assert out[0]["sc"] == out[1]["sc"] == [0.25 + 1.25, 0.5 + 1.0, 3.0]      # (exact: multiples of 2**-32)
     assert out[0]["tmax"] == out[1]["tmax"] == 2.0
     assert out[0]["per_rank"] == out[1]["per_rank"] == [6 * 20, 5 * 20]
     # weak scaling: rank r owns global replicas [3r, 3r+3), each with its own MT19937 state

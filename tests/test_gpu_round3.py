@@ -41,10 +41,12 @@ def test_score_sums_equal_the_reference_evaluator_scores():
     from flatland_marl_amd import dist_utils
     mm, ss = dist_utils.reduce_metrics(env.metrics().clone(), env.scores().clone())
     assert mm.cpu().numpy().tolist() == m.tolist()
-    np.testing.assert_allclose(ss.cpu().numpy(), s[:2], rtol=0, atol=2.0 ** -32)
-    # reset of the counters
-    env.scores(reset=True)
+    np.testing.assert_allclose(ss.cpu().numpy()[:2], s[:2], rtol=0, atol=2.0 ** -32)
+    assert ss.cpu().numpy()[2] == 2
+    # the scores keep an episode counter of their own: resetting the metrics alone leaves sums AND count of the same window
     env.metrics(reset=True)
+    assert env.scores().cpu().numpy().tolist() == s.tolist() and env.metrics().cpu().numpy()[3] == 0
+    env.scores(reset=True)
     assert env.scores().cpu().numpy().tolist() == [0.0, 0.0, 0.0]
     env.check()
 
@@ -178,11 +180,34 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["agent_steps_per_rank"]) == 2
+    assert d["dist_backend"] == "gloo" and d["device_per_rank"] == [0, 0]       # the rehearsal: both ranks on the one GPU
     A = d["config"]["agents"]
     assert d["agent_steps_per_rank"] == [8 * A * 12, 8 * A * 12] and d["agent_steps"] == 2 * 8 * A * 12
     assert abs(d["value"] - 2 * 8 * A * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 1e-6 * d["value"]     # sum over ranks / max time
     assert "cpu_baseline" not in d and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and "note" in d["roofline"]
+
+
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """`python bench.py --gpus 2` on RCCL (backend "nccl"), one rank per GPU: runs wherever at least two GPUs are visible (the
+    driver's multi-GPU node; skipped on the one-GPU box, where test_bench_starts_its_own_ranks rehearses the same path on gloo).
+    Every rank on a device of its own, equal shards, the job-level sums from the one all-reduce."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FL_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--envs", "64",
+                        "--event-steps", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    A = d["config"]["agents"]
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["dist_backend"] == "nccl"
+    assert sorted(d["device_per_rank"]) == [0, 1]
+    assert d["agent_steps_per_rank"] == [64 * A * 40] * 2 and d["agent_steps"] == 2 * 64 * A * 40
+    assert abs(d["value"] - d["agent_steps"] / (d["ms_per_step"] * 40 * 1e-3)) <= 1e-6 * d["value"]
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
 
 
 def test_capacities_are_checked_before_anything_is_allocated():

@@ -66,3 +66,27 @@ def test_ingested_env_steps_like_the_golden_episode():
     for t, a in enumerate(fx["actions"][:80]):
         e.step(a)
         np.testing.assert_array_equal(e.state(), util.golden_state(fx, t))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_reset_of_a_file_env_redraws_the_timetable_like_the_reference(tag):
+    """RailEnvPersister.load_new(file) + env.reset() of the REAL reference from a known MT19937 state (golden
+    persist_reset_cfg1.npz; a: reset(), b: reset(regenerate_rail=False, regenerate_schedule=True)): same rail and line, a NEW
+    timetable and max_episode_steps drawn by timetable_generator without hints (num_cities = 2), the stream advanced."""
+    from flatland_marl_amd import generators
+    g = util.load("persist_reset_cfg1")
+    d = persistence.load_env_dict(os.path.join(util.GOLD, "cfg1_persist.pkl"))
+    st = persistence.static_from_env_dict(d, g[tag + "_mt_key0"], g[tag + "_mt_pos0"])
+    out = generators.redraw_timetable(st, st["mt_key"], st["mt_pos"], num_cities=2)
+    np.testing.assert_array_equal(out["earliest"], g[tag + "_earliest"])
+    np.testing.assert_array_equal(out["latest"], g[tag + "_latest"])
+    assert int(out["T"]) == int(g[tag + "_T"])
+    np.testing.assert_array_equal(out["mt_key"], g[tag + "_mt_key1"])
+    assert int(out["mt_pos"]) == int(g[tag + "_mt_pos1"])
+    np.testing.assert_array_equal(out["grid"], g[tag + "_grid"])
+    np.testing.assert_array_equal(out["init_pos"], g[tag + "_init_pos"])
+    np.testing.assert_array_equal(out["target"], g[tag + "_target"])
+    # FileMalfunctionGen (malfunction_generators.py:63-74): the parameters of the file
+    assert [float(st["malf_rate"]), float(st["malf_min"]), float(st["malf_max"])] == g[tag + "_malf"].tolist()
+    # the file's own timetable differs (it was drawn with the generator's hints: 2 cities there too, but from another state)
+    assert not np.array_equal(out["earliest"], st["earliest"])

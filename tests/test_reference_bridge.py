@@ -135,3 +135,10 @@ def test_upstream_plugin_inside_the_real_reference_railenv(cap, monkeypatch):
         np.testing.assert_array_equal(_Recorder.made[-1].static["grid"], fx["grid"])
     finally:
         del _Recorder.obs_tree
+
+
+def test_committed_goldens_are_what_the_reference_produces_here(cap):
+    """The pin, verified: two small capture jobs re-run on the REAL reference into a temporary directory and compared with the
+    committed fixtures, every array bit for bit and no key missing on either side (oracle/refharness/capture_golden.py --check
+    does the same for all jobs; the whole set takes ~25 minutes of reference CPU time)."""
+    assert cap.check(["cfg1_sparse", "cfg1_malf20_spfollow"], verbose=False) == []
