@@ -832,21 +832,21 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
 
 // diagnostic (not part of the public header): threads, LDS bytes, keys in LDS, next-hop in LDS, work-list bytes, time masks,
 // second index, items in LDS, one pass B for both builders, compact upstream trees of the fused observation launch on this batch
-extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out10) {
+extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out11) {
     NEED_COMMIT(h);
-    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out10);
+    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11);
 }
 
 // diagnostic (not part of the public header), no GPU needed: the same for a batch of the given sizes -- agents, rail-cell and
 // unique-target capacities, maps taller than wide (compact prediction keys), most transitions of a (cell, direction)
 extern "C" int fl_debug_obs_config_of(int A, int Rcap, int Ucap, int tall, int max_branch, int pred_depth, int max_depth, int tree_pred,
-                                      int *out10) {
+                                      int *out11) {
     FlDev d;
     memset(&d, 0, sizeof d);
     d.A = A; d.Rcap = Rcap; d.Ucap = Ucap; d.max_branch = max_branch;
     static uint16_t dummy_key;
     d.rkey = tall ? &dummy_key : nullptr;
-    return fl_obs_config_of_fused(d, pred_depth, max_depth, tree_pred, out10);
+    return fl_obs_config_of_fused(d, pred_depth, max_depth, tree_pred, out11);
 }
 
 double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {

@@ -33,4 +33,4 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
 // more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
 FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s);
-int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[10]);  // diagnostic
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11]);  // diagnostic

@@ -88,59 +88,10 @@ void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipS
     (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
-// what a launch may keep in LDS besides the arrays every launch needs
-struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap; };
-
-// carve the dynamic LDS of a launch: every array the kernel uses, in one place (the kernel follows ObsLayout::off)
+// carve the dynamic LDS of a launch (obs_layout_c in fl_obs_layout.h: one function for the host and for the kernels with a
+// compile-time layout)
 static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &o) {
-    ObsLayout L;
-    for (int k = 0; k < L_COUNT; k++) L.off[k] = L_ABSENT;
-    size_t off = 0;
-    auto put = [&](int which, size_t bytes) { L.off[which] = (unsigned)off; off += (bytes + 15) & ~(size_t)15; };
-    const size_t R = d.Rcap, NS = R * 4, A = d.A, K1 = R + 1, U = d.Ucap;
-    put(L_CELLW, R * 4);
-    put(L_NBR, NS * 2);
-    if (o.snext) put(L_SNEXT, NS * 2);
-    if (d.rkey) put(L_RKEY, R * 2);
-    put(L_SLOT_AGENT, A * 4); put(L_SLOT_READY, A * 4);
-    put(L_CELL_TARGET, ((R + 31) / 32) * 4);
-    put(L_A_SPEED, A * 8); put(L_A_TQ, A * 8);
-    if (P.merged && o.raw) { put(L_A_RAW, A * 32); put(L_RTYPE, R); }   // the agents' raw words and the road types (attribute rows)
-    put(L_A_VPOS, A * 2); put(L_A_POS, A * 4); put(L_A_TSLOT, A * 2); put(L_A_TARGET, A * 2);
-    put(L_A_MALF, A * 2); put(L_A_TPC, A * 2); put(L_A_LP, A * 2); put(L_A_N, A * 2); put(L_A_SRANK, A * 2);
-    put(L_A_DIR, A); put(L_A_STATE, A); put(L_A_FREE, A); put(L_A_DEAD, A);
-    put(L_MISC, 64 * 4); put(L_TEAM_META, 320 * 4);
-    {
-        // trees_merged: 32 flatland_cutils + 32 compact upstream tables a round; else a slot per team + the dummy.  Large maps
-        // borrow this space for the per-(key, time bucket) counters while the bucketed index is built (P.bk): room for those too
-        size_t scr = P.merged ? (size_t)32 * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
-                              : (size_t)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4;
-        if (o.bk_room) scr = std::max(scr, (size_t)(d.Rcap + 1) * OBS_BK_NB * 2 + 4);
-        put(L_WAVE_SCR, scr);
-    }
-    put(L_CSR, K1 * 4);
-    // one pass B for both builders needs the room for twice the node tables: a tighter first-index copy (128 waypoints an agent)
-    const size_t cap1 = o.items_cap ? (size_t)o.items_cap : (size_t)OBS_ITEMS_LDS_CAP;
-    L.items_cap = (P.merged && o.own_filter) ? (int)std::min<size_t>(cap1, std::max<size_t>(1024, A * 128)) : (int)cap1;
-    L.items2_cap = (int)std::min<size_t>(OBS_ITEMS2_CAP, A * (size_t)(P.tree_pred + 2));  // an agent has at most tree_pred + 1 of them
-    if (o.items) put(L_ITEMS, (size_t)L.items_cap * 4);
-    if (o.wl_bytes) put(L_WL, (size_t)o.wl_bytes);       // 0: the work lists live in HBM scratch
-    if (o.partial || !o.wl_bytes) put(L_PARTIAL, (size_t)o.nt * 4);
-    if (o.tmask) put(L_TMASK, K1 * 8);
-    if (o.tmask && P.merged && o.own_filter) put(L_TMASK2, K1 * 8);
-    if (o.nh || o.tab) put(L_NH, U * R * 2);
-    if (o.dual) {
-        put(L_CSR2, K1 * 4);
-        if (o.tmask) put(L_TMASKB, K1 * 8);
-        if (o.tmask && P.merged && o.own_filter) put(L_TMASKB2, K1 * 8);
-        put(L_ITEMS2, (size_t)std::max(L.items2_cap, 4) * 4);
-        put(L_A_LP2, A * 2); put(L_A_TPC2, A * 2); put(L_A_TQ2, A * 8);
-    }
-    if (o.fb) put(L_BKREL, K1 * (OBS_FB_NB + 2) * 2);
-    if (o.tab) { put(L_SEG, NS * 16); put(L_DM, U * NS * 2); put(L_HOP8, U * NS * 2); }
-    L.total = (unsigned)off;
-    L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
-    return L;
+    return obs_layout_c(ObsDims{d.Rcap, d.A, d.Ucap, d.rkey != nullptr}, ObsShape{P.merged, P.tw_c, P.tw_t, P.tpw_t, P.tree_pred}, o);
 }
 
 // Choose what lives in LDS so that the workgroup fits 160 KiB.
@@ -214,8 +165,23 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                         for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
                             if (!ok(force.nh, o.nh)) continue;
                             o.items_cap = caps[ck];
-                            const ObsLayout L = obs_layout(d, P, o);
+                            ObsLayout L = obs_layout(d, P, o);
                             if (L.total > lds_limit) continue;
+                            // a FIXED launch class (compile-time carving, fl_obs_layout.h): the batch fits the class's capacities
+                            // and this choice of options is the class's
+                            static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;
+                            P.fix = 0;
+                            if (!no_fix && P.merged == 1 && !force_nt && lds_limit == (size_t)160 * 1024) {
+                                using F = ObsFixed<1>;
+                                const size_t nh_bytes = ((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15;
+                                if (d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) &&
+                                    P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t &&
+                                    (size_t)d.A * (P.tree_pred + 2) <= (size_t)F::L.items2_cap && F::L.off[L_NH] + nh_bytes <= lds_limit) {
+                                    L = F::L;
+                                    L.total = (unsigned)(F::L.off[L_NH] + nh_bytes);
+                                    P.fix = 1;
+                                }
+                            }
                             P.L = L; P.use_tmask = 1; P.dual_index = 1;
                             P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
                             P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
@@ -276,8 +242,8 @@ static void obs_verbose(const ObsArgs &P) {
     const ObsLayout &L = P.L;
     if (verbose && printed < 4) {
         printed++;
-        fprintf(stderr, "[fl_obs] %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d, one pass B for both builders %d, compact upstream trees %d, bucketed index %d\n",
-                L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT, P.merged, P.compact_t, P.bk);
+        fprintf(stderr, "[fl_obs] fixed launch class %d, %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d, one pass B for both builders %d, compact upstream trees %d, bucketed index %d\n",
+                P.fix, L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT, P.merged, P.compact_t, P.bk);
     }
 }
 static int obs_var(const ObsArgs &P) { return P.L.tab_lds ? 1 : P.L.wl_bytes == 0 ? 2 : 0; }
@@ -337,7 +303,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
 
 // diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth):
 // threads, LDS bytes, static tables in LDS, next-hop in LDS, work-list bytes, time masks, second index, items in LDS
-int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[10]) {
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11]) {
     ObsArgs P = {};
     P.pred_depth = pred_depth;
     P.tw_c = N_WORDS_C * OBS_CAP_C;
@@ -357,7 +323,7 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     out[0] = P.L.nt; out[1] = (int)P.L.total; out[2] = P.L.tab_lds; out[3] = P.L.off[L_NH] != L_ABSENT; out[4] = P.L.wl_bytes;
     out[5] = P.use_tmask + 2 * (P.L.off[L_TMASK2] != L_ABSENT);                    // 3: time masks + the own-path filter's second set
     out[6] = P.dual_index; out[7] = P.L.off[L_ITEMS] != L_ABSENT ? P.L.items_cap : 0;  // entries of the LDS copy of the items
-    out[8] = P.merged; out[9] = P.compact_t;
+    out[8] = P.merged; out[9] = P.compact_t; out[10] = P.fix;   // fixed launch class (compile-time LDS carving), 0 = none
     return FL_OK;
 }
 

@@ -39,7 +39,7 @@
 // index would be vector arithmetic -- 29 spilled vector registers in the rounds kernel)
 __device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return __builtin_amdgcn_readfirstlane(S.order ? S.order[blockIdx.x] : (int)blockIdx.x); }
 
-template <bool CUTILS, int VAR, int STAGE, int MERGED = 0>
+template <bool CUTILS, int VAR, int STAGE, int MERGED = 0, int FIX = 0>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
@@ -49,9 +49,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int lane = tid & 63, wave = tid >> 6;
 
     extern __shared__ __align__(16) unsigned char lds[];
-    const ObsLayout &L = P.L;
-#define LDS_AT(T, which) reinterpret_cast<T *>(lds + L.off[which])
-#define LDS_OPT(T, which) (L.off[which] == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L.off[which]))
+    // FIX != 0: the carving is ObsFixed<FIX>::L, a compile-time constant (every base below folds into an immediate)
+    using FixT = ObsFixed<FIX != 0 ? FIX : 1>;
+#define L_OFF(which) (FIX != 0 ? FixT::L.off[which] : P.L.off[which])
+#define L_FIELD(f) (FIX != 0 ? FixT::L.f : P.L.f)
+#define LDS_AT(T, which) reinterpret_cast<T *>(lds + L_OFF(which))
+#define LDS_OPT(T, which) (L_OFF(which) == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L_OFF(which)))
     uint32_t *cellw = LDS_AT(uint32_t, L_CELLW);  // rail bitmap | occupied-cell table index << 16
     uint16_t *nbr = LDS_AT(uint16_t, L_NBR);
     uint16_t *snext = LDS_OPT(uint16_t, L_SNEXT);
@@ -80,8 +83,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     int *csr = LDS_AT(int, L_CSR);
     uint32_t *items_lds = LDS_OPT(uint32_t, L_ITEMS);
     uint32_t *wl_lds = WL_HBM ? nullptr : LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
-    int *partial = (WL_HBM || L.off[L_PARTIAL] != L_ABSENT) ? LDS_AT(int, L_PARTIAL) : reinterpret_cast<int *>(wl_lds);
-    const int wl_entries = WL_HBM ? S.wl_cap : L.wl_bytes / 8;
+    int *partial = (WL_HBM || L_OFF(L_PARTIAL) != L_ABSENT) ? LDS_AT(int, L_PARTIAL) : reinterpret_cast<int *>(wl_lds);
+    const int wl_entries = WL_HBM ? S.wl_cap : L_FIELD(wl_bytes) / 8;
     unsigned long long *tmask = LDS_OPT(unsigned long long, L_TMASK);
     uint16_t *nh_lds = LDS_OPT(uint16_t, L_NH);
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
@@ -866,8 +869,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
         if (STAGE != 2) { __syncthreads(); if (tid == 0) P.dbg[(size_t)b * 64 + 56] = (long long)wall_clock64(); }   // keys scanned, bucket offsets done
 #endif
-        const bool fit = items_lds != nullptr && misc[2] <= L.items_cap;
-        const bool dual_fill = dual && misc[3] <= L.items2_cap;
+        const bool fit = items_lds != nullptr && misc[2] <= L_FIELD(items_cap);
+        const bool dual_fill = dual && misc[3] <= L_FIELD(items2_cap);
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
         if (merged && !dual_fill) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);  // (cannot happen: the LDS copy holds the exact bound)
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
@@ -1096,7 +1099,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 
 // MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch (two stages), 3 = both with one pass B per
 // round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents); VAR: see obs_body
-template <int MODE, int VAR>
+template <int MODE, int VAR, int FIX = 0>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
     // what this env takes goes to S.cost: the next launch starts the longest envs first.  Env and start clock wait in two LDS words
     // (not in registers: the kernel sits at its register ceiling, and every scalar that lives through it costs spills)
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     }
     if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
-    else if (MODE == 3) obs_body<true, VAR, 1, 1>(d, S, P);
+    else if (MODE == 3) obs_body<true, VAR, 1, 1, FIX>(d, S, P);
     else if (MODE == 4) obs_body<true, VAR, 1, 2>(d, S, P);
     else {
         obs_body<true, VAR, 1>(d, S, P);

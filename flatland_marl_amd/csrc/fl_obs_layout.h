@@ -99,6 +99,91 @@ struct ObsLayout {
                                 // falls back to the items in HBM scratch / to the two stages
 };
 
+// ---- the carving of the dynamic LDS, one function for the host (obs_pick_config: any env size) and for the kernels whose layout
+// is a compile-time constant (FIXED launch classes below: every LDS base is an immediate instead of a scalar register)
+// what a launch may keep in LDS besides the arrays every launch needs
+struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap; };
+struct ObsDims { int Rcap, A, Ucap, rkey; };                   // capacities of the batch (rkey: colliding prediction keys, H > W)
+struct ObsShape { int merged, tw_c, tw_t, tpw_t, tree_pred; };  // what of ObsArgs decides sizes
+
+__host__ __device__ constexpr unsigned obs_al16(unsigned long long bytes) { return (unsigned)((bytes + 15ull) & ~15ull); }
+__host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const ObsShape &P, const ObsOptions &o) {
+    ObsLayout L = {};
+    for (int k = 0; k < L_COUNT; k++) L.off[k] = L_ABSENT;
+    unsigned off = 0;
+#define OBS_PUT(which, bytes) do { L.off[which] = off; off += obs_al16((unsigned long long)(bytes)); } while (0)
+    const unsigned long long R = (unsigned long long)d.Rcap, NS = R * 4, A = (unsigned long long)d.A, K1 = R + 1, U = (unsigned long long)d.Ucap;
+    OBS_PUT(L_CELLW, R * 4);
+    OBS_PUT(L_NBR, NS * 2);
+    if (o.snext) OBS_PUT(L_SNEXT, NS * 2);
+    if (d.rkey) OBS_PUT(L_RKEY, R * 2);
+    OBS_PUT(L_SLOT_AGENT, A * 4); OBS_PUT(L_SLOT_READY, A * 4);
+    OBS_PUT(L_CELL_TARGET, ((R + 31) / 32) * 4);
+    OBS_PUT(L_A_SPEED, A * 8); OBS_PUT(L_A_TQ, A * 8);
+    if (P.merged && o.raw) { OBS_PUT(L_A_RAW, A * 32); OBS_PUT(L_RTYPE, R); }   // the agents' raw words and the road types (attribute rows)
+    OBS_PUT(L_A_VPOS, A * 2); OBS_PUT(L_A_POS, A * 4); OBS_PUT(L_A_TSLOT, A * 2); OBS_PUT(L_A_TARGET, A * 2);
+    OBS_PUT(L_A_MALF, A * 2); OBS_PUT(L_A_TPC, A * 2); OBS_PUT(L_A_LP, A * 2); OBS_PUT(L_A_N, A * 2); OBS_PUT(L_A_SRANK, A * 2);
+    OBS_PUT(L_A_DIR, A); OBS_PUT(L_A_STATE, A); OBS_PUT(L_A_FREE, A); OBS_PUT(L_A_DEAD, A);
+    OBS_PUT(L_MISC, 64 * 4); OBS_PUT(L_TEAM_META, 320 * 4);
+    {
+        // trees_merged: 32 flatland_cutils + 32 compact upstream tables a round; else a slot per team + the dummy.  Large maps
+        // borrow this space for the per-(key, time bucket) counters while the bucketed index is built (P.bk): room for those too
+        unsigned long long scr = P.merged ? 32ull * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
+                                          : (unsigned long long)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4;
+        const unsigned long long bkc = (R + 1) * OBS_BK_NB * 2 + 4;
+        if (o.bk_room && bkc > scr) scr = bkc;
+        OBS_PUT(L_WAVE_SCR, scr);
+    }
+    OBS_PUT(L_CSR, K1 * 4);
+    // one pass B for both builders needs the room for twice the node tables: a tighter first-index copy (128 waypoints an agent)
+    const unsigned long long cap1 = o.items_cap ? (unsigned long long)o.items_cap : (unsigned long long)OBS_ITEMS_LDS_CAP;
+    const unsigned long long own_cap = A * 128 > 1024 ? A * 128 : 1024;
+    L.items_cap = (P.merged && o.own_filter) ? (int)(cap1 < own_cap ? cap1 : own_cap) : (int)cap1;
+    const unsigned long long i2 = A * (unsigned long long)(P.tree_pred + 2);  // an agent has at most tree_pred + 1 of them
+    L.items2_cap = (int)(i2 < OBS_ITEMS2_CAP ? i2 : OBS_ITEMS2_CAP);
+    if (o.items) OBS_PUT(L_ITEMS, (unsigned long long)L.items_cap * 4);
+    if (o.wl_bytes) OBS_PUT(L_WL, o.wl_bytes);       // 0: the work lists live in HBM scratch
+    if (o.partial || !o.wl_bytes) OBS_PUT(L_PARTIAL, (unsigned long long)o.nt * 4);
+    if (o.tmask) OBS_PUT(L_TMASK, K1 * 8);
+    if (o.tmask && P.merged && o.own_filter) OBS_PUT(L_TMASK2, K1 * 8);
+    if (o.dual) {
+        OBS_PUT(L_CSR2, K1 * 4);
+        if (o.tmask) OBS_PUT(L_TMASKB, K1 * 8);
+        if (o.tmask && P.merged && o.own_filter) OBS_PUT(L_TMASKB2, K1 * 8);
+        OBS_PUT(L_ITEMS2, (unsigned long long)(L.items2_cap > 4 ? L.items2_cap : 4) * 4);
+        OBS_PUT(L_A_LP2, A * 2); OBS_PUT(L_A_TPC2, A * 2); OBS_PUT(L_A_TQ2, A * 8);
+    }
+    if (o.fb) OBS_PUT(L_BKREL, K1 * (OBS_FB_NB + 2) * 2);
+    // the arrays sized by the number of unique targets come last: a launch class with a compile-time layout fixes everything above
+    if (o.nh || o.tab) OBS_PUT(L_NH, U * R * 2);
+    if (o.tab) { OBS_PUT(L_SEG, NS * 16); OBS_PUT(L_DM, U * NS * 2); OBS_PUT(L_HOP8, U * NS * 2); }
+#undef OBS_PUT
+    L.total = off;
+    L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
+    return L;
+}
+
+// FIXED launch classes: the pinned configurations of the small-env kernels with every capacity rounded up to a class value, so that
+// the whole carving is a compile-time constant -- an LDS base is an immediate of the ds_* instruction instead of one of ~50 scalar
+// registers the kernel cannot keep (311-373 spilled SGPRs before, every one a v_readlane / v_writelane in the hot loops).  The
+// host (obs_pick_config) takes a class when the batch fits its capacities AND its own choice of options is the class's; any
+// other batch runs the same kernel with the runtime layout (FIX 0).  The next-hop tables (sized by the unique targets) come last
+// in the carving: their base is fixed, their size is the batch's.
+//   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells -- cfg1, cfg2 (BASELINE configs[0..1])
+template <int FIX> struct ObsFixed;
+template <> struct ObsFixed<1> {
+    static constexpr ObsDims dims = {256, 32, 0, 0};
+    static constexpr ObsShape shape = {1, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    //                                  nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap
+    static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+__host__ __device__ constexpr bool obs_same_options(const ObsOptions &a, const ObsOptions &b) {
+    return a.nt == b.nt && a.wl_bytes == b.wl_bytes && a.tab == b.tab && a.nh == b.nh && a.tmask == b.tmask && a.dual == b.dual &&
+           a.items == b.items && a.snext == b.snext && a.partial == b.partial && a.bk_room == b.bk_room &&
+           a.own_filter == b.own_filter && a.fb == b.fb && a.raw == b.raw && a.items_cap == b.items_cap;
+}
+
 // outputs of the flatland_cutils builder and of the upstream dense tree builder (k_obs MODE 0 / 1 / 2 = both)
 struct ObsArgs {
     int max_nodes, pred_depth, max_depth, tree_pred;  // pred_depth: cutils predictor, tree_pred: upstream predictor
@@ -119,7 +204,9 @@ struct ObsArgs {
     int bk_nb, bk_shift;
     int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged); 1: one round (at most 32 agents), 2: several
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
-    ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it)
+    int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
+    ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it -- or, fix != 0, has the same
+                       // carving compiled in)
 };
 
 // kernel launchers, one translation unit per MODE (0 = flatland_cutils outputs, 1 = upstream dense tree, 2 / 3 = both in one launch);

@@ -10,12 +10,12 @@ import pytest
 from flatland_marl_amd import hip_backend as hb
 from flatland_marl_amd import workload as wl
 
-KEYS = ("nt", "lds", "tab", "nh", "wl", "tmask", "dual", "items", "merged", "compact")
+KEYS = ("nt", "lds", "tab", "nh", "wl", "tmask", "dual", "items", "merged", "compact", "fix")
 
 
 def _config(A, R, U, depth, tall=0, max_branch=2, pred=500, tree_pred=30):
     L = ctypes.CDLL(hb.LIB_PATH)       # plain dlopen: no torch, no GPU
-    out = (ctypes.c_int * 10)()
+    out = (ctypes.c_int * 11)()
     assert L.fl_debug_obs_config_of(A, R, U, tall, max_branch, pred, depth, tree_pred, out) == 0
     return dict(zip(KEYS, out))
 
@@ -32,8 +32,10 @@ def _sizes(workload):
     # depth 2 is the bench default, depth 3 is BASELINE's definition of configs[2] / configs[4].
     # merged: one pass B for the trees of both builders (1 = one round, 2 = rounds of 32 agents); wl = 0: work lists in HBM scratch;
     # tmask 3 = time masks + the second set of the classify loop's own-path filter; items = entries of the LDS copy of the items
-    ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=2560, merged=1, compact=1)),
-    ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1)),
+    # fix = 1: the launch class with a compile-time LDS carving (ObsFixed<1>: at most 32 agents / 256 rail cells; items = its capacity)
+    ("cfg1", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
+    ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
+    ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=0)),
     ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=4096, merged=2, compact=1)),
     ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),
     ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1)),   # round 2: 512 threads (85-slot tables)
@@ -54,3 +56,17 @@ def test_grids_with_three_way_cells_take_the_dfs_slot_tables():
     assert got["compact"] == 0 and got["merged"] == 0, got
     got = _config(20, 213, 5, 2, tall=1)   # colliding prediction keys: two stages
     assert got["merged"] == 0 and got["compact"] == 1, got
+
+
+def test_fixed_launch_class_boundaries():
+    """ObsFixed<1> (compile-time LDS carving of the one-round kernel) is taken exactly when the batch fits its capacities --
+    at most 32 agents, 256 rail cells, keys = rail indices -- and obs_pick_config's own choice of options is the class's; any
+    other batch runs the runtime-layout kernel (same code, fix = 0)."""
+    assert _config(32, 256, 8, 2)["fix"] == 1
+    assert _config(32, 257, 8, 2)["fix"] == 0 and _config(32, 257, 8, 2)["merged"] == 1
+    assert _config(33, 200, 8, 2)["fix"] == 0
+    assert _config(20, 213, 5, 2, tall=1)["fix"] == 0
+    assert _config(20, 213, 5, 3)["fix"] == 1                 # depth 3 of the upstream tree: same tables, same class
+    assert _config(20, 213, 5, 2, tree_pred=60)["fix"] == 0   # 20 * 62 items of the second index exceed the class's 1024
+    got = _config(20, 213, 20, 2)
+    assert got["fix"] == 1 and got["lds"] <= 160 * 1024      # the next-hop tables (last in the carving) at the batch's size

@@ -7,7 +7,7 @@ for rep in 1 2; do
   n=0
   for setting in "$@"; do
     n=$((n+1)); [ "$setting" = "-" ] && setting=""
-    env $setting python bench.py --no-extra-workloads > gpurun_out/env_${tag}_$n.json 2> gpurun_out/env_${tag}_$n.err
+    env $setting python bench.py --no-extra-workloads --no-cpu-baseline > gpurun_out/env_${tag}_$n.json 2> gpurun_out/env_${tag}_$n.err
     python -c "
 import json,sys;d=json.load(open(sys.argv[1]));print(sys.argv[2] or '(default)', '%.2f M' % (d['value']/1e6), d['kernel_ms'])" gpurun_out/env_${tag}_$n.json "$setting"
   done
