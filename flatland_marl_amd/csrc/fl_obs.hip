@@ -94,6 +94,34 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
     return obs_layout_c(ObsDims{d.Rcap, d.A, d.Ucap, d.rkey != nullptr}, ObsShape{P.merged, P.tw_c, P.tw_t, P.tpw_t, P.tree_pred}, o);
 }
 
+// A FIXED launch class (compile-time carving, ObsFixed<k> in fl_obs_layout.h) is taken when the batch fits the class's capacities
+// and the configuration just chosen for it has the class's options and shape; L becomes the class's carving (what the kernel has
+// compiled in) with the next-hop tables, last in the carving, at the batch's size.
+template <int FIX>
+static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o, ObsLayout &L) {
+    using F = ObsFixed<FIX>;
+    const size_t nh_bytes = F::opt.nh ? (((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15) : 0;
+    if (!(d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) && P.merged == F::shape.merged &&
+          P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
+    if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return false;
+    const size_t total = F::opt.nh ? F::L.off[L_NH] + nh_bytes : F::L.total;
+    if (total > (size_t)160 * 1024) return false;
+    L = F::L;
+    L.total = (unsigned)total;
+    return true;
+}
+static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o, ObsLayout &L, bool allowed) {
+    static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;   // diagnostic: the runtime carving for every batch
+    P.fix = 0;
+    if (no_fix || !allowed) return;
+    if (obs_fits_fixed<1>(d, P, o, L)) P.fix = 1;
+    else if (obs_fits_fixed<2>(d, P, o, L)) P.fix = 2;
+    else if (obs_fits_fixed<3>(d, P, o, L)) P.fix = 3;
+    else if (obs_fits_fixed<4>(d, P, o, L)) P.fix = 4;
+}
+
+static ObsOptions g_last_options;   // diagnostic (FL_OBS_VERBOSE): the options of the last configuration obs_pick_config chose
+
 // Choose what lives in LDS so that the workgroup fits 160 KiB.
 static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // diagnostic overrides (experiments on the LDS / occupancy trade-off): FL_OBS_NT, FL_OBS_LDS_LIMIT (bytes), FL_OBS_NO_TAB
@@ -167,21 +195,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                             o.items_cap = caps[ck];
                             ObsLayout L = obs_layout(d, P, o);
                             if (L.total > lds_limit) continue;
-                            // a FIXED launch class (compile-time carving, fl_obs_layout.h): the batch fits the class's capacities
-                            // and this choice of options is the class's
-                            static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;
-                            P.fix = 0;
-                            if (!no_fix && P.merged == 1 && !force_nt && lds_limit == (size_t)160 * 1024) {
-                                using F = ObsFixed<1>;
-                                const size_t nh_bytes = ((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15;
-                                if (d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) &&
-                                    P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t &&
-                                    (size_t)d.A * (P.tree_pred + 2) <= (size_t)F::L.items2_cap && F::L.off[L_NH] + nh_bytes <= lds_limit) {
-                                    L = F::L;
-                                    L.total = (unsigned)(F::L.off[L_NH] + nh_bytes);
-                                    P.fix = 1;
-                                }
-                            }
+                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024);
+                            g_last_options = o;
                             P.L = L; P.use_tmask = 1; P.dual_index = 1;
                             P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
                             P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
@@ -223,6 +238,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                 if (Lt.total <= lds_limit) L = Lt;
                                 else if (force.tab == 1) continue;
                             } else if (force.tab == 1) continue;
+                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024);
+                            g_last_options = o;
                             P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
                             P.bk = o.bk_room; P.bk_nb = OBS_BK_NB; P.bk_shift = OBS_BK_SHIFT;
                             // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
@@ -287,6 +304,13 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     FlObsScratch u = o;
     if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
     else u = fl_obs_env_order(o, d, s);
+    switch (P.fix) {   // a fixed launch class: its own kernel (MODE and VAR are the class's)
+    case 1: return fl_obs_launch_f1(d, u, P, s);
+    case 2: return fl_obs_launch_f2(d, u, P, s);
+    case 3: return fl_obs_launch_f3(d, u, P, s);
+    case 4: return fl_obs_launch_f4(d, u, P, s);
+    default: break;
+    }
     return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
 }
 
@@ -310,6 +334,11 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     obs_tree_args(d, P, max_depth, tree_pred, nullptr);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     if (getenv("FL_OBS_VERBOSE")) {   // diagnostic: the carving of the LDS, array by array (enum L_* of fl_obs_layout.h)
+        const ObsOptions &q = g_last_options;
+        fprintf(stderr, "  options {nt %d, wl_bytes %d, tab %d, nh %d, tmask %d, dual %d, items %d, snext %d, partial %d, bk_room %d, own_filter %d, fb %d, raw %d, items_cap %d}; "
+                        "shape {merged %d, tw_c %d, tw_t %d, tpw_t %d, tree_pred %d}; bk %d tshift %d wl_occ_div %d\n",
+                q.nt, q.wl_bytes, q.tab, q.nh, q.tmask, q.dual, q.items, q.snext, q.partial, q.bk_room, q.own_filter, q.fb, q.raw, q.items_cap,
+                P.merged, P.tw_c, P.tw_t, P.tpw_t, P.tree_pred, P.bk, P.tshift, P.wl_occ_div);
         static const char *names[L_COUNT] = {"cellw", "nbr", "snext", "rkey", "slot_agent", "slot_ready", "cell_target", "a_speed", "a_vpos", "a_pos", "a_tslot",
             "a_target", "a_malf", "a_tpc", "a_tq", "a_tq2", "a_raw", "rtype", "a_lp", "a_n", "a_srank", "a_dir", "a_state", "a_free", "a_dead", "misc", "team_meta", "node_tables",
             "csr", "items", "wl", "partial", "tmask", "tmask2", "nh", "csr2", "tmaskb", "tmaskb2", "items2", "a_lp2", "a_tpc2", "bkrel", "seg", "dm", "hop8"};

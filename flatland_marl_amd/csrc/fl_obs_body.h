@@ -1105,22 +1105,22 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     // (not in registers: the kernel sits at its register ceiling, and every scalar that lives through it costs spills)
     if (MODE != 3 && S.order && threadIdx.x == 0) {
         extern __shared__ __align__(16) unsigned char lds[];
-        int *misc = reinterpret_cast<int *>(lds + P.L.off[L_MISC]);
+        int *misc = reinterpret_cast<int *>(lds + (FIX != 0 ? ObsFixed<FIX != 0 ? FIX : 1>::L.off[L_MISC] : P.L.off[L_MISC]));
         misc[62] = obs_env_of_workgroup(S);
         misc[63] = (int)(uint32_t)wall_clock64();
     }
     if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else if (MODE == 3) obs_body<true, VAR, 1, 1, FIX>(d, S, P);
-    else if (MODE == 4) obs_body<true, VAR, 1, 2>(d, S, P);
+    else if (MODE == 4) obs_body<true, VAR, 1, 2, FIX>(d, S, P);
     else {
-        obs_body<true, VAR, 1>(d, S, P);
+        obs_body<true, VAR, 1, 0, FIX>(d, S, P);
         __syncthreads();
-        obs_body<false, VAR, 2>(d, S, P);
+        obs_body<false, VAR, 2, 0, FIX>(d, S, P);
     }
     if (MODE != 3 && S.order && threadIdx.x == 0) {
         extern __shared__ __align__(16) unsigned char lds[];
-        const int *misc = reinterpret_cast<const int *>(lds + P.L.off[L_MISC]);
+        const int *misc = reinterpret_cast<const int *>(lds + (FIX != 0 ? ObsFixed<FIX != 0 ? FIX : 1>::L.off[L_MISC] : P.L.off[L_MISC]));
         S.cost[misc[62]] = (uint32_t)wall_clock64() - (uint32_t)misc[63];
     }
 }

@@ -78,7 +78,7 @@ enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO =
 #define OBS_CAP_T_COMPACT 16
 
 // LDS words of the trees' node tables: one slot per team that can hold an agent plus one dummy slot that the idle teams share
-__host__ __device__ inline int obs_scr_words(int nwaves, int A, int tw_c, int tw_t, int tpw_t) {
+__host__ __device__ constexpr int obs_scr_words(int nwaves, int A, int tw_c, int tw_t, int tpw_t) {
     const int n_c = 2 * nwaves <= A ? 2 * nwaves : A + 1, n_t = tpw_t * nwaves <= A ? tpw_t * nwaves : A + 1;
     const int w_c = n_c * tw_c, w_t = n_t * tw_t;
     return w_c > w_t ? w_c : w_t;
@@ -178,8 +178,33 @@ template <> struct ObsFixed<1> {
     static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
+//   FIX 2: rounds of 32 agents, work lists in LDS (MODE 4, VAR 0): at most 80 agents, 232 rail cells -- cfg3 (BASELINE configs[2])
+//   FIX 3: rounds of 32 agents, work lists in HBM scratch (MODE 4, VAR 2): at most 80 agents, 656 rail cells -- cfg4 (configs[3])
+//   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): at most 400 agents, 2688 rail cells -- cfg5 (configs[4])
+// The LDS of these three is full to the last few hundred bytes (that is how obs_pick_config chose their options), so the classes
+// are the BASELINE maps' own sizes rounded up to a multiple of 8 / 16 rail cells; tests/test_obs_config.py checks that each class
+// IS what obs_pick_config chooses at the class's capacities.
+template <> struct ObsFixed<2> {
+    static constexpr ObsDims dims = {232, 80, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 36 * 1024, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 4096};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<3> {
+    static constexpr ObsDims dims = {656, 80, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 4096};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<4> {
+    static constexpr ObsDims dims = {2688, 400, 0, 0};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+// (the next-hop tables in LDS are the one option a class may differ in from the batch's own choice: nh is the class's)
 __host__ __device__ constexpr bool obs_same_options(const ObsOptions &a, const ObsOptions &b) {
-    return a.nt == b.nt && a.wl_bytes == b.wl_bytes && a.tab == b.tab && a.nh == b.nh && a.tmask == b.tmask && a.dual == b.dual &&
+    return a.nt == b.nt && a.wl_bytes == b.wl_bytes && a.tab == b.tab && (a.nh == b.nh || !b.nh) && a.tmask == b.tmask && a.dual == b.dual &&
            a.items == b.items && a.snext == b.snext && a.partial == b.partial && a.bk_room == b.bk_room &&
            a.own_filter == b.own_filter && a.fb == b.fb && a.raw == b.raw && a.items_cap == b.items_cap;
 }
@@ -216,3 +241,8 @@ int fl_obs_launch_m1(int var, const FlDev &d, const FlObsScratch &o, const ObsAr
 int fl_obs_launch_m2(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_m3(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B, one round
 int fl_obs_launch_m4(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B per round of 32 agents
+// the FIXED launch classes (P.fix = k: MODE and VAR are the class's, the LDS carving is compiled in)
+int fl_obs_launch_f1(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

@@ -10,6 +10,5 @@ static int obs_launch(KernelT kern, const FlDev &d, const FlObsScratch &o, const
 }
 
 int fl_obs_launch_m3(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
-    if (P.fix == 1 && var == 0) return obs_launch(k_obs<3, 0, 1>, d, o, P, s);   // compile-time LDS carving (ObsFixed<1>)
     return var == 1 ? obs_launch(k_obs<3, 1>, d, o, P, s) : var == 2 ? obs_launch(k_obs<3, 2>, d, o, P, s) : obs_launch(k_obs<3, 0>, d, o, P, s);
 }
