@@ -71,6 +71,9 @@ __global__ __launch_bounds__(1024) void k_env_order(int B, const uint32_t *__res
     for (int b = tid; b < B; b += 1024) order[atomicAdd(&hist[1023u - (unsigned int)((unsigned long long)cost[b] * 1023ull / top)], 1u)] = b;
 }
 
+#ifndef OBS_ROUND16_DEFAULT
+#define OBS_ROUND16_DEFAULT 0   // rounds of 16 agents on 512 threads, two workgroups a CU (MODE 5) for envs of more than 32 agents
+#endif
 #ifndef OBS_ORDER_EVERY
 #define OBS_ORDER_EVERY 4   // what an env takes changes slowly from step to step: the order of every fourth launch serves the next three
 #endif
@@ -160,11 +163,17 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     static const bool no_merge = getenv("FL_OBS_NO_MERGE") != nullptr;
     P.merged = 0;
     P.wl_occ_div = OBS_WL_OCC_DIV;
-    if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT) &&
+    // Rounds of 16 agents on 512 threads and at most 80 KB of LDS (MODE 5): a CU then holds TWO workgroups, and one env's barriers
+    // and L2 round trips are filled by the other's issue.  FL_OBS_ROUND16=0 / 1 overrides the default.
+    static const int round16_env = getenv("FL_OBS_ROUND16") ? atoi(getenv("FL_OBS_ROUND16")) : -1;
+    const bool r16 = d.A > 32 && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
+    const int merged_nt = r16 ? 512 : OBS_NT;
+    const size_t merged_limit = r16 ? std::min(lds_limit, (size_t)80 * 1024) : lds_limit;
+    if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
         ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.snext, 1) &&
         (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP) {
-        P.merged = d.A <= 32 ? 1 : 2;
-        o.nt = OBS_NT; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
+        P.merged = d.A <= 32 ? 1 : r16 ? 3 : 2;
+        o.nt = merged_nt; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
         // Order of preference, from same-box sweeps (tools/gpu_env_sweep.sh).  One round (at most 32 agents, cfg2): 24 KB of LDS work
         // lists, the items in LDS, plain lists (the extra counting pass of the bucketed lists costs more than their short scans
         // save: 57.9 against 51.8 us).  Rounds of 32 agents: a round of 64 trees meets thousands of occupied cells, and a work
@@ -177,8 +186,11 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                       {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
         static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
         static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
-        const Pref *prefs = P.merged == 1 ? one_round : rounds;
-        const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : (int)(sizeof rounds / sizeof rounds[0]);
+        // rounds of 16 agents in 80 KB: half the trees a round meet half the cells -- 16 KB of LDS lists, else HBM scratch
+        static const Pref rounds16[] = {{1, 16 * 1024, 1}, {0, 16 * 1024, 1}, {1, 0, 1}, {1, 12 * 1024, 1}, {0, 12 * 1024, 1}, {0, 0, 1}, {1, 16 * 1024, 0}, {1, 0, 0}, {0, 16 * 1024, 0},
+                                        {0, 0, 0}, {0, 8 * 1024, 0}};
+        const Pref *prefs = P.merged == 1 ? one_round : P.merged == 3 ? rounds16 : rounds;
+        const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : P.merged == 3 ? (int)(sizeof rounds16 / sizeof rounds16[0]) : (int)(sizeof rounds / sizeof rounds[0]);
         for (int pk = 0; pk < n_prefs; pk++) {
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
@@ -186,15 +198,15 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             // the own-path filter of the classify loop (a second set of time masks) before the full-size LDS copy of the items: on
             // sparse maps a third of the conflict entries are the walking agent's own prediction (cfg4: 34 %), and an env whose
             // items do not fit the smaller copy scans them in HBM scratch at nearly the same speed
-            static const int caps[2] = {OBS_ITEMS_LDS_CAP, 4096};   // (2048: cfg3 0.86 against 0.77 ms -- most envs' items then sit in HBM)
+            static const int caps[3] = {OBS_ITEMS_LDS_CAP, 4096, 2048};   // (2048: cfg3 0.86 against 0.77 ms -- most envs' items then sit in HBM; only in 80 KB)
             for (o.own_filter = no_own ? 0 : 1; o.own_filter >= 0; o.own_filter--)
-                for (int ck = 0; ck < (o.items ? 2 : 1); ck++)
+                for (int ck = 0; ck < (o.items ? (P.merged == 3 ? 3 : 2) : 1); ck++)
                     for (o.raw = o.own_filter; o.raw >= 0; o.raw--)
                         for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
                             if (!ok(force.nh, o.nh)) continue;
                             o.items_cap = caps[ck];
                             ObsLayout L = obs_layout(d, P, o);
-                            if (L.total > lds_limit) continue;
+                            if (L.total > merged_limit) continue;
                             obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024);
                             g_last_options = o;
                             P.L = L; P.use_tmask = 1; P.dual_index = 1;
@@ -311,7 +323,8 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     case 4: return fl_obs_launch_f4(d, u, P, s);
     default: break;
     }
-    return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
+    return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) :
+           P.merged == 3 ? fl_obs_launch_m5(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
 }
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {

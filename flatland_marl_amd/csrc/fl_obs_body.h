@@ -262,10 +262,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
     X.long_lists = misc + 11;
-    X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = min(t >> tshift, 63)
+    X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = tb_of(t, tshift)
     // one pass B over the trees of both builders (stage 1 of the fused launch): the upstream builder's side of the context
-    constexpr bool merged = MERGED != 0;   // 1: at most 32 agents (one round), 2: rounds of 32 agents
-    X.n_cu = OBS_MERGED_ROUND; X.round_base = 0;
+    constexpr bool merged = MERGED != 0;   // 1: at most 32 agents (one round), 2: rounds of 32 agents, 3: rounds of 16 agents on 512 threads
+    constexpr int ROUND = MERGED == 3 ? 16 : 32;
+    X.n_cu = ROUND; X.round_base = 0;
     X.u_csr_end = csr2; X.u_items = items2; X.u_tmask = tmaskb; X.a_tq2 = a_tq2;
     X.tmask_m2 = merged ? tmask_m2 : nullptr; X.u_tmask_m2 = tmaskb_m2;
     X.path = S.path + (size_t)b * A * S.pred_cap; X.pred_cap = S.pred_cap;
@@ -471,7 +472,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // wavefronts finish at very different times (late_jobs) -- this phase then ends with the last pass A.
     const int n_p1_all = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
     const bool late_p1 = merged && n_p1_all > 0;
-    const int n_up_jobs = merged ? (min(A, OBS_MERGED_ROUND) + 3) / 4 : 0, n_p1_jobs = late_p1 ? 0 : n_p1_all;
+    const int n_up_jobs = merged ? (min(A, ROUND) + 3) / 4 : 0, n_p1_jobs = late_p1 ? 0 : n_p1_all;
     // ... and, last, the -inf pre-fill of the env's upstream rows (see phase 0) in chunks of 16 KB: pure stores that drain beside
     // the latency-bound rest of the phase (no builder writes a row before the trees phase)
     constexpr int PF_CHUNK = 64 * 16;  // double2 per job
@@ -488,7 +489,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (j >= n_up_jobs + n_p1_jobs + n_pf_jobs) break;
             if (j < n_up_jobs) {
                 const int u = 4 * j + (lane >> 4);
-                upstream_pass_a<16, OBS_CAP_T_COMPACT, true, 32>(X, P, b, u, u < A, lane & 15, merged_table_t(wave_scr, min(u, OBS_MERGED_ROUND - 1)), &d.err[b]);
+                upstream_pass_a<16, OBS_CAP_T_COMPACT, true, 32>(X, P, b, u, u < A, lane & 15, merged_table_t<ROUND>(wave_scr, min(u, ROUND - 1)), &d.err[b]);
             } else if (j < n_up_jobs + n_p1_jobs) {
                 const int i = 2 * (j - n_up_jobs) + (lane >> 5);
                 if (i < A) phase1b(i, lane & 31, phase1b_load(i));
@@ -679,7 +680,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 int node_base, levels;
                 const bool have = team_id < A;
                 cutils_pass_a(X, d, P, b, team_id, have, grp, gl,
-                              merged ? merged_table_c(wave_scr, min(team_id, OBS_MERGED_ROUND - 1)) : wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (N_WORDS_C * OBS_CAP_C),
+                              merged ? merged_table_c(wave_scr, min(team_id, ROUND - 1)) : wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (N_WORDS_C * OBS_CAP_C),
                               a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
                               a_raw ? a_raw[(have ? team_id : 0) * 8 + 1] : d.spk[b * A + (have ? team_id : 0)],
                               a_raw ? a_raw[(have ? team_id : 0) * 8 + 2] : d.malf[b * A + (have ? team_id : 0)], node_base, levels);
@@ -956,7 +957,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     if (bb < b1 || bb > b2) continue;
                     const int key = key_of(X, (int)(w >> 2));
                     if (X.tmask && bb == b1) {  // time-mask buckets this item covers (once per item)
-                        const int m1 = min(tlo >> X.tshift, 63), m2 = min(thi >> X.tshift, 63);
+                        const int m1 = tb_of(tlo, X.tshift), m2 = tb_of(thi, X.tshift);
                         atomicOr(&tmask[key], ((2ull << m2) - 1ull) & ~((1ull << m1) - 1ull));
                     }
                     const uint32_t dnext = k < lp ? (wnx & 3u) : (w & 3u), dprev = k > 0 ? (wpv & 3u) : (w & 3u);
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const bool to_end = k == lp || tlo + span - 1 >= tlast;
                 const int key = key_of(X, (int)(w >> 2));
                 if (X.tmask) {  // time buckets this item covers
-                    const int b1 = min(tlo >> X.tshift, 63), b2 = min((to_end ? tlast : tlo + span - 1) >> X.tshift, 63);
+                    const int b1 = tb_of(tlo, X.tshift), b2 = tb_of(to_end ? tlast : tlo + span - 1, X.tshift);
                     const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
                     if (X.tmask_m2) {
                         const unsigned long long seen = atomicOr(&tmask[key], bits);
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
                     const uint32_t dnext2 = k < lp2 ? dnext : (w & 3u);
                     if (P.use_tmask) {
-                        const int b1 = min(tlo2 >> tshift2, 63), b2 = min((to_end2 ? tlast2 : tlo2 + tpc2 - 1) >> tshift2, 63);
+                        const int b1 = tb_of(tlo2, tshift2), b2 = tb_of(to_end2 ? tlast2 : tlo2 + tpc2 - 1, tshift2);
                         const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
                         if (X.tmask_m2) {
                             const unsigned long long seen = atomicOr(&tmaskb[key], bits);
@@ -1077,8 +1078,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (merged) {
-        if (items_in_lds) trees_merged<true, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
-        else trees_merged<false, MERGED == 2>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
+        if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
+        else trees_merged<false, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
@@ -1098,7 +1099,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 }
 
 // MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch (two stages), 3 = both with one pass B per
-// round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents); VAR: see obs_body
+// round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents; 5 = rounds of 16 agents on 512 threads, two
+// workgroups a CU); VAR: see obs_body
 template <int MODE, int VAR, int FIX = 0>
 __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
     // what this env takes goes to S.cost: the next launch starts the longest envs first.  Env and start clock wait in two LDS words
@@ -1113,6 +1115,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else if (MODE == 3) obs_body<true, VAR, 1, 1, FIX>(d, S, P);
     else if (MODE == 4) obs_body<true, VAR, 1, 2, FIX>(d, S, P);
+    else if (MODE == 5) obs_body<true, VAR, 1, 3, FIX>(d, S, P);
     else {
         obs_body<true, VAR, 1, 0, FIX>(d, S, P);
         __syncthreads();

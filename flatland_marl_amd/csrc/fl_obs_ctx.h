@@ -45,11 +45,11 @@ struct ObsCtx {
     bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
     int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
     const int *long_lists;        // LDS flag: some key's list has more than CF_DIRECT items (else no conflict query needs chunks)
-    const unsigned long long *tmask;  // LDS per key: time buckets min(t >> tshift, 63) covered by some item; nullptr = none
+    const unsigned long long *tmask;  // LDS per key: time buckets tb_of(t, tshift) covered by some item; nullptr = none
     int tshift;
     // pass B over the trees of BOTH builders at once (PB = 2): teams below n_cu are flatland_cutils trees and use the members
     // above, the others are upstream trees and use the upstream predictor's index:
-    int n_cu;                     // (= OBS_MERGED_ROUND: teams below are flatland_cutils trees)
+    int n_cu;                     // agents of a round of trees (32, or 16 on 512 threads): the teams below it are flatland_cutils trees
     int round_base;               // first agent of the round of trees being built
     const int *u_csr_end;
     const uint32_t *u_items;
@@ -66,6 +66,12 @@ struct ObsCtx {
     long long *dbg;               // diagnostic builds
     int dbg_base;
 };
+
+// Time bucket of the per-key masks (64 bits a key): equal buckets of 1 << tshift steps and one catch-all for everything later.
+// (Round 4, measured and dropped: a piecewise map -- 2-step buckets to t = 64, 8-step to 192, 16-step to 448 -- instead of the
+// catch-all: 1 to 3 % slower on all four workloads, the longer bucket arithmetic of every classified cell costs more than the
+// late queries it filters save.)
+__device__ __forceinline__ int tb_of(int t, int ts) { return min(t >> ts, 63); }
 
 __device__ __forceinline__ uint32_t cw_bits(const ObsCtx &X, int r) { return X.cellw[r] & 0xFFFFu; }
 // occupied-cell table index of the cell, 0xFFFF = nobody on it and nobody waiting to depart from it

@@ -128,7 +128,8 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
     {
         // trees_merged: 32 flatland_cutils + 32 compact upstream tables a round; else a slot per team + the dummy.  Large maps
         // borrow this space for the per-(key, time bucket) counters while the bucketed index is built (P.bk): room for those too
-        unsigned long long scr = P.merged ? 32ull * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
+        // (a round = one flatland_cutils tree per 32 lanes: 32 agents on 1024 threads, 16 on 512)
+        unsigned long long scr = P.merged ? (unsigned long long)(o.nt / 32) * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
                                           : (unsigned long long)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4;
         const unsigned long long bkc = (R + 1) * OBS_BK_NB * 2 + 4;
         if (o.bk_room && bkc > scr) scr = bkc;
@@ -227,7 +228,8 @@ struct ObsArgs {
     int bk;            // the lists of the cutils index are grouped by time bucket: 1 = large maps (OBS_BK_NB buckets, counted in the node
                        // tables' LDS, offsets in HBM scratch), 2 = small maps (OBS_FB_NB buckets, offsets in LDS: L_BKREL)
     int bk_nb, bk_shift;
-    int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged); 1: one round (at most 32 agents), 2: several
+    int merged;        // fused launch: ONE pass B per round over the trees of both builders (trees_merged); 1: one round (at most 32 agents), 2: rounds
+                       // of 32 agents, 3: rounds of 16 agents on 512 threads (at most 80 KB of LDS: two workgroups a CU)
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it -- or, fix != 0, has the same
@@ -241,6 +243,7 @@ int fl_obs_launch_m1(int var, const FlDev &d, const FlObsScratch &o, const ObsAr
 int fl_obs_launch_m2(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_m3(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B, one round
 int fl_obs_launch_m4(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // both, one pass B per round of 32 agents
+int fl_obs_launch_m5(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);   // the same in rounds of 16 agents on 512 threads (two workgroups a CU)
 // the FIXED launch classes (P.fix = k: MODE and VAR are the class's, the LDS carving is compiled in)
 int fl_obs_launch_f1(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

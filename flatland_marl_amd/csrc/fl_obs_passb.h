@@ -219,15 +219,15 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 // (rail word, successor, time mask, the next node's descriptor when the walk ends here) is requested while the work-list
 // reservation of the current cell is in flight -- about one round trip per cell.
 // Tables: PB 0 / 1: team t's table is scr0 + t * team_words, fields CAP words apart.  PB 2 (both builders, trees_merged): the
-// teams below OBS_MERGED_ROUND are flatland_cutils trees (32 slots, N_WORDS_C fields of 32 words); behind them the compact
+// teams below X.n_cu (the agents of a round) are flatland_cutils trees (32 slots, N_WORDS_C fields of 32 words); behind them the compact
 // upstream trees, TWO to a table of N_WORDS_T fields of 32 words (tree u uses the slots (u & 1) * 16 ... + 15 of every field):
 // the field stride is 32 words for every team, a compile-time constant in the classify loop.
-#define OBS_MERGED_ROUND 32
+// The trees of a round: X.n_cu agents (32 on sixteen wavefronts; 16 on eight -- the 512-thread kernels, two workgroups a CU).
 template <int PB, int CAP>
 __device__ __forceinline__ int *team_table(const ObsCtx &X, int *scr0, int team_words, int team) {
     if (PB == 2) {
-        const int u = team - OBS_MERGED_ROUND;
-        return u < 0 ? scr0 + team * (N_WORDS_C * 32) : scr0 + OBS_MERGED_ROUND * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
+        const int u = team - X.n_cu;
+        return u < 0 ? scr0 + team * (N_WORDS_C * 32) : scr0 + X.n_cu * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
     }
     return scr0 + team * team_words;
 }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 pt = cu ? (int)((float)tot * (float)tq) : (int)((double)tot * tq);
                 if (pt < Tn_t) {
                     if (has_tmask) {  // buckets of the times pt - 1 .. pt + 1: at most three consecutive bits from b1 on
-                        const int b1 = min(max(pt - 1, 0) >> tshift_t, 63), b2 = min(min(pt + 1, Tn_t - 1) >> tshift_t, 63);
+                        const int b1 = tb_of(max(pt - 1, 0), tshift_t), b2 = tb_of(min(pt + 1, Tn_t - 1), tshift_t);
                         unsigned long long others = tm;
                         if (FAST && self_filter && tot >= 1 && tot <= lp_t && (int)(own_w >> 2) == cell) {
                             // this cell is waypoint tot of the walking agent's own path: the buckets of that item (same formulas as
@@ -388,7 +388,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                             const int tlast = Tn_t - 1;
                             const int tlo = cu ? (tot - 1) * tpc_t + 1 : tot * tpc_t, te = tlo + tpc_t - 1;
                             const int thi = (tot == lp_t || te >= tlast) ? tlast : te;
-                            const int o1 = min(tlo >> tshift_t, 63), o2 = min(thi >> tshift_t, 63);
+                            const int o1 = tb_of(tlo, tshift_t), o2 = tb_of(thi, tshift_t);
                             others = (tm & ~(((2ull << o2) - 1ull) & ~((1ull << o1) - 1ull))) | tm2;
                         }
                         cand = ((uint32_t)(others >> b1) & ((2u << (b2 - b1)) - 1u)) != 0u;
@@ -488,7 +488,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             const uint32_t f = R.n > 0 ? conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, R.n) : 0u;
             if (X.dbg) {
                 atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
-                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+                if (tb_of(pt, X.tshift) >= 63) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
                 if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
                 if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
                 if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
@@ -534,7 +534,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down; first chunks only)
             if (X.dbg) {
                 atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
-                if (pt >= (63 << X.tshift)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
+                if (tb_of(pt, X.tshift) >= 63) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 28], 1ull);
                 if (f & 7u) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 29], 1ull);
                 if (conflict_hit(f)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 30], 1ull);
                 if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);

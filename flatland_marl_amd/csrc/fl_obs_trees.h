@@ -398,44 +398,47 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
 // Pass A of the first round ran beside the path walk (obs_body).
 __device__ __forceinline__ int *merged_table_c(int *wave_scr, int t) { return wave_scr + t * (N_WORDS_C * 32); }
 // (two compact upstream trees share a table whose fields are 32 words apart, see team_table)
+template <int ROUND>
 __device__ __forceinline__ int *merged_table_t(int *wave_scr, int u) {
-    return wave_scr + OBS_MERGED_ROUND * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
+    return wave_scr + ROUND * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
 }
-// the upstream tree a lane works on in a merged round: u in [0, 32) or -1
+// the upstream tree a lane works on in a merged round: u in [0, ROUND) or -1
+template <int ROUND>
 __device__ __forceinline__ int merged_upstream_of(int wave, int lane, int nwaves) {
     const int u = (nwaves - 1 - wave) * 4 + (lane >> 4);
-    return u < OBS_MERGED_ROUND ? u : -1;
+    return u < ROUND ? u : -1;
 }
 
 // MULTI = false: an env of at most 32 agents -- one round, whose pass A ran beside the path walk: no pass A code here.
-template <bool ITL, bool MULTI, typename LATE>
+// ROUND = agents of a round = 2 * wavefronts of the workgroup: 32 (1024 threads) or 16 (512 threads, two workgroups a CU).
+template <bool ITL, bool MULTI, int ROUND, typename LATE>
 __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane, int nwaves,
                                              int *wave_scr, int *team_meta, const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot, float max_dist,
                                              const LATE &late) {
     constexpr int CT = OBS_CAP_T_COMPACT;
     const int A = X.A;
-    const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;   // (nwaves = 16: ct covers 0 .. 31)
-    int *scr_c = merged_table_c(wave_scr, min(ct, OBS_MERGED_ROUND - 1));
-    const int u = merged_upstream_of(wave, lane, nwaves), tl = lane & 15;
-    const bool wave_has_u = (nwaves - 1 - wave) * 4 < OBS_MERGED_ROUND;  // wave-uniform
-    int *scr_u = merged_table_t(wave_scr, u < 0 ? 0 : u);
+    const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;   // (ct covers 0 .. ROUND - 1)
+    int *scr_c = merged_table_c(wave_scr, min(ct, ROUND - 1));
+    const int u = merged_upstream_of<ROUND>(wave, lane, nwaves), tl = lane & 15;
+    const bool wave_has_u = (nwaves - 1 - wave) * 4 < ROUND;  // wave-uniform
+    int *scr_u = merged_table_t<ROUND>(wave_scr, u < 0 ? 0 : u);
     const int ns = upstream_slots<true>(P);
-    for (int base = 0; base < (MULTI ? A : 1); base += OBS_MERGED_ROUND) {
+    for (int base = 0; base < (MULTI ? A : 1); base += ROUND) {
         X.round_base = base;
         const int i_c = base + ct, i_u = base + u;
-        const bool have_c = ct < OBS_MERGED_ROUND && i_c < A, have_u = u >= 0 && i_u < A;
+        const bool have_c = ct < ROUND && i_c < A, have_u = u >= 0 && i_u < A;
         int node_base = 1, levels = 0;
         if (!MULTI || base == 0) {  // pass A of the first round already ran beside the path walk
             if (have_c) { node_base = team_meta[64 + ct]; levels = team_meta[192 + ct]; }
         } else {
-            if (ct < OBS_MERGED_ROUND)
+            if (ct < ROUND)
                 cutils_pass_a(X, d, P, b, i_c, have_c, grp, gl, scr_c, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist,
                               d.spk[b * A + (have_c ? i_c : 0)], d.malf[b * A + (have_c ? i_c : 0)], node_base, levels);
             if (wave_has_u) upstream_pass_a<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u, &d.err[b]);
         }
         TREE_STAMP(X, 6);
-        if (ct < OBS_MERGED_ROUND) {
+        if (ct < ROUND) {
             int first;
             const int cells = team_prepare<32, OBS_CAP_C, false>(have_c, gl, have_c ? node_base : 1, scr_c, first);
             if (gl == 0) { team_meta[ct] = have_c ? cells : 0; team_meta[64 + ct] = have_c ? node_base : 1; team_meta[192 + ct] = levels; team_meta[256 + ct] = first; }
@@ -443,13 +446,13 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
         if (wave_has_u) {
             int first;
             const int cells = team_prepare<16, CT, true, 32>(have_u, tl, have_u ? ns : 1, scr_u, first);
-            const int id = OBS_MERGED_ROUND + (u < 0 ? 0 : u);
+            const int id = ROUND + (u < 0 ? 0 : u);
             if (u >= 0 && tl == 0) { team_meta[id] = have_u ? cells : 0; team_meta[64 + id] = have_u ? ns : 1; team_meta[256 + id] = first; }
         }
-        wg_pass_b<2, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, 2 * OBS_MERGED_ROUND, wave_scr, 0, team_meta, late);
+        wg_pass_b<2, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, 2 * ROUND, wave_scr, 0, team_meta, late);
         if (base == 0) late();  // (whatever the queue still holds)
         TREE_STAMP(X, 7);
-        if (ct < OBS_MERGED_ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
+        if (ct < ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
         if (wave_has_u) upstream_rows<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u);
         team_sync();
         TREE_STAMP(X, 16);

@@ -445,3 +445,102 @@ class BatchedRailEnv:
 
     def algorithmic_bytes_per_agent_step(self, with_cutils_obs=True, tree_depth=0):
         return float(lib().fl_algorithmic_bytes_per_agent_step(self.h, int(with_cutils_obs), int(tree_depth)))
+
+
+class MixedBatch:
+    """Envs of DIFFERENT shapes stepped together: the reference's evaluator runs tests of different map sizes and agent counts
+    back to back (solution/debug-environments/parameters_flatland_round_2_new.csv: 30x30 / 7 agents ... 158x158 / 425 agents).
+    A C-ABI handle holds envs of one (A, H, W); this groups any list of env descriptions by shape into one handle per shape,
+    each on a HIP stream of its own (kernels of different shapes overlap on the GPU), and keeps the caller's env order.
+
+    env i lives in group `self.where[i][0]` at batch index `self.where[i][1]`; the per-group tensors are what BatchedRailEnv
+    returns, `pick(i, tensors)` gives env i's slice of a per-group result list."""
+
+    def __init__(self, envs, device=0, max_nodes=31, pred_depth=500):
+        import torch
+        self.torch = torch
+        shapes, self.where = {}, []
+        for e in envs:
+            H, W = np.asarray(e["grid"]).shape
+            key = (int(len(e["init_dir"])), int(H), int(W))
+            g = shapes.setdefault(key, [])
+            self.where.append((key, len(g)))
+            g.append(e)
+        self.keys = list(shapes)
+        self.where = [(self.keys.index(k), b) for k, b in self.where]
+        self.streams, self.groups = [], []
+        for k in self.keys:
+            s = torch.cuda.Stream(device=torch.device("cuda", device))
+            with torch.cuda.stream(s):
+                self.groups.append(BatchedRailEnv(shapes[k], device=device, max_nodes=max_nodes, pred_depth=pred_depth))
+            self.streams.append(s)
+        self.n = len(envs)
+
+    def _each(self, fn):
+        out = []
+        for g, s in zip(self.groups, self.streams):
+            with self.torch.cuda.stream(s):
+                out.append(fn(g))
+        return out
+
+    def pick(self, i, per_group):
+        g, b = self.where[i]
+        r = per_group[g]
+        if isinstance(r, dict):
+            return {k: v[b] for k, v in r.items()}
+        if isinstance(r, tuple):
+            return tuple(self.pick_one(x, b) for x in r)
+        return r[b]
+
+    @staticmethod
+    def pick_one(x, b):
+        return {k: v[b] for k, v in x.items()} if isinstance(x, dict) else (None if x is None else x[b])
+
+    def step(self, actions, auto_reset=False, filter_required=False):
+        """actions: one uint8 array [A_i] per env (255 = agent not in the dict), in the caller's env order"""
+        per = [np.full((g.B, g.A), ACTION_ABSENT, dtype=np.uint8) for g in self.groups]
+        for i, a in enumerate(actions):
+            g, b = self.where[i]
+            per[g][b] = np.asarray(a, dtype=np.uint8)
+        res = []
+        for k, (g, s) in enumerate(zip(self.groups, self.streams)):
+            with self.torch.cuda.stream(s):
+                res.append(g.step(per[k], auto_reset=auto_reset, filter_required=filter_required))
+        return res
+
+    def step_synth(self, seed, kind=0, auto_reset=True):
+        """the on-device action stream; env i uses stream id i (its index in the caller's order)"""
+        k0 = 0
+        res = []
+        for k, (g, s) in enumerate(zip(self.groups, self.streams)):
+            with self.torch.cuda.stream(s):
+                res.append(g.step_synth(seed, k0, kind, auto_reset=auto_reset))
+            k0 += g.B
+        return res
+
+    def obs_cutils(self):
+        return self._each(lambda g: g.obs_cutils())
+
+    def obs_both(self, max_depth=2, pred_depth=30):
+        return self._each(lambda g: g.obs_both(max_depth, pred_depth))
+
+    def state(self, i):
+        g, b = self.where[i]
+        st, el = self.groups[g].state()
+        return st[b], int(el[b])
+
+    def metrics(self):
+        """int64[4] on the host: the sums over all groups (what a multi-GPU harness all-reduces)"""
+        return sum(g.metrics().cpu().numpy() for g in self.groups)
+
+    def check(self):
+        for g in self.groups:
+            g.check()
+
+    def sync(self):
+        for g in self.groups:
+            g.sync()
+
+    def close(self):
+        for g in self.groups:
+            g.close()

@@ -268,3 +268,34 @@ def test_grid_with_a_three_way_cell_matches_the_reference(name, fused):
         if tree2 is not None:
             np.testing.assert_array_equal(tree2.cpu().numpy()[0], fx["py_d2_p30"][t], err_msg=f"t={t} depth-2 tree")
     env.check()
+
+
+def test_mixed_shapes_step_together_like_their_golden_episodes():
+    """MixedBatch: envs of different (agents, height, width) -- the reference evaluates the Round-2 tests of different sizes back to
+    back -- grouped into one handle per shape on streams of their own; every env follows its own golden episode (state, rewards,
+    observations), whatever its neighbours in the list are."""
+    from flatland_marl_amd.hip_backend import MixedBatch
+    names = ["cfg1_sparse", "cfg2_fwd", "cfg3_uniform", "cfg1_malf50", "cfg0_tall_uniform", "cfg2_uniform"]
+    fxs = [util.load(n) for n in names]
+    mb = MixedBatch([util.static_of(fx) for fx in fxs])
+    assert len(mb.groups) == 4 and sorted(g.B for g in mb.groups) == [1, 1, 2, 2]      # 30x30/7 twice, 30x30/20 twice, 35x30/80, 40x26/20
+    acts = [util.actions_of(fx) for fx in fxs]
+    obs_steps = [{int(t): k for k, t in enumerate(fx["obs_steps"])} for fx in fxs]
+    n_obs = 0
+    for t in range(150):
+        res = mb.step([a[t] for a in acts])
+        o = mb.obs_cutils()
+        for i, fx in enumerate(fxs):
+            st, el = mb.state(i)
+            np.testing.assert_array_equal(st, util.golden_state(fx, t), err_msg=f"{names[i]} step {t}")
+            rew = mb.pick(i, res)[0].cpu().numpy()
+            np.testing.assert_array_equal(rew, fx["s_reward"][t], err_msg=f"{names[i]} rewards, step {t}")
+            if (t + 1) in obs_steps[i]:
+                k = obs_steps[i][t + 1]
+                mine = mb.pick(i, o)
+                np.testing.assert_array_equal(mine["forest"].cpu().numpy(), fx["o_forest"][k], err_msg=f"{names[i]} forest, step {t}")
+                np.testing.assert_array_equal(mine["agent_attr"].cpu().numpy(), fx["o_attr"][k], err_msg=f"{names[i]} attr, step {t}")
+                n_obs += 1
+    mb.check()
+    assert n_obs > 40
+    mb.close()
