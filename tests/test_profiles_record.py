@@ -1,15 +1,17 @@
 """CPU: the profiles of record under profiles/ are complete and consistent with each other -- every workload has its rocprofv3
 kernel summary, its bench line and its PMC traffic entry from ONE build (the same kernel-source stamp), and the default bench
-line carries what the measurement contract asks for.  (Whether the stamp still matches the sources in the tree is for bench.py to
-say at run time: `roofline.traffic` is null when it does not.)"""
+line carries what the measurement contract asks for -- and that build IS the tree's: the stamp of the stored PMC traffic equals
+the hash of the kernel sources here (a kernel change without new profiles of record fails this test; bench.py reports
+`roofline.traffic` from the stored measurement only under the same condition)."""
 import csv
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3")
-TAG = "r03"
+WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3", "cfg4_d2_distinct4", "cfg5_d3_distinct2")   # the last two: distinct generated maps
+TAG = "r04"
 
 
 def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
@@ -31,6 +33,10 @@ def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
         assert t["write_size_kib"] * 1024 > 0.9 * line["roofline"]["algorithmic_bytes_per_launch"]
         stamps.add(t["kernel_source_sha"])
     assert len(stamps) == 1, stamps
+    # ... and that build is this tree's (the stored traffic is stale otherwise: re-run tools/round_artefacts.sh)
+    sys.path.insert(0, ROOT)
+    import bench
+    assert stamps == {bench.kernel_source_sha()}, "profiles of record are from other kernel sources than the tree's"
 
 
 def test_default_bench_line_of_record_keeps_the_contract():
@@ -44,5 +50,6 @@ def test_default_bench_line_of_record_keeps_the_contract():
     assert r["traffic"] is not None and r["traffic"] >= r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["cpu_model"] and c["sample"]
+    assert c["cores"] == c["physical_cores"] <= c["threads"]      # one worker per PHYSICAL core is the stated figure
     # whole-job throughput and time per step belong together: B * A agent-steps per step
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 256 * 20) < 1.0

@@ -8,7 +8,8 @@ and pmc_traffic.json (per workload and kernel: mean FETCH_SIZE / WRITE_SIZE per 
 2 * FETCH_SIZE + WRITE_SIZE KiB -- on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads; the factor is an
 upper bound for narrow gathers -- stamped with the sha of the kernel sources).  Copy what is to be judged into profiles/.
 
-  python tools/profile_workloads.py r02 [cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild]
+  python tools/profile_workloads.py r02 [cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild cfg4:2:distinct4 cfg5:3:rebuild:distinct2]
+(":distinctK": K distinct generated maps instead of the committed base envs -- key <W>_d<D>_distinctK)
 """
 import collections
 import csv
@@ -23,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha only; nothing touches the GPU at import)
 
-NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_obs<3": "k_obs<cutils+tree>", "k_obs<4": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
+NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_obs<3": "k_obs<cutils+tree>", "k_obs<4": "k_obs<cutils+tree>",
+         "k_obs<5": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
          "k_distance_map": "k_distance_map", "k_hop8": "k_hop8", "k_nexthop": "k_nexthop", "k_segments": "k_segments"}
 tag = sys.argv[1]
 specs = sys.argv[2:] or ["cfg2:2", "cfg3:3", "cfg4:2", "cfg5:3:rebuild"]
@@ -57,12 +59,15 @@ def pmc_mean(tmp, counter):
 
 for spec in specs:
     parts = spec.split(":")
-    w, depth, rebuild = parts[0], int(parts[1]), len(parts) > 2
-    key = "%s_d%d" % (w, depth)
+    w, depth, rebuild = parts[0], int(parts[1]), "rebuild" in parts[2:]
+    distinct = next((int(x[len("distinct"):]) for x in parts[2:] if x.startswith("distinct")), 0)
+    key = "%s_d%d" % (w, depth) + ("_distinct%d" % distinct if distinct else "")
     steps = {"cfg2": 300, "cfg3": 100, "cfg4": 100, "cfg5": 60}[w]
     bargs = ["--no-cpu-baseline", "--no-extra-workloads", "--workload", w, "--tree-depth", str(depth), "--steps", str(steps), "--warmup", "20"]
     if rebuild:
         bargs.append("--dm-rebuild")
+    if distinct:
+        bargs += ["--distinct-maps", str(distinct)]
     tmp = "/tmp/prof_%s_%d" % (key, os.getpid())
     p = run(["--kernel-trace", "--stats", "--output-format", "csv"], bargs, tmp)
     stats = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)

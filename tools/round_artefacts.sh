@@ -6,7 +6,7 @@ set -uo pipefail
 tag=$1
 out=gpurun_out/prof_$tag
 mkdir -p $out
-python tools/profile_workloads.py $tag > $out/profile_workloads.log 2>&1 || tail -5 $out/profile_workloads.log
+python tools/profile_workloads.py $tag cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild cfg4:2:distinct4 cfg5:3:rebuild:distinct2 > $out/profile_workloads.log 2>&1 || tail -5 $out/profile_workloads.log
 echo "[artefacts] traces + traffic done"
 A="--no-extra-workloads --steps 100"
 python tools/pmc_pass.py $out/sq1.json "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" $A > /dev/null 2>&1 || echo "sq pass 1 failed"
