@@ -458,8 +458,9 @@ int fl_reset(fl_batch *h, const uint8_t *mask, int fresh) {
 
 int fl_reset_dev(fl_batch *h, const uint8_t *mask_dev, int fresh) {
     NEED_COMMIT(h);
+    // (the observation side keeps no state of its own across steps: the sticky deadlock flags live in the agents' packed word and
+    // are cleared by k_reset -- flatland_cutils rebuilds its DeadlockChecker in TreeObsForRailEnv::reset(), treeobs.cpp:22-28)
     fl_launch_reset(h->d, mask_dev, fresh, h->stream);
-    fl_obs_reset(h->obs, h->d, mask_dev, h->stream);
     HIPCHK(hipGetLastError());
     return FL_OK;
 }

@@ -23,7 +23,6 @@ struct FlObsScratch {
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);
-void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                          hipStream_t s);

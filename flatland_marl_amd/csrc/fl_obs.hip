@@ -1,6 +1,8 @@
-// fl_obs.hip -- host side of the observation kernels: scratch allocation, the carving of the LDS (obs_layout), the choice of
-// what a launch keeps there (obs_pick_config) and the three launch entry points.  The kernels are in fl_obs_m{0,1,2}.hip
-// (fl_obs_body.h and the phase-level headers it includes: fl_obs_ctx.h, fl_obs_passb.h, fl_obs_trees.h).
+// fl_obs.hip -- host side of the observation kernels: scratch allocation, the choice of what a launch keeps in LDS
+// (obs_pick_config; the carving itself is obs_layout_c in fl_obs_layout.h, shared with the kernels), the fixed launch classes
+// and the three launch entry points.  The kernels are in fl_obs_m0 ... m5.hip (one unit per MODE) and fl_obs_f1 ... f4.hip (one
+// per fixed launch class), all instantiating fl_obs_body.h and the phase-level headers it includes (fl_obs_ctx.h,
+// fl_obs_passb.h, fl_obs_trees.h).
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
@@ -83,12 +85,6 @@ FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s) {
     if (off || d.B <= o.n_cu) { u.order = nullptr; return u; }
     if (o.order_age++ % OBS_ORDER_EVERY == 0) hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, s, d.B, o.cost, o.order);
     return u;
-}
-
-void fl_obs_reset(FlObsScratch &o, const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    // the sticky deadlock flags live in pk and are cleared by the agent reset kernel (flatland_cutils rebuilds its
-    // DeadlockChecker in TreeObsForRailEnv::reset(), treeobs.cpp:22-28 / loader.cpp:207-219)
-    (void)o; (void)d; (void)mask_dev; (void)s;
 }
 
 // carve the dynamic LDS of a launch (obs_layout_c in fl_obs_layout.h: one function for the host and for the kernels with a

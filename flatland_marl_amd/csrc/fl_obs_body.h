@@ -53,6 +53,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     using FixT = ObsFixed<FIX != 0 ? FIX : 1>;
 #define L_OFF(which) (FIX != 0 ? FixT::L.off[which] : P.L.off[which])
 #define L_FIELD(f) (FIX != 0 ? FixT::L.f : P.L.f)
+    // ... and so is what obs_pick_config derives from the class's options for ObsArgs (the launcher sets the same values in P)
+    const int p_bk = FIX != 0 ? (MERGED != 0 ? (FixT::opt.fb ? 2 : 0) : FixT::opt.bk_room) : P.bk;
+    const int p_bk_nb = FIX != 0 ? (MERGED != 0 ? OBS_FB_NB : OBS_BK_NB) : P.bk_nb, p_bk_shift = FIX != 0 ? (MERGED != 0 ? OBS_FB_SHIFT : OBS_BK_SHIFT) : P.bk_shift;
+    const bool p_use_tmask = FIX != 0 ? FixT::opt.tmask != 0 : P.use_tmask != 0, p_dual_index = FIX != 0 ? FixT::opt.dual != 0 : P.dual_index != 0;
+    const bool p_compact_t = FIX != 0 ? true : P.compact_t != 0;   // (every class's shape has the compact upstream tables)
+    const int p_wl_occ_div = FIX != 0 ? ((FIX == 2 || FIX == 3) ? 3 : OBS_WL_OCC_DIV) : P.wl_occ_div;
 #define LDS_AT(T, which) reinterpret_cast<T *>(lds + L_OFF(which))
 #define LDS_OPT(T, which) (L_OFF(which) == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L_OFF(which)))
     uint32_t *cellw = LDS_AT(uint32_t, L_CELLW);  // rail bitmap | occupied-cell table index << 16
@@ -155,7 +161,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             a_srank[i] = d.srank[g];
             a_tpc[i] = CUTILS ? (uint16_t)(int)(1.0f / (float)speed) : (uint16_t)(int)(1.0 / speed);
             a_tq[i] = CUTILS ? (double)(float)(1.0 / (double)(float)speed) : 1.0 / speed;
-            if (CUTILS && STAGE == 1 && P.dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
+            if (CUTILS && STAGE == 1 && p_dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
         }
         {
             const uint16_t *grg = d.rgrid + (size_t)b * Rcap;
@@ -252,13 +258,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.a_tpc = a_tpc; X.a_tq = a_tq; X.a_tslot = a_tslot; X.a_target = a_target; X.a_srank = a_srank;
     uint32_t *csr_items = S.cell_items + (size_t)b * S.items_cap;
     X.csr_end = csr; X.items_lds = nullptr; X.items_glb = csr_items; X.bk_rel = nullptr; X.bk_rel_lds = nullptr; X.bk_base = nullptr; X.bk_k1 = 0;
-    X.bk_nb = P.bk_nb; X.bk_shift = P.bk_shift;
+    X.bk_nb = p_bk_nb; X.bk_shift = p_bk_shift;
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
-    X.tmask = (P.use_tmask && X.Tn > 0) ? tmask : nullptr;
+    X.tmask = (p_use_tmask && X.Tn > 0) ? tmask : nullptr;
     X.wl_hbm = WL_HBM;
     X.wl_occ = WL_HBM ? S.wl + (size_t)b * S.wl_cap : reinterpret_cast<uint2 *>(wl_lds);
-    X.wl_occ_cap = X.tmask ? wl_entries / P.wl_occ_div : wl_entries;  // a share of the entries
+    X.wl_occ_cap = X.tmask ? wl_entries / p_wl_occ_div : wl_entries;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
     X.long_lists = misc + 11;
@@ -525,15 +531,15 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (X.Tn > 0) {
         // fused launch: stage 1 builds the upstream predictor's index too (same paths, one pass over the waypoints); stage 2
         // then starts at its trees.  misc[4] tells stage 2 that the second index is complete.
-        const bool dual = CUTILS && STAGE == 1 && P.dual_index != 0 && P.tree_pred >= 0;
-        const bool reuse = STAGE == 2 && P.dual_index != 0 && misc[4] != 0;
+        const bool dual = CUTILS && STAGE == 1 && p_dual_index && P.tree_pred >= 0;
+        const bool reuse = STAGE == 2 && p_dual_index && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
         // large maps: bucketed lists (OBS_BK_NB).  Their per-(key, bucket) counters -- u16, two per word -- live in the node
         // tables' LDS while the index is built (so no tree work is hoisted beside the walk), the offsets go to HBM afterwards
         // (P.bk 1).  Small maps (P.bk 2): finer buckets, counters and offsets in an LDS array of their own.
-        const bool bk = CUTILS && STAGE != 2 && P.bk != 0 && X.Tn > 64 && X.tmask != nullptr;
-        const bool bk_lds = bk && P.bk == 2;
-        const int bk_nb = P.bk_nb, bk_shift = P.bk_shift;
+        const bool bk = CUTILS && STAGE != 2 && p_bk != 0 && X.Tn > 64 && X.tmask != nullptr;
+        const bool bk_lds = bk && p_bk == 2;
+        const int bk_nb = p_bk_nb, bk_shift = p_bk_shift;
         // counters / offsets per key: bk_nb time buckets; with LDS-resident offsets also the bucket of the items that stay until the
         // end of the horizon (a path's last waypoint -- no copies of it in every later time bucket) and a padding entry
         const int bk_w = bk_lds ? bk_nb + 2 : bk_nb;
@@ -544,7 +550,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (X.tmask) for (int k = tid; k <= K; k += nt) { tmask[k] = 0ull; if (X.tmask_m2) tmask_m2[k] = 0ull; }
             if (bk) for (int k = tid; k < (bk_lds ? K * bk_w / 2 : ((K + 1) * bk_nb + 1) / 2); k += nt) bkc[k] = 0u;
         }
-        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (P.use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
+        if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (p_use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
@@ -844,7 +850,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         __syncthreads();
         if (reuse) {  // stage 1 built this index
             csr = csr2; X.csr_end = csr2; X.items_lds = items2;
-            X.tmask = P.use_tmask ? tmaskb : nullptr;
+            X.tmask = p_use_tmask ? tmaskb : nullptr;
             if (!X.tmask) { X.wl_occ_cap = wl_entries; X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = 0; }
         }
         if (bk_lds) {  // counts of a key's buckets -> their start offsets inside the key's list (bumped to the ends by the fill)
@@ -1033,7 +1039,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const int tlo2 = k * tpc2, tlast2 = Tn2 - 1;
                     const bool to_end2 = k == lp2 || tlo2 + tpc2 - 1 >= tlast2;
                     const uint32_t dnext2 = k < lp2 ? dnext : (w & 3u);
-                    if (P.use_tmask) {
+                    if (p_use_tmask) {
                         const int b1 = tb_of(tlo2, tshift2), b2 = tb_of(to_end2 ? tlast2 : tlo2 + tpc2 - 1, tshift2);
                         const unsigned long long bits = ((2ull << b2) - 1ull) & ~((1ull << b1) - 1ull);
                         if (X.tmask_m2) {
@@ -1083,7 +1089,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
-    } else if (P.compact_t) {
+    } else if (p_compact_t) {
         if (items_in_lds) tree_upstream<16, OBS_CAP_T_COMPACT, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
         else tree_upstream<16, OBS_CAP_T_COMPACT, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
     } else if (P.max_depth <= 2) {

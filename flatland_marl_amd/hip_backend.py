@@ -304,7 +304,8 @@ class BatchedRailEnv:
     def scores(self, reset=False):
         """float64[3] device tensor: (sum of normalized rewards, sum of completion ratios, episodes) over the episodes finished
         since the counters were reset -- the evaluator's mean_normalized_reward / mean_percentage_complete as sums
-        (flatland/evaluators/service.py:875-879, 900-913).  Call it before metrics(reset=True): the episode count is that counter."""
+        (flatland/evaluators/service.py:875-879, 900-913).  The episode count is the scores' own counter, reset with the sums
+        (independent of metrics(reset=True))."""
         if not hasattr(self, "_scores"):
             self._scores = self.torch.zeros(3, dtype=self.torch.float64, device=self.device)
         _chk(lib().fl_scores(self.h, self._scores.data_ptr(), int(reset)))

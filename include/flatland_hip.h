@@ -160,7 +160,9 @@ int fl_metrics(fl_batch *h, int64_t *out4_dev, int reset);
  * (flatland/evaluators/service.py:875-879, 900-913: mean_normalized_reward = mean over episodes of 1 + sum(rewards) / (T * A),
  * mean_percentage_complete = mean over episodes of arrived / A), as sums a multi-GPU harness can all-reduce:
  * out3_dev float64[3] (device) = (sum of normalized rewards, sum of completion ratios, episodes).  The per-episode terms
- * are accumulated on the device in double precision in episode order per env and summed over the envs in env order. */
+ * are accumulated on the device in double precision in episode order per env and summed over the envs in env order; the episode
+ * count is the scores' OWN counter (incremented where the sums are, reset with them): resetting fl_metrics and fl_scores at
+ * different times never mixes windows. */
 int fl_scores(fl_batch *h, double *out3_dev, int reset);
 /* Synchronise and return the first error any kernel recorded (FL_OK if none); clears it. */
 int fl_check(fl_batch *h);

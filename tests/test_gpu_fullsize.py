@@ -86,17 +86,17 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         s_env.check()
 
 
-def _cfg4_digest(steps=24):
-    """sha256 over the state, rewards and both observations of every step of the full cfg4 shard"""
+def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2):
+    """sha256 over the state, rewards and both observations of every step of the full cfg4 shard (or of another workload)"""
     import hashlib
     from flatland_marl_amd import workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
-    envs, seed = wl.make_envs("cfg4", B=512, distinct=4)
+    envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
     env = BatchedRailEnv(envs)
     h = hashlib.sha256()
     for t in range(steps):
         rew, done, done_all = env.step_synth(seed, 0, 2, auto_reset=True)      # dense traffic: envs of very different cost
-        o, tree = env.obs_both(2, 30)
+        o, tree = env.obs_both(depth, 30)
         h.update(env.state()[0].tobytes())
         h.update(rew.cpu().numpy().tobytes())
         for k in sorted(o):
@@ -120,5 +120,29 @@ def test_workgroup_order_does_not_change_the_results_at_cfg4():
     assert _cfg4_digest() == plain
 
 
+def test_other_launch_paths_give_the_same_bytes():
+    """The launcher's alternative paths, each selected by an environment switch that is read once per process (hence children):
+    the runtime LDS carving instead of the fixed launch classes (FL_OBS_NO_FIX) and the 512-thread kernel in rounds of 16 agents,
+    two workgroups a CU (FL_OBS_ROUND16, MODE 5) -- on cfg3 (depth 3) and cfg2 (depth 2) batches in dense traffic.  Same bytes
+    as the default path."""
+    import os
+    import subprocess
+    import sys
+    from tests import util
+    cases = {"cfg3": dict(steps=60, workload="cfg3", B=24, distinct=3, depth=3), "cfg2": dict(steps=80, workload="cfg2", B=16, distinct=4, depth=2)}
+    want = {k: _cfg4_digest(**kw) for k, kw in cases.items()}
+    for switch in ("FL_OBS_NO_FIX", "FL_OBS_ROUND16"):
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "paths"], env=dict(os.environ, PYTHONPATH=util.ROOT, **{switch: "1"}),
+                               capture_output=True, text=True, timeout=900)
+        assert child.returncode == 0, child.stderr[-2000:]
+        got = dict(ln.split()[1:3] for ln in child.stdout.splitlines() if ln.startswith("DIGEST "))
+        assert got == want, switch
+
+
 if __name__ == "__main__":
-    print("DIGEST", _cfg4_digest())
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "paths":
+        print("DIGEST cfg3", _cfg4_digest(steps=60, workload="cfg3", B=24, distinct=3, depth=3))
+        print("DIGEST cfg2", _cfg4_digest(steps=80, workload="cfg2", B=16, distinct=4, depth=2))
+    else:
+        print("DIGEST", _cfg4_digest())
