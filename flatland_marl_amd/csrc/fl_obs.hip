@@ -103,6 +103,8 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
     if (!(d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) && P.merged == F::shape.merged &&
           P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
     if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return false;
+    // the class's kernel has the builders' parameters compiled in
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred) return false;
     const size_t total = F::opt.nh ? F::L.off[L_NH] + nh_bytes : F::L.total;
     if (total > (size_t)160 * 1024) return false;
     L = F::L;
@@ -203,7 +205,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                             o.items_cap = caps[ck];
                             ObsLayout L = obs_layout(d, P, o);
                             if (L.total > merged_limit) continue;
-                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024);
+                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0);
                             g_last_options = o;
                             P.L = L; P.use_tmask = 1; P.dual_index = 1;
                             P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
@@ -246,7 +248,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                 if (Lt.total <= lds_limit) L = Lt;
                                 else if (force.tab == 1) continue;
                             } else if (force.tab == 1) continue;
-                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024);
+                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0);
                             g_last_options = o;
                             P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
                             P.bk = o.bk_room; P.bk_nb = OBS_BK_NB; P.bk_shift = OBS_BK_SHIFT;
@@ -339,6 +341,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11]) {
     ObsArgs P = {};
     P.pred_depth = pred_depth;
+    P.max_nodes = 31;   // (the solution's tree size; the fixed launch classes are for exactly that)
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, nullptr);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;

@@ -40,7 +40,16 @@
 __device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return __builtin_amdgcn_readfirstlane(S.order ? S.order[blockIdx.x] : (int)blockIdx.x); }
 
 template <bool CUTILS, int VAR, int STAGE, int MERGED = 0, int FIX = 0>
-__device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
+__device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P_launch) {
+    // A fixed launch class also fixes the builders' parameters (BASELINE's: 31 nodes, predictor depths 500 / 30): the launcher only
+    // takes the class for exactly these, the kernel has them as constants (a local copy the compiler takes apart; no memory).
+    using FixT = ObsFixed<FIX != 0 ? FIX : 1>;
+    ObsArgs P_local = P_launch;
+    if (FIX != 0) {
+        P_local.max_nodes = FixT::max_nodes; P_local.pred_depth = FixT::pred_depth; P_local.tree_pred = FixT::shape.tree_pred;
+        P_local.tshift = FIX == 1 ? (d.A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT;
+    }
+    const ObsArgs &P = P_local;
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
     const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = blockDim.x;
@@ -50,7 +59,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 
     extern __shared__ __align__(16) unsigned char lds[];
     // FIX != 0: the carving is ObsFixed<FIX>::L, a compile-time constant (every base below folds into an immediate)
-    using FixT = ObsFixed<FIX != 0 ? FIX : 1>;
 #define L_OFF(which) (FIX != 0 ? FixT::L.off[which] : P.L.off[which])
 #define L_FIELD(f) (FIX != 0 ? FixT::L.f : P.L.f)
     // ... and so is what obs_pick_config derives from the class's options for ObsArgs (the launcher sets the same values in P)

@@ -173,6 +173,7 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 //   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells -- cfg1, cfg2 (BASELINE configs[0..1])
 template <int FIX> struct ObsFixed;
 template <> struct ObsFixed<1> {
+    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr ObsDims dims = {256, 32, 0, 0};
     static constexpr ObsShape shape = {1, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     //                                  nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap
@@ -186,18 +187,21 @@ template <> struct ObsFixed<1> {
 // are the BASELINE maps' own sizes rounded up to a multiple of 8 / 16 rail cells; tests/test_obs_config.py checks that each class
 // IS what obs_pick_config chooses at the class's capacities.
 template <> struct ObsFixed<2> {
+    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr ObsDims dims = {232, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 36 * 1024, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 4096};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<3> {
+    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr ObsDims dims = {656, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 4096};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<4> {
+    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr ObsDims dims = {2688, 400, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
