@@ -12,7 +12,7 @@
 #include "fl_obs_layout.h"
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs) {
-    o.pred_cap = FL_OBS_MAX_PRED + 2;
+    o.pred_cap = OBS_PRED_CAP;
     o.items_cap = (size_t)d.A * (o.pred_cap + 2 * OBS_FB_NB + 2);  // bucketed lists: an item sits in every time bucket it touches
     const size_t BA = (size_t)d.B * d.A;
     void *p = nullptr;

@@ -52,7 +52,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const ObsArgs &P = P_local;
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
-    const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = blockDim.x;
+    // (every fixed launch class runs on OBS_NT threads: the strides of the workgroup-wide loops are constants there)
+    const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = FIX != 0 ? OBS_NT : (int)blockDim.x;
     const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
@@ -98,7 +99,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint32_t *items_lds = LDS_OPT(uint32_t, L_ITEMS);
     uint32_t *wl_lds = WL_HBM ? nullptr : LDS_AT(uint32_t, L_WL);  // pass B work lists; scratch of the key scan before that
     int *partial = (WL_HBM || L_OFF(L_PARTIAL) != L_ABSENT) ? LDS_AT(int, L_PARTIAL) : reinterpret_cast<int *>(wl_lds);
-    const int wl_entries = WL_HBM ? S.wl_cap : L_FIELD(wl_bytes) / 8;
+    const int wl_entries = WL_HBM ? OBS_WL_HBM_ENTRIES : L_FIELD(wl_bytes) / 8;
     unsigned long long *tmask = LDS_OPT(unsigned long long, L_TMASK);
     uint16_t *nh_lds = LDS_OPT(uint16_t, L_NH);
     // second index (fused launch): keys, masks, items and per-agent last waypoint of the upstream predictor
@@ -271,7 +272,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (p_use_tmask && X.Tn > 0) ? tmask : nullptr;
     X.wl_hbm = WL_HBM;
-    X.wl_occ = WL_HBM ? S.wl + (size_t)b * S.wl_cap : reinterpret_cast<uint2 *>(wl_lds);
+    X.wl_occ = WL_HBM ? S.wl + (size_t)b * OBS_WL_HBM_ENTRIES : reinterpret_cast<uint2 *>(wl_lds);
     X.wl_occ_cap = X.tmask ? wl_entries / p_wl_occ_div : wl_entries;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
     X.wl_cnt = misc + 8;
@@ -283,7 +284,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.n_cu = ROUND; X.round_base = 0;
     X.u_csr_end = csr2; X.u_items = items2; X.u_tmask = tmaskb; X.a_tq2 = a_tq2;
     X.tmask_m2 = merged ? tmask_m2 : nullptr; X.u_tmask_m2 = tmaskb_m2;
-    X.path = S.path + (size_t)b * A * S.pred_cap; X.pred_cap = S.pred_cap;
+    X.path = S.path + (size_t)b * A * OBS_PRED_CAP; X.pred_cap = OBS_PRED_CAP;
     X.a_lp = a_lp; X.a_lp2 = a_lp2; X.a_tpc2 = a_tpc2;
     X.u_Tn = P.tree_pred + 1; X.u_tshift = X.u_Tn <= 64 ? 0 : P.tshift;
 
@@ -586,7 +587,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int i = base + wsel * 8 + slot;
             const bool have = i < A;
             const int ia = have ? i : 0;
-            uint16_t *path = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            uint16_t *path = S.path + ((size_t)b * A + ia) * OBS_PRED_CAP;
             const int u = a_tslot[ia];
             uint32_t st = ((uint32_t)a_vpos[ia] << 2) | a_dir[ia];
             bool alive = have && j < n_max;
@@ -718,7 +719,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                               // touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp)); four waypoints per lane a round trip
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
-                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const uint16_t *path = S.path + ((size_t)b * A + i) * OBS_PRED_CAP;
                 const int lp = a_lp[i];
                 const int tpc = a_tpc[i], tlast = X.Tn - 1;
                 for (int k0 = lane; k0 <= lp; k0 += 256) {
@@ -752,7 +753,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             }
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
-                const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+                const uint16_t *path = S.path + ((size_t)b * A + i) * OBS_PRED_CAP;
                 const int lp = a_lp[i];
                 for (int k = lane; k <= lp; k += 64) atomicAdd(&csr[key_of(X, (int)(path[k] >> 2))], 1);
             }
@@ -898,7 +899,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         uint32_t pfv[FU] = {0, 0, 0, 0}, pfn[FU] = {0, 0, 0, 0}, pfp[FU] = {0, 0, 0, 0};
         auto prefetch = [&](int ia) __attribute__((always_inline)) {
             if (reuse || ia >= A) return;
-            const uint16_t *pth = S.path + ((size_t)b * A + ia) * S.pred_cap;
+            const uint16_t *pth = S.path + ((size_t)b * A + ia) * OBS_PRED_CAP;
             const int lpn = a_lp[ia];
 #pragma unroll
             for (int q = 0; q < FU; q++) {
@@ -954,7 +955,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     }
                     n_i = lo_a;
                     n_k = (int)klo16[lo_a] + (t - (int)pre16[lo_a]);
-                    const uint16_t *pth = S.path + ((size_t)b * A + lo_a) * S.pred_cap;
+                    const uint16_t *pth = S.path + ((size_t)b * A + lo_a) * OBS_PRED_CAP;
                     const int lp = a_lp[lo_a];
                     nv = pth[n_k]; nn = pth[min(n_k + 1, lp)]; np = pth[max(n_k - 1, 0)];
                 };
@@ -986,7 +987,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         prefetch(bk_major ? A : wave);
         for (int i = wave; !reuse && !bk_major && i < A; i += (nt >> 6)) {
-            const uint16_t *path = S.path + ((size_t)b * A + i) * S.pred_cap;
+            const uint16_t *path = S.path + ((size_t)b * A + i) * OBS_PRED_CAP;
             const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
             uint32_t wv[FU], wnx[FU], wpv[FU];

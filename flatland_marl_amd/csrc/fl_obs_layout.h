@@ -28,6 +28,7 @@
 #define OBS_ITEMS_LDS_CAP 6144       // prediction items are kept in LDS when an env has at most this many (else HBM scratch)
 #endif
 #define OBS_WL_HBM_ENTRIES 32768     // pass B work-list entries per env when the lists live in HBM scratch (large maps)
+#define OBS_PRED_CAP (FL_OBS_MAX_PRED + 2)   // waypoints kept per agent in the path scratch (FlObsScratch::pred_cap: a constant of the build)
 // Large maps (items in HBM, hundreds of agents): the items are grouped by bucket of 64 time steps and laid out BUCKET-major (all
 // items of bucket 0 by key, then bucket 1, ...: a bucket's share of an env's items stays in the L2 while it is written), an item
 // sits in every bucket its interval touches, and a conflict query reads the key's items of the one or two buckets its three time
