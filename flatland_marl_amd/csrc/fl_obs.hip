@@ -104,7 +104,8 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
           P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
     if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return false;
     // the class's kernel has the builders' parameters compiled in
-    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred) return false;
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return false;
+    if (F::agents != 0 && d.A != F::agents) return false;
     const size_t total = F::opt.nh ? F::L.off[L_NH] + nh_bytes : F::L.total;
     if (total > (size_t)160 * 1024) return false;
     L = F::L;

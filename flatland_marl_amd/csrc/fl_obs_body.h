@@ -48,13 +48,15 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (FIX != 0) {
         P_local.max_nodes = FixT::max_nodes; P_local.pred_depth = FixT::pred_depth; P_local.tree_pred = FixT::shape.tree_pred;
         P_local.tshift = FIX == 1 ? (d.A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT;
+        P_local.max_depth = FixT::max_depth;
+        P_local.n_tree_nodes = FixT::max_depth == 2 ? 21 : 85;   // (4^(depth + 1) - 1) / 3
     }
     const ObsArgs &P = P_local;
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
     // (every fixed launch class runs on OBS_NT threads: the strides of the workgroup-wide loops are constants there)
     const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = FIX != 0 ? OBS_NT : (int)blockDim.x;
-    const int A = d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
+    const int A = (FIX != 0 && FixT::agents != 0) ? FixT::agents : d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
 

@@ -171,38 +171,44 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 // host (obs_pick_config) takes a class when the batch fits its capacities AND its own choice of options is the class's; any
 // other batch runs the same kernel with the runtime layout (FIX 0).  The next-hop tables (sized by the unique targets) come last
 // in the carving: their base is fixed, their size is the batch's.
-//   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells -- cfg1, cfg2 (BASELINE configs[0..1])
+// A class is a BASELINE configuration: besides the capacities it fixes the builders' parameters (31 nodes, predictor depths 500 / 30,
+// the upstream tree's depth) and, for the larger ones, the exact number of agents -- all constants in its kernel.
+//   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells, depth 2 -- cfg1, cfg2 (BASELINE configs[0..1])
 template <int FIX> struct ObsFixed;
 template <> struct ObsFixed<1> {
-    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int agents = 0;   // agents per env, exactly (0 = any number up to dims.A)
     static constexpr ObsDims dims = {256, 32, 0, 0};
     static constexpr ObsShape shape = {1, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     //                                  nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap
     static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
-//   FIX 2: rounds of 32 agents, work lists in LDS (MODE 4, VAR 0): at most 80 agents, 232 rail cells -- cfg3 (BASELINE configs[2])
-//   FIX 3: rounds of 32 agents, work lists in HBM scratch (MODE 4, VAR 2): at most 80 agents, 656 rail cells -- cfg4 (configs[3])
-//   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): at most 400 agents, 2688 rail cells -- cfg5 (configs[4])
+//   FIX 2: rounds of 32 agents, work lists in LDS (MODE 4, VAR 0): 80 agents, at most 232 rail cells, depth 3 -- cfg3 (BASELINE configs[2])
+//   FIX 3: rounds of 32 agents, work lists in HBM scratch (MODE 4, VAR 2): 80 agents, at most 656 rail cells, depth 2 -- cfg4 (configs[3])
+//   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): 400 agents, at most 2688 rail cells, depth 3 -- cfg5 (configs[4])
 // The LDS of these three is full to the last few hundred bytes (that is how obs_pick_config chose their options), so the classes
 // are the BASELINE maps' own sizes rounded up to a multiple of 8 / 16 rail cells; tests/test_obs_config.py checks that each class
 // IS what obs_pick_config chooses at the class's capacities.
 template <> struct ObsFixed<2> {
-    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 3;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int agents = 80;   // agents per env, exactly (0 = any number up to dims.A)
     static constexpr ObsDims dims = {232, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 36 * 1024, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 4096};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<3> {
-    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int agents = 80;   // agents per env, exactly (0 = any number up to dims.A)
     static constexpr ObsDims dims = {656, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 4096};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<4> {
-    static constexpr int max_nodes = 31, pred_depth = 500;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 3;   // the builders' parameters of the class (tree_pred: shape)
+    static constexpr int agents = 400;   // agents per env, exactly (0 = any number up to dims.A)
     static constexpr ObsDims dims = {2688, 400, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};

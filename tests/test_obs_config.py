@@ -37,7 +37,8 @@ def _sizes(workload):
     ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
     ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=2)),
     ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=3)),
-    ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=4)),
+    ("cfg3", 2, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=0)),   # not BASELINE's depth: runtime carving
+    ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=0)),
     ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=4)),   # round 2: 512 threads (85-slot tables)
 ])
 def test_observation_launch_configuration_of_the_bench_workloads(workload, depth, expect):
@@ -76,7 +77,8 @@ def test_fixed_launch_class_boundaries():
     assert _config(32, 257, 8, 2)["fix"] == 0 and _config(32, 257, 8, 2)["merged"] == 1
     assert _config(33, 200, 8, 2)["fix"] == 0
     assert _config(20, 213, 5, 2, tall=1)["fix"] == 0
-    assert _config(20, 213, 5, 3)["fix"] == 1                 # depth 3 of the upstream tree: same tables, same class
+    assert _config(20, 213, 5, 3)["fix"] == 0                 # depth 3 of the upstream tree: not the class's (BASELINE: depth 2)
+    assert _config(79, 200, 7, 3)["fix"] == 0                 # classes 2 - 4 are for exactly 80 / 80 / 400 agents
     assert _config(20, 213, 5, 2, tree_pred=60)["fix"] == 0   # 20 * 62 items of the second index exceed the class's 1024
     got = _config(20, 213, 20, 2)
     assert got["fix"] == 1 and got["lds"] <= 160 * 1024      # the next-hop tables (last in the carving) at the batch's size
