@@ -54,8 +54,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const ObsArgs &P = P_local;
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
     // (the one-round kernel of small envs is never ordered: its env index stays the workgroup id the hardware hands over)
-    // (every fixed launch class runs on OBS_NT threads: the strides of the workgroup-wide loops are constants there)
-    const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x, nt = FIX != 0 ? OBS_NT : (int)blockDim.x;
+    // (every fixed launch class and every one-pass kernel runs on a known number of threads -- obs_pick_config launches MODE 3 / 4 on
+    // OBS_NT, MODE 5 on 512: the strides of the workgroup-wide loops are constants there)
+    const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x,
+              nt = (FIX != 0 || MERGED == 1 || MERGED == 2) ? OBS_NT : MERGED == 3 ? 512 : (int)blockDim.x;
     const int A = (FIX != 0 && FixT::agents != 0) ? FixT::agents : d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;
@@ -65,6 +67,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #define L_OFF(which) (FIX != 0 ? FixT::L.off[which] : P.L.off[which])
 #define L_FIELD(f) (FIX != 0 ? FixT::L.f : P.L.f)
     // ... and so is what obs_pick_config derives from the class's options for ObsArgs (the launcher sets the same values in P)
+    // (the same folding for the runtime-carving one-pass kernels, whose launches always have masks / second index / compact tables,
+    // measured in the static code only: two spilled VECTOR registers in k_obs<4,2,0> -- not done)
     const int p_bk = FIX != 0 ? (MERGED != 0 ? (FixT::opt.fb ? 2 : 0) : FixT::opt.bk_room) : P.bk;
     const int p_bk_nb = FIX != 0 ? (MERGED != 0 ? OBS_FB_NB : OBS_BK_NB) : P.bk_nb, p_bk_shift = FIX != 0 ? (MERGED != 0 ? OBS_FB_SHIFT : OBS_BK_SHIFT) : P.bk_shift;
     const bool p_use_tmask = FIX != 0 ? FixT::opt.tmask != 0 : P.use_tmask != 0, p_dual_index = FIX != 0 ? FixT::opt.dual != 0 : P.dual_index != 0;
