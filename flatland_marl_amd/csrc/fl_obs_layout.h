@@ -7,8 +7,14 @@
 #include "fl_obs.h"
 
 #define OBS_NT 1024
-#ifndef CF_CHUNK
-#define CF_CHUNK 16                  // items of a key's list scanned per conflict work-list entry
+// items of a key's list scanned per conflict work-list entry: 16 where the items sit in LDS, 8 where they sit in HBM scratch (there the
+// whole chunk is requested at once, and a lane that waits for 16 scattered words waits longer than two lanes for 8 each -- same-box
+// A/B round 4: cfg4 0.356 -> 0.341 ms, cfg5 1.352 -> 1.306 ms with 8; cfg3, items in LDS, 0.656 -> 0.670 ms with 8 and 0.700 with 24)
+#ifndef CF_CHUNK_LDS
+#define CF_CHUNK_LDS 16
+#endif
+#ifndef CF_CHUNK_HBM
+#define CF_CHUNK_HBM 8
 #endif
 #ifndef OBS_GLB_BATCH
 #define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch

@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
     // one after the other)
     if (ITL) scan(second ? X.u_items : X.items_lds, std::integral_constant<int, 8>());
     else if (second) scan(X.u_items, std::integral_constant<int, 8>());      // (the second index is always LDS-resident)
-    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK>());  // chunked work-list entries: the whole chunk in flight at once
+    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK_HBM>());  // chunked work-list entries: the whole chunk in flight at once
     else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
     return flags;
 }
@@ -507,6 +507,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         __syncthreads();
         return;
     }
+    constexpr int CF_CHUNK = ITL ? CF_CHUNK_LDS : CF_CHUNK_HBM;
     // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone.  Every lane scans the FIRST chunk of
     // its entry right away (with lists grouped by time bucket that is the whole list of most queries: no second look at the entry,
     // its offsets and its flag word -- which are HBM round trips on large maps); a longer list pushes an entry per further chunk,
