@@ -509,8 +509,13 @@ class MixedBatch:
                 res.append(g.step(per[k], auto_reset=auto_reset, filter_required=filter_required))
         return res
 
+    def stream_of(self, i):
+        """stream id of env i in the on-device action stream of step_synth (groups in order, envs of a group consecutive)"""
+        g, b = self.where[i]
+        return sum(x.B for x in self.groups[:g]) + b
+
     def step_synth(self, seed, kind=0, auto_reset=True):
-        """the on-device action stream; env i uses stream id i (its index in the caller's order)"""
+        """the on-device action stream; env i uses stream id stream_of(i)"""
         k0 = 0
         res = []
         for k, (g, s) in enumerate(zip(self.groups, self.streams)):
