@@ -385,6 +385,7 @@ int fl_commit(fl_batch *h) {
         int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
         if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
     }
+    h->obs.h_R = h->h_R.data();   // (host copy: which envs fit a fixed launch class, fl_obs.hip)
     d.max_branch = 0;
     for (int b = 0; b < B; b++) d.max_branch = std::max(d.max_branch, h->h_maxbr[b]);
     // (re)build the host tables of every env loaded since the last commit and upload them; the device tables of exactly
@@ -836,6 +837,15 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
 extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out11) {
     NEED_COMMIT(h);
     return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11);
+}
+
+// diagnostic (not part of the public header): what the last fused observation launch (fl_obs_cutils_tree / fl_step_obs with a tree)
+// of this handle ran -- out[0] fixed launch class (0 = the runtime-carving kernel), out[1] 1 = the class's split kernel (the class's
+// body only for the envs that fit it), out[2] envs that took the class's body
+extern "C" int fl_debug_last_obs_class(fl_batch *h, int *out3) {
+    if (!h || !out3) return FL_ERR_ARG;
+    out3[0] = h->obs.last_fix; out3[1] = h->obs.last_split; out3[2] = h->obs.last_fit;
+    return FL_OK;
 }
 
 // diagnostic (not part of the public header), no GPU needed: the same for a batch of the given sizes -- agents, rail-cell and

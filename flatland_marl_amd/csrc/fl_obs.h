@@ -20,6 +20,9 @@ struct FlObsScratch {
     int *order;        // [B] env of workgroup k, longest first (k_env_order), or null: env k (batches of at most one env per CU)
     int n_cu;          // CUs of the device
     unsigned order_age;  // ordered launches so far: the order is recomputed every OBS_ORDER_EVERY-th (host side)
+    const int *h_R;    // HOST [B] rail cells of every env (the handle's copy; null: unknown) -- which envs of a batch fit a fixed launch class
+    int last_fix, last_split, last_fit;  // host side, diagnostic: class of the last fused launch (0 = runtime carving), whether the class
+                                         // served only the envs that fit it, and how many envs took the class's body
 };
 
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);

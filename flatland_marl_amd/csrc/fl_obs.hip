@@ -106,6 +106,8 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
     // the class's kernel has the builders' parameters compiled in
     if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return false;
     if (F::agents != 0 && d.A != F::agents) return false;
+    // ... and what the launcher derives from the options (the kernel has the class's values: obs_fixed_* in fl_obs_layout.h)
+    if (!P.compact_t || P.bk != obs_fixed_bk<FIX>() || P.wl_occ_div != obs_fixed_wl_occ_div<FIX>() || P.tshift != obs_fixed_tshift<FIX>(d.A)) return false;
     const size_t total = F::opt.nh ? F::L.off[L_NH] + nh_bytes : F::L.total;
     if (total > (size_t)160 * 1024) return false;
     L = F::L;
@@ -114,12 +116,47 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
 }
 static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o, ObsLayout &L, bool allowed) {
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;   // diagnostic: the runtime carving for every batch
-    P.fix = 0;
+    P.fix = 0; P.split = 0;
     if (no_fix || !allowed) return;
     if (obs_fits_fixed<1>(d, P, o, L)) P.fix = 1;
     else if (obs_fits_fixed<2>(d, P, o, L)) P.fix = 2;
     else if (obs_fits_fixed<3>(d, P, o, L)) P.fix = 3;
     else if (obs_fits_fixed<4>(d, P, o, L)) P.fix = 4;
+}
+
+static bool g_fix_allowed = false;  // the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
+// A batch whose LARGEST map exceeds a class's rail cells still has the class's kind of envs in it (the levels of a Round-2 test differ
+// by a few per cent in rail cells; the classes are the BASELINE maps' own sizes): when everything but the rail-cell capacity matches
+// -- agents, builder parameters, and the runtime configuration just chosen for the batch runs the class's MODE and VAR -- the launch
+// takes the class's SPLIT kernel: per workgroup the class's body for an env that fits, the runtime-carving body (P.L, unchanged) for
+// the others.  h_R: the host's copy of the envs' rail cells (null: unknown, no split).  Returns the number of envs that fit.
+static int obs_var(const ObsArgs &P);
+template <int FIX>
+static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R) {
+    using F = ObsFixed<FIX>;
+    if (!h_R || F::opt.nh) return 0;   // (class 1 keeps the next-hop tables, sized by the batch, behind its carving: not split)
+    if ((F::agents != 0 ? d.A != F::agents : d.A > F::dims.A) || d.rkey != nullptr || !P.compact_t) return 0;
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return 0;
+    if (P.merged != F::shape.merged || obs_var(P) != obs_fixed_var<FIX>() || P.L.nt != F::opt.nt) return 0;
+    if (P.tw_c != F::shape.tw_c || P.tw_t != F::shape.tw_t || P.tpw_t != F::shape.tpw_t) return 0;
+    if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return 0;
+    if (F::L.total > (size_t)160 * 1024) return 0;
+    int n = 0;
+    for (int b = 0; b < d.B; b++) n += h_R[b] <= F::dims.Rcap;
+    return n;
+}
+static int obs_take_split_class(const FlDev &d, ObsArgs &P, const int *h_R) {
+    static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr, no_split = getenv("FL_OBS_NO_SPLIT") != nullptr;   // diagnostic
+    if (no_fix || no_split || !g_fix_allowed || P.fix != 0) return 0;
+    int n = 0, k = 0;
+    unsigned total = 0;
+    if ((n = obs_split_fits<2>(d, P, h_R)) > 0) { k = 2; total = ObsFixed<2>::L.total; }
+    else if ((n = obs_split_fits<3>(d, P, h_R)) > 0) { k = 3; total = ObsFixed<3>::L.total; }
+    else if ((n = obs_split_fits<4>(d, P, h_R)) > 0) { k = 4; total = ObsFixed<4>::L.total; }
+    if (k == 0) return 0;
+    P.fix = k; P.split = 1;
+    if (total > P.L.total) P.L.total = total;   // dynamic LDS of the launch: the larger of the two carvings
+    return n;
 }
 
 static ObsOptions g_last_options;   // diagnostic (FL_OBS_VERBOSE): the options of the last configuration obs_pick_config chose
@@ -165,13 +202,14 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // Rounds of 16 agents on 512 threads and at most 80 KB of LDS (MODE 5): a CU then holds TWO workgroups, and one env's barriers
     // and L2 round trips are filled by the other's issue.  FL_OBS_ROUND16=0 / 1 overrides the default.
     static const int round16_env = getenv("FL_OBS_ROUND16") ? atoi(getenv("FL_OBS_ROUND16")) : -1;
-    const bool r16 = d.A > 32 && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
+    // (FL_OBS_ROUND16=2: also for envs of 17 .. 32 agents -- two rounds instead of the one-round kernel, for batches of more envs than CUs)
+    const bool r16 = (d.A > 32 || (d.A > 16 && round16_env == 2)) && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
     const int merged_nt = r16 ? 512 : OBS_NT;
     const size_t merged_limit = r16 ? std::min(lds_limit, (size_t)80 * 1024) : lds_limit;
     if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
         ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.snext, 1) &&
         (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP) {
-        P.merged = d.A <= 32 ? 1 : r16 ? 3 : 2;
+        P.merged = r16 ? 3 : d.A <= 32 ? 1 : 2;
         o.nt = merged_nt; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
         // Order of preference, from same-box sweeps (tools/gpu_env_sweep.sh).  One round (at most 32 agents, cfg2): 24 KB of LDS work
         // lists, the items in LDS, plain lists (the extra counting pass of the bucketed lists costs more than their short scans
@@ -188,8 +226,10 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         // rounds of 16 agents in 80 KB: half the trees a round meet half the cells -- 16 KB of LDS lists, else HBM scratch
         static const Pref rounds16[] = {{1, 16 * 1024, 1}, {0, 16 * 1024, 1}, {1, 0, 1}, {1, 12 * 1024, 1}, {0, 12 * 1024, 1}, {0, 0, 1}, {1, 16 * 1024, 0}, {1, 0, 0}, {0, 16 * 1024, 0},
                                         {0, 0, 0}, {0, 8 * 1024, 0}};
-        const Pref *prefs = P.merged == 1 ? one_round : P.merged == 3 ? rounds16 : rounds;
-        const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : P.merged == 3 ? (int)(sizeof rounds16 / sizeof rounds16[0]) : (int)(sizeof rounds / sizeof rounds[0]);
+        // ... of small envs (17 .. 32 agents, two rounds): plain lists like the one-round kernel, so that the own-path filter fits too
+        static const Pref rounds16_small[] = {{0, 16 * 1024, 1}, {0, 12 * 1024, 1}, {1, 16 * 1024, 1}, {0, 0, 1}, {0, 16 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
+        const Pref *prefs = P.merged == 1 ? one_round : P.merged == 3 ? (d.A <= 32 ? rounds16_small : rounds16) : rounds;
+        const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : P.merged == 3 ? (d.A <= 32 ? (int)(sizeof rounds16_small / sizeof rounds16_small[0]) : (int)(sizeof rounds16 / sizeof rounds16[0])) : (int)(sizeof rounds / sizeof rounds[0]);
         for (int pk = 0; pk < n_prefs; pk++) {
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
@@ -206,13 +246,15 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                             o.items_cap = caps[ck];
                             ObsLayout L = obs_layout(d, P, o);
                             if (L.total > merged_limit) continue;
-                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0);
                             g_last_options = o;
-                            P.L = L; P.use_tmask = 1; P.dual_index = 1;
+                            P.use_tmask = 1; P.dual_index = 1;
                             P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
                             P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
                             // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
                             P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
+                            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
+                            obs_take_fixed_class(d, P, o, L, g_fix_allowed);
+                            P.L = L;
                             return true;
                         }
         }
@@ -249,13 +291,15 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                                 if (Lt.total <= lds_limit) L = Lt;
                                 else if (force.tab == 1) continue;
                             } else if (force.tab == 1) continue;
-                            obs_take_fixed_class(d, P, o, L, !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0);
                             g_last_options = o;
-                            P.L = L; P.use_tmask = o.tmask; P.dual_index = o.dual;
+                            P.use_tmask = o.tmask; P.dual_index = o.dual;
                             P.bk = o.bk_room; P.bk_nb = OBS_BK_NB; P.bk_shift = OBS_BK_SHIFT;
                             // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
                             // whole horizon measured slower on every map size)
                             P.tshift = force_tshift >= 0 ? force_tshift : OBS_TSHIFT;
+                            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
+                            obs_take_fixed_class(d, P, o, L, g_fix_allowed);
+                            P.L = L;
                             return true;
                         }
             }
@@ -270,8 +314,8 @@ static void obs_verbose(const ObsArgs &P) {
     const ObsLayout &L = P.L;
     if (verbose && printed < 4) {
         printed++;
-        fprintf(stderr, "[fl_obs] fixed launch class %d, %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d, one pass B for both builders %d, compact upstream trees %d, bucketed index %d\n",
-                P.fix, L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT, P.merged, P.compact_t, P.bk);
+        fprintf(stderr, "[fl_obs] fixed launch class %d%s, %d threads, %u B LDS: static tables in LDS %d, next-hop in LDS %d, successor table %d, work lists %d B, time masks %d, second index %d, items in LDS %d, one pass B for both builders %d, compact upstream trees %d, bucketed index %d\n",
+                P.fix, P.split ? " (split: the envs that fit it)" : "", L.nt, L.total, L.tab_lds, L.off[L_NH] != L_ABSENT, L.off[L_SNEXT] != L_ABSENT, L.wl_bytes, P.use_tmask, P.dual_index, L.off[L_ITEMS] != L_ABSENT, P.merged, P.compact_t, P.bk);
     }
 }
 static int obs_var(const ObsArgs &P) { return P.L.tab_lds ? 1 : P.L.wl_bytes == 0 ? 2 : 0; }
@@ -296,6 +340,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);
     return fl_obs_launch_m0(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }
@@ -311,10 +356,20 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    const int n_split = obs_take_split_class(d, P, o.h_R);
+    o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
     obs_verbose(P);
     FlObsScratch u = o;
     if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
     else u = fl_obs_env_order(o, d, s);
+    if (P.split) {   // the class for the envs that fit it, the runtime carving for the others: one kernel, the choice per workgroup
+        switch (P.fix) {
+        case 2: return fl_obs_launch_s2(d, u, P, s);
+        case 3: return fl_obs_launch_s3(d, u, P, s);
+        case 4: return fl_obs_launch_s4(d, u, P, s);
+        default: return FL_ERR_ARG;
+        }
+    }
     switch (P.fix) {   // a fixed launch class: its own kernel (MODE and VAR are the class's)
     case 1: return fl_obs_launch_f1(d, u, P, s);
     case 2: return fl_obs_launch_f2(d, u, P, s);
@@ -333,6 +388,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.dbg = o.dbg;
     obs_tree_args(d, P, max_depth, pred_depth, out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);
     return fl_obs_launch_m1(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }

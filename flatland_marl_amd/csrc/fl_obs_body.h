@@ -47,7 +47,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     ObsArgs P_local = P_launch;
     if (FIX != 0) {
         P_local.max_nodes = FixT::max_nodes; P_local.pred_depth = FixT::pred_depth; P_local.tree_pred = FixT::shape.tree_pred;
-        P_local.tshift = FIX == 1 ? (d.A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT;
+        P_local.tshift = obs_fixed_tshift<FIX != 0 ? FIX : 1>(d.A);
         P_local.max_depth = FixT::max_depth;
         P_local.n_tree_nodes = FixT::max_depth == 2 ? 21 : 85;   // (4^(depth + 1) - 1) / 3
     }
@@ -69,11 +69,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // ... and so is what obs_pick_config derives from the class's options for ObsArgs (the launcher sets the same values in P)
     // (the same folding for the runtime-carving one-pass kernels, whose launches always have masks / second index / compact tables,
     // measured in the static code only: two spilled VECTOR registers in k_obs<4,2,0> -- not done)
-    const int p_bk = FIX != 0 ? (MERGED != 0 ? (FixT::opt.fb ? 2 : 0) : FixT::opt.bk_room) : P.bk;
+    const int p_bk = FIX != 0 ? obs_fixed_bk<FIX != 0 ? FIX : 1>() : P.bk;
     const int p_bk_nb = FIX != 0 ? (MERGED != 0 ? OBS_FB_NB : OBS_BK_NB) : P.bk_nb, p_bk_shift = FIX != 0 ? (MERGED != 0 ? OBS_FB_SHIFT : OBS_BK_SHIFT) : P.bk_shift;
     const bool p_use_tmask = FIX != 0 ? FixT::opt.tmask != 0 : P.use_tmask != 0, p_dual_index = FIX != 0 ? FixT::opt.dual != 0 : P.dual_index != 0;
     const bool p_compact_t = FIX != 0 ? true : P.compact_t != 0;   // (every class's shape has the compact upstream tables)
-    const int p_wl_occ_div = FIX != 0 ? ((FIX == 2 || FIX == 3) ? 3 : OBS_WL_OCC_DIV) : P.wl_occ_div;
+    const int p_wl_occ_div = FIX != 0 ? obs_fixed_wl_occ_div<FIX != 0 ? FIX : 1>() : P.wl_occ_div;
 #define LDS_AT(T, which) reinterpret_cast<T *>(lds + L_OFF(which))
 #define LDS_OPT(T, which) (L_OFF(which) == L_ABSENT ? (T *)nullptr : reinterpret_cast<T *>(lds + L_OFF(which)))
     uint32_t *cellw = LDS_AT(uint32_t, L_CELLW);  // rail bitmap | occupied-cell table index << 16
@@ -1122,8 +1122,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 // MODE 0 = flatland_cutils outputs, 1 = upstream dense tree, 2 = both in one launch (two stages), 3 = both with one pass B per
 // round (MERGED: 3 = envs of at most 32 agents, one round; 4 = rounds of 32 agents; 5 = rounds of 16 agents on 512 threads, two
 // workgroups a CU); VAR: see obs_body
-template <int MODE, int VAR, int FIX = 0>
-__global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) {
+template <int MODE, int VAR, int FIX>
+__device__ __forceinline__ void obs_kernel_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     // what this env takes goes to S.cost: the next launch starts the longest envs first.  Env and start clock wait in two LDS words
     // (not in registers: the kernel sits at its register ceiling, and every scalar that lives through it costs spills)
     if (MODE != 3 && S.order && threadIdx.x == 0) {
@@ -1147,4 +1147,16 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
         const int *misc = reinterpret_cast<const int *>(lds + (FIX != 0 ? ObsFixed<FIX != 0 ? FIX : 1>::L.off[L_MISC] : P.L.off[L_MISC]));
         S.cost[misc[62]] = (uint32_t)wall_clock64() - (uint32_t)misc[63];
     }
+}
+template <int MODE, int VAR, int FIX = 0>
+__global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs P) { obs_kernel_body<MODE, VAR, FIX>(d, S, P); }
+
+// A batch whose largest map exceeds a class's rail cells (P.split): the workgroup looks at ITS env -- the class's body (compile-time
+// carving) when the env fits the class, the runtime-carving body (P.L) otherwise; one launch, one order of the workgroups.  The
+// class's capacities bound what its carving holds per env (R, K <= dims.Rcap); the HBM strides are the batch's (d.Rcap) either way.
+template <int MODE, int VAR, int FIX>
+__global__ __launch_bounds__(OBS_NT) void k_obs_split(FlDev d, FlObsScratch S, ObsArgs P) {
+    const int b = MODE == 3 ? (int)blockIdx.x : obs_env_of_workgroup(S);
+    if (d.R[b] <= ObsFixed<FIX>::dims.Rcap) obs_kernel_body<MODE, VAR, FIX>(d, S, P);
+    else obs_kernel_body<MODE, VAR, 0>(d, S, P);
 }

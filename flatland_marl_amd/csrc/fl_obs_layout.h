@@ -220,6 +220,14 @@ template <> struct ObsFixed<4> {
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
+// what obs_pick_config derives from a class's options for ObsArgs: ONE definition for the kernel (which has them as constants) and
+// for the host (obs_fits_fixed only takes the class when its own derivation for the batch gives the same values)
+template <int FIX> __host__ __device__ constexpr int obs_fixed_bk() { return ObsFixed<FIX>::shape.merged != 0 ? (ObsFixed<FIX>::opt.fb ? 2 : 0) : ObsFixed<FIX>::opt.bk_room; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (FIX == 2 || FIX == 3) ? 3 : OBS_WL_OCC_DIV; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return FIX == 1 ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
+// kernel of a class: MODE 3 (one round) / 4 (rounds of 32 agents) / 2 (two stages), VAR 1 (static tables in LDS) / 2 (work lists in HBM scratch) / 0
+template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() { return ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : 2; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_var() { return ObsFixed<FIX>::opt.tab ? 1 : ObsFixed<FIX>::opt.wl_bytes == 0 ? 2 : 0; }
 // (the next-hop tables in LDS are the one option a class may differ in from the batch's own choice: nh is the class's)
 __host__ __device__ constexpr bool obs_same_options(const ObsOptions &a, const ObsOptions &b) {
     return a.nt == b.nt && a.wl_bytes == b.wl_bytes && a.tab == b.tab && (a.nh == b.nh || !b.nh) && a.tmask == b.tmask && a.dual == b.dual &&
@@ -249,6 +257,9 @@ struct ObsArgs {
                        // of 32 agents, 3: rounds of 16 agents on 512 threads (at most 80 KB of LDS: two workgroups a CU)
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
+    int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
+                       // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving
+                       // body with L below; 0: every env of the launch fits the class
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it -- or, fix != 0, has the same
                        // carving compiled in)
 };
@@ -266,3 +277,7 @@ int fl_obs_launch_f1(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hi
 int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+// the same classes for a batch with larger maps among its envs (P.split): per env the class's body or the runtime-carving one
+int fl_obs_launch_s2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_s3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_s4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

@@ -94,6 +94,7 @@ def lib():
         L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
         L.fl_distance_map_rebuild.argtypes = [vp]
         L.fl_positions_map.argtypes = [vp, i32, vp]
+        L.fl_debug_last_obs_class.argtypes = [vp, vp]       # diagnostic, not part of the public header
         L.fl_algorithmic_bytes_per_agent_step.argtypes = [vp, i32, i32]
         L.fl_algorithmic_bytes_per_agent_step.restype = C.c_double
         _lib = L
@@ -444,6 +445,13 @@ class BatchedRailEnv:
         _chk(lib().fl_positions_map(self.h, b, _p(out)))
         return out
 
+    def last_obs_class(self):
+        """diagnostic: (fixed launch class, split, envs on the class's body) of the last obs_both / step_obs launch -- class 0 = the
+        runtime-carving kernel; split 1 = the class served only the envs that fit it, the others ran the runtime-carving body"""
+        out = (C.c_int * 3)()
+        _chk(lib().fl_debug_last_obs_class(self.h, out))
+        return tuple(out)
+
     def algorithmic_bytes_per_agent_step(self, with_cutils_obs=True, tree_depth=0):
         return float(lib().fl_algorithmic_bytes_per_agent_step(self.h, int(with_cutils_obs), int(tree_depth)))
 
@@ -477,12 +485,23 @@ class MixedBatch:
             self.streams.append(s)
         self.n = len(envs)
 
-    def _each(self, fn):
+    def _on_streams(self, fn):
+        """fn(k, group) enqueued on every group's own stream (the groups' kernels overlap); the CALLER's current stream then waits for
+        all of them, so whatever the caller does next with the returned tensors -- a .cpu(), a torch op, its own kernels -- is ordered
+        after the groups' work (the groups' streams are non-blocking: nothing orders them with the caller's stream otherwise)"""
+        t = self.torch
+        cur = t.cuda.current_stream(self.groups[0].device)
         out = []
-        for g, s in zip(self.groups, self.streams):
-            with self.torch.cuda.stream(s):
-                out.append(fn(g))
+        for k, (g, s) in enumerate(zip(self.groups, self.streams)):
+            s.wait_stream(cur)                   # ... and the group's work after what the caller enqueued before (e.g. the actions' upload)
+            with t.cuda.stream(s):
+                out.append(fn(k, g))
+        for s in self.streams:
+            cur.wait_stream(s)
         return out
+
+    def _each(self, fn):
+        return self._on_streams(lambda k, g: fn(g))
 
     def pick(self, i, per_group):
         g, b = self.where[i]
@@ -503,11 +522,7 @@ class MixedBatch:
         for i, a in enumerate(actions):
             g, b = self.where[i]
             per[g][b] = np.asarray(a, dtype=np.uint8)
-        res = []
-        for k, (g, s) in enumerate(zip(self.groups, self.streams)):
-            with self.torch.cuda.stream(s):
-                res.append(g.step(per[k], auto_reset=auto_reset, filter_required=filter_required))
-        return res
+        return self._on_streams(lambda k, g: g.step(per[k], auto_reset=auto_reset, filter_required=filter_required))
 
     def stream_of(self, i):
         """stream id of env i in the on-device action stream of step_synth (groups in order, envs of a group consecutive)"""
@@ -516,13 +531,8 @@ class MixedBatch:
 
     def step_synth(self, seed, kind=0, auto_reset=True):
         """the on-device action stream; env i uses stream id stream_of(i)"""
-        k0 = 0
-        res = []
-        for k, (g, s) in enumerate(zip(self.groups, self.streams)):
-            with self.torch.cuda.stream(s):
-                res.append(g.step_synth(seed, k0, kind, auto_reset=auto_reset))
-            k0 += g.B
-        return res
+        base = [sum(x.B for x in self.groups[:k]) for k in range(len(self.groups))]
+        return self._on_streams(lambda k, g: g.step_synth(seed, base[k], kind, auto_reset=auto_reset))
 
     def obs_cutils(self):
         return self._each(lambda g: g.obs_cutils())
@@ -537,7 +547,7 @@ class MixedBatch:
 
     def metrics(self):
         """int64[4] on the host: the sums over all groups (what a multi-GPU harness all-reduces)"""
-        return sum(g.metrics().cpu().numpy() for g in self.groups)
+        return sum(m.cpu().numpy() for m in self._each(lambda g: g.metrics()))
 
     def check(self):
         for g in self.groups:

@@ -25,16 +25,28 @@ The env's own `distance_map` is not read: the reference's is the BFS of `env.rai
 `handles`: the observation is computed for the whole env and the rows of `handles` are returned; `RailEnv` always passes every
 handle (rail_env.py:665).  (With a strict subset the reference leaves the other agents' predictions out of the conflict test,
 treeobs.cpp:50-62: not reproduced.)
+
+Cost of a call (tools/plugin_latency.py, profiles/r05_plugin_latency.json): the per-call host work is the reference's own -- one
+pass over the agents' attributes -- and nothing that grows with the map: the grid is read and hashed at reset() only, the per-call
+check of the static side compares the agents' line / timetable arrays.  `get_many(handles, as_arrays=True)` returns the numpy
+arrays themselves instead of the nested lists the pybind11 casters of the reference build.
 """
+import time
+
 import numpy as np
 
 from .hip_backend import BatchedRailEnv, FlatlandHipError
-from .reference_bridge import static_of_env, dynamic_state_of_env
+from .reference_bridge import static_of_env, agents_static_of_env, dynamic_state_of_env, AGENT_STATIC_KEYS
 from . import rail_env as _re
 
 
+def _agents_signature(st):
+    return tuple(np.asarray(st[k]).tobytes() for k in AGENT_STATIC_KEYS)
+
+
 def _static_signature(st):
-    return tuple((k, np.asarray(st[k]).tobytes()) for k in ("grid", "init_pos", "init_dir", "target", "speed", "earliest", "latest", "T"))
+    g = np.asarray(st["grid"])
+    return (g.shape, g.tobytes()) + _agents_signature(st)
 
 
 class _EnvBinding:
@@ -49,6 +61,18 @@ class _EnvBinding:
         self.static = None
         self.dead = None          # the DeadlockChecker's sticky flags (deadlock_checker.cpp:3-9)
         self.elapsed = 0
+        self.agents_sig = None    # the agents' line / timetable as of the last static read (compared on every call)
+        self.profile = None       # a dict: seconds per stage of the calls, accumulated (tools/plugin_latency.py)
+
+    def lap(self, key, t0, sync=False):
+        """profiling only: seconds since t0 into stage `key` (sync: after the handle's stream has drained)"""
+        if self.profile is None:
+            return t0
+        if sync:
+            self.batch.sync()
+        t1 = time.perf_counter()
+        self.profile[key] = self.profile.get(key, 0.0) + (t1 - t0)
+        return t1
 
     def load_static(self, env, max_nodes=31, pred_depth=500):
         st = static_of_env(env)
@@ -72,6 +96,7 @@ class _EnvBinding:
             self.batch, self.sig, self.static = b, sig, st
             if self.verify:
                 self._verify_distance_map(env)
+        self.agents_sig = _agents_signature(st)
         if self.batch.max_nodes != max_nodes:
             self.batch._obs = None
         self.batch.max_nodes, self.batch.pred_depth = max_nodes, pred_depth
@@ -89,8 +114,10 @@ class _EnvBinding:
 
     def push_dynamic(self, env):
         """Agent::Agent for every agent (loader.cpp:8-120); the line and timetable are re-read too, like the reference does on
-        every call, and a change of them (or of the grid) reloads the static side."""
-        if _static_signature(static_of_env(env)) != self.sig:
+        every call (loader.cpp:19-73), and a change of them reloads the static side.  The rail is the reference's RailLoader: read
+        at reset() only (loader.cpp:329-333) -- nothing here is proportional to the map."""
+        t0 = time.perf_counter() if self.profile is not None else 0.0
+        if _agents_signature(agents_static_of_env(env)) != self.agents_sig:
             dead = self.dead
             self.load_static(env, self.batch.max_nodes, self.batch.pred_depth)
             if dead is not None and len(dead) == len(self.dead):
@@ -98,7 +125,9 @@ class _EnvBinding:
         state, aux, elapsed = dynamic_state_of_env(env)
         aux[:, 2] = self.dead
         self.elapsed = elapsed
+        t0 = self.lap("extract_python", t0)
         self.batch.set_state(state[None], aux[None], np.array([elapsed], dtype=np.int32))
+        self.lap("fl_set_state", t0)
 
 
 class TreeObsForRailEnv(_re.TreeObsForRailEnv):
@@ -125,30 +154,38 @@ class TreeObsForRailEnv(_re.TreeObsForRailEnv):
         H, W = st["grid"].shape
         self._cfg = {"n_agents": len(st["init_dir"]), "max_timesteps": int(st["T"]), "height": int(getattr(env, "height", H)),
                      "width": int(getattr(env, "width", W))}
-        self._last = None
-        if any(a.position is not None for a in env.agents):
-            self._compute()                      # AgentsLoader::update inside reset(): the checker sees the state at reset
+        self._compute()                          # AgentsLoader::update inside reset() (treeobs.cpp:22-28): the checker sees the state
+                                                 # at reset, and get_properties() is valid straight after it
 
     def _compute(self):
         b = self._bind
         b.push_dynamic(self.env)
+        t0 = time.perf_counter() if b.profile is not None else 0.0
         o = b.batch.obs_cutils()
-        b.batch.check()
+        b.batch.check()                          # (synchronises: the kernel has run)
+        t0 = b.lap("kernel", t0)
         self._last = {k: v[0].cpu().numpy() for k, v in o.items()}
         b.dead = self._last["props"][:, 1].astype(np.int32)
+        b.lap("read_back", t0)
         return self._last
 
-    def get_many(self, handles):
+    def get_many(self, handles, as_arrays=False):
         """-> (agent_attr [n][83], (nodes [n][N][12], adjacency [n][N-1][3], node_order [n][N], edge_order [n][N-1])) as nested
-        lists, what the pybind11 STL casters return (treeobs.h:160-161, treeobs.cpp:30-108)."""
+        lists, what the pybind11 STL casters return (treeobs.h:160-161, treeobs.cpp:30-108); as_arrays=True: the same five as
+        numpy arrays (float32 / int32), without the conversion to Python lists."""
         if self._native:
             return super().get_many(handles)
         if self._bind.batch is None:
             raise RuntimeError("TreeObsForRailEnv.get_many() before reset()")
         L = self._compute()
         h = list(handles)
-        return (L["agent_attr"][h].tolist(),
-                (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(), L["edge_order"][h].tolist()))
+        if as_arrays:
+            return (L["agent_attr"][h], (L["forest"][h], L["adjacency"][h], L["node_order"][h], L["edge_order"][h]))
+        t0 = time.perf_counter() if self._bind.profile is not None else 0.0
+        out = (L["agent_attr"][h].tolist(),
+               (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(), L["edge_order"][h].tolist()))
+        self._bind.lap("tolist", t0)
+        return out
 
     def get_properties(self):
         """treeobs.cpp:612-640: the values of the last get_many() / reset()"""
@@ -204,7 +241,9 @@ class TreeObsUpstream(_re.TreeObsUpstream):
         t = b.batch.obs_tree(self.max_depth, pred)
         b.batch.check()
         arr = t[0].cpu().numpy()
-        return {h: arr[h] for h in ([] if handles is None else handles)}      # observations.py:66-67: None -> no handles
+        return {h: arr[h] for h in (range(arr.shape[0]) if handles is None else handles)}   # (the dense form is this library's own: None = every agent)
 
     def get_many(self, handles=None):
+        if handles is None:
+            return {}                            # observations.py:66-67: None -> no handles, no observations
         return {h: _re.nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}

@@ -282,6 +282,8 @@ class TreeObsUpstream(ObservationBuilder):
         return {h: arr[h] for h in handles}
 
     def get_many(self, handles=None):
+        if handles is None:
+            return {}                 # observations.py:66-67: None -> no handles, no observations (get_many_dense(None): every agent)
         return {h: nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}
 
 

@@ -28,8 +28,30 @@ def _rng_state_of(env, required):
         return np.zeros(624, dtype=np.uint32), 624       # observation-only use: the stream is never drawn from
     st = rs.get_state()
     if st[0] != "MT19937" or st[3] != 0:
-        raise ValueError("env.np_random must be a numpy RandomState (MT19937) without a cached gaussian")
+        if required:
+            raise ValueError("env.np_random must be a numpy RandomState (MT19937) without a cached gaussian")
+        return np.zeros(624, dtype=np.uint32), 624       # observation-only use: the stream is never drawn from
     return np.asarray(st[1], dtype=np.uint32), int(st[2])
+
+
+AGENT_STATIC_KEYS = ("init_pos", "init_dir", "target", "speed", "earliest", "latest", "T")
+
+
+def agents_static_of_env(env):
+    """the agents' line and timetable and the episode length -- the part of the static description flatland_cutils reads again on
+    every call (Agent::Agent, loader.cpp:19-73; AgentsLoader::update reads max_timesteps, loader.cpp:221-233); no grid, no RNG"""
+    agents = env.agents
+    if any(a.initial_position is None or a.target is None for a in agents):
+        raise ValueError("the env has to be reset() first (agents without initial position / target)")
+    n = len(agents)
+    return dict(
+        init_pos=np.array([a.initial_position for a in agents], dtype=np.int32).reshape(n, 2),
+        init_dir=np.array([int(a.initial_direction) for a in agents], dtype=np.int32),
+        target=np.array([a.target for a in agents], dtype=np.int32).reshape(n, 2),
+        speed=np.array([a.speed_counter.speed for a in agents], dtype=np.float64),
+        earliest=np.array([a.earliest_departure for a in agents], dtype=np.int32),
+        latest=np.array([a.latest_arrival for a in agents], dtype=np.int32),
+        T=np.int32(env._max_episode_steps))
 
 
 def static_of_env(env, require_rng=False):
@@ -37,23 +59,12 @@ def static_of_env(env, require_rng=False):
     it at reset() (loader.cpp:207-219, 329-333) and per agent (loader.cpp:19-73): `rail.grid`, `_max_episode_steps`, `agents`
     with initial_position / initial_direction / target / speed_counter.speed / earliest_departure / latest_arrival.  The
     malfunction parameters and the MT19937 state matter to step() only; without require_rng an env that has none is accepted."""
-    agents = env.agents
     rate, mn, mx = _malfunction_parameters(env)
-    if any(a.initial_position is None or a.target is None for a in agents):
-        raise ValueError("the env has to be reset() first (agents without initial position / target)")
+    st = agents_static_of_env(env)
     key, pos = _rng_state_of(env, require_rng)
-    return dict(
-        grid=np.asarray(env.rail.grid, dtype=np.uint16),
-        init_pos=np.array([a.initial_position for a in agents], dtype=np.int32).reshape(len(agents), 2),
-        init_dir=np.array([int(a.initial_direction) for a in agents], dtype=np.int32),
-        target=np.array([a.target for a in agents], dtype=np.int32).reshape(len(agents), 2),
-        speed=np.array([a.speed_counter.speed for a in agents], dtype=np.float64),
-        earliest=np.array([a.earliest_departure for a in agents], dtype=np.int32),
-        latest=np.array([a.latest_arrival for a in agents], dtype=np.int32),
-        T=np.int32(env._max_episode_steps),
-        malf_rate=np.float64(rate), malf_min=np.int32(mn), malf_max=np.int32(mx),
-        mt_key=key, mt_pos=np.int32(pos),
-    )
+    st.update(grid=np.asarray(env.rail.grid, dtype=np.uint16), malf_rate=np.float64(rate), malf_min=np.int32(mn), malf_max=np.int32(mx),
+              mt_key=key, mt_pos=np.int32(pos))
+    return st
 
 
 def from_reference_env(env):

@@ -20,20 +20,27 @@ def _same(got, exp, msg):
         raise AssertionError(f"{msg}: {len(bad)} mismatches, first {bad[0].tolist()}: {got[tuple(bad[0])]} vs {exp[tuple(bad[0])]}")
 
 
-@pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct,depth", [
+# fixed launch class of every case (fl_obs_layout.h ObsFixed<k>; BatchedRailEnv.last_obs_class): `klass` = (class, split) of the full
+# batch's launch -- split 1: the batch's largest map exceeds the class's rail cells, the class's body builds the envs that fit it and
+# the runtime-carving body of the same kernel the others (k_obs_split), so those cases cover BOTH bodies at shard size.
+@pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct,depth,klass", [
     # (replicas with b % 7 == 3 have short episodes: 3, 766, 1018 / 3, 255 restart inside the window)
-    ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10, 3),
+    ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10, 3, (2, 0)),
     # the per-GPU shard of cfg4 as the bench runs it: rounds of 32 agents, pass-B work lists in HBM scratch (per-env stride) AND
     # the longest-first workgroup order of k_env_order (more envs than CUs)
-    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2),
-    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3),
+    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2, (3, 1)),
+    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3, (4, 1)),
+    # the SINGLE-map shards of bench.py's EXTRA_WORKLOADS and of the profiles of record: every env fits its class -- k_obs<4,2,3>
+    # with k_env_order and the per-env HBM work-list stride at B = 512, k_obs<2,2,4> with the masked rebuild at B = 256
+    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 0, 2, (3, 0)),
+    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 0, 3, (4, 0)),
 ])
-def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct, depth):
+def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct, depth, klass):
     from flatland_marl_amd import synth, workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
     from oracle import orc
     envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
-    assert len({e["grid"].tobytes() for e in envs[:distinct]}) == distinct
+    assert len({e["grid"].tobytes() for e in envs}) == max(distinct, 1)
     # short episodes for some replicas, so that auto-resets (and the masked rebuild) happen inside the window
     for b in range(B):
         if b % 7 == 3:
@@ -47,6 +54,13 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
     for t in range(steps):
         rew, done, done_all = env.step_synth(seed, 0, 0, auto_reset=True)
         o, tree = env.obs_both(depth, 30)
+        if t == 0:      # which kernel builds the batch: the class, for every env (split 0) or for the envs that fit it (split 1)
+            fix, split, n_fit = env.last_obs_class()
+            rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
+            cap = {2: 232, 3: 656, 4: 2688}[klass[0]]
+            assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
+            if split:   # both bodies are under test: replicas on either side of the class's capacity among the picks / shadows
+                assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]
         if rebuild:
             env.rebuild_distance_maps(env.done_all)
         st, el = env.state()
@@ -86,8 +100,9 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         s_env.check()
 
 
-def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2):
-    """sha256 over the state, rewards and both observations of every step of the full cfg4 shard (or of another workload)"""
+def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2, want_class=None):
+    """sha256 over the state, rewards and both observations of every step of the full cfg4 shard (or of another workload);
+    want_class: (fixed launch class, split) the launches must have taken"""
     import hashlib
     from flatland_marl_amd import workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
@@ -97,6 +112,8 @@ def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2):
     for t in range(steps):
         rew, done, done_all = env.step_synth(seed, 0, 2, auto_reset=True)      # dense traffic: envs of very different cost
         o, tree = env.obs_both(depth, 30)
+        if want_class is not None:
+            assert env.last_obs_class()[:2] == tuple(want_class), (workload, env.last_obs_class(), want_class)
         h.update(env.state()[0].tobytes())
         h.update(rew.cpu().numpy().tobytes())
         for k in sorted(o):
@@ -106,43 +123,47 @@ def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2):
     return h.hexdigest()
 
 
-def test_workgroup_order_does_not_change_the_results_at_cfg4():
-    """k_env_order hands the envs to the workgroups longest first (B > CUs); FL_OBS_NO_ORDER (read once per process, hence the
-    child) makes workgroup k build env k.  Same bytes either way."""
+def _child(switches, *argv):
     import os
     import subprocess
     import sys
     from tests import util
-    child = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, FL_OBS_NO_ORDER="1", PYTHONPATH=util.ROOT),
+    child = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=dict(os.environ, PYTHONPATH=util.ROOT, **{k: "1" for k in switches}),
                            capture_output=True, text=True, timeout=900)
     assert child.returncode == 0, child.stderr[-2000:]
-    plain = [ln for ln in child.stdout.splitlines() if ln.startswith("DIGEST ")][-1].split()[1]
-    assert _cfg4_digest() == plain
+    return dict(ln.split()[1:3] for ln in child.stdout.splitlines() if ln.startswith("DIGEST "))
+
+
+def test_workgroup_order_and_the_split_of_a_launch_do_not_change_the_results_at_cfg4():
+    """The cfg4 shard on four distinct maps, two of them beyond class 3's rail cells: the default launch is the class's SPLIT kernel
+    (class body / runtime-carving body per env) with the envs handed to the workgroups longest first by k_env_order (B > CUs).
+    FL_OBS_NO_ORDER (read once per process, hence the children) makes workgroup k build env k; FL_OBS_NO_SPLIT runs every env on
+    the runtime-carving kernel k_obs<4,2,0>.  Same bytes all three ways."""
+    want = _cfg4_digest(want_class=(3, 1))
+    assert _child(("FL_OBS_NO_ORDER",), "cfg4", "3", "1") == {"cfg4": want}
+    assert _child(("FL_OBS_NO_SPLIT",), "cfg4", "0", "0") == {"cfg4": want}
+
+
+CASES = {"cfg3": dict(steps=60, workload="cfg3", B=24, distinct=3, depth=3), "cfg2": dict(steps=80, workload="cfg2", B=16, distinct=4, depth=2)}
+CLASS_OF = {"cfg3": (2, 0), "cfg2": (1, 0)}
 
 
 def test_other_launch_paths_give_the_same_bytes():
     """The launcher's alternative paths, each selected by an environment switch that is read once per process (hence children):
     the runtime LDS carving instead of the fixed launch classes (FL_OBS_NO_FIX) and the 512-thread kernel in rounds of 16 agents,
     two workgroups a CU (FL_OBS_ROUND16, MODE 5) -- on cfg3 (depth 3) and cfg2 (depth 2) batches in dense traffic.  Same bytes
-    as the default path."""
-    import os
-    import subprocess
-    import sys
-    from tests import util
-    cases = {"cfg3": dict(steps=60, workload="cfg3", B=24, distinct=3, depth=3), "cfg2": dict(steps=80, workload="cfg2", B=16, distinct=4, depth=2)}
-    want = {k: _cfg4_digest(**kw) for k, kw in cases.items()}
-    for switch in ("FL_OBS_NO_FIX", "FL_OBS_ROUND16"):
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), "paths"], env=dict(os.environ, PYTHONPATH=util.ROOT, **{switch: "1"}),
-                               capture_output=True, text=True, timeout=900)
-        assert child.returncode == 0, child.stderr[-2000:]
-        got = dict(ln.split()[1:3] for ln in child.stdout.splitlines() if ln.startswith("DIGEST "))
-        assert got == want, switch
+    as the default path, and every run asserts the launch class it took (default: classes 2 / 1; with a switch: none)."""
+    want = {k: _cfg4_digest(want_class=CLASS_OF[k], **kw) for k, kw in CASES.items()}
+    assert _child(("FL_OBS_NO_FIX",), "paths", "0") == want
+    assert _child(("FL_OBS_ROUND16",), "paths", "r16") == want
 
 
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "paths":
-        print("DIGEST cfg3", _cfg4_digest(steps=60, workload="cfg3", B=24, distinct=3, depth=3))
-        print("DIGEST cfg2", _cfg4_digest(steps=80, workload="cfg2", B=16, distinct=4, depth=2))
+        for k, kw in CASES.items():
+            # rounds of 16 agents apply to envs of more than 32 agents only: cfg2 keeps its class there
+            klass = (0, 0) if sys.argv[2] == "0" or k == "cfg3" else CLASS_OF[k]
+            print("DIGEST", k, _cfg4_digest(want_class=klass, **kw))
     else:
-        print("DIGEST", _cfg4_digest())
+        print("DIGEST cfg4", _cfg4_digest(want_class=(int(sys.argv[2]), int(sys.argv[3]))))

@@ -301,3 +301,33 @@ def test_mixed_shapes_step_together_like_their_golden_episodes():
     mb.check()
     assert n_obs > 40
     mb.close()
+
+
+def test_mixed_batch_results_are_ordered_with_the_callers_stream():
+    """The groups of a MixedBatch run on non-blocking streams of their own; what a call returns is read by the CALLER on its current
+    stream.  No state() / check() / sync() (which would drain the groups' streams) before the reads here: a `.cpu()` straight after the
+    call has to see the finished results -- the caller's stream waits for the groups' streams inside every MixedBatch call."""
+    import torch
+    from flatland_marl_amd.hip_backend import MixedBatch
+    names = ["cfg3_uniform", "cfg1_sparse", "cfg2_fwd", "cfg3_uniform", "cfg2_uniform"]
+    fxs = [util.load(n) for n in names]
+    mb = MixedBatch([util.static_of(fx) for fx in fxs])
+    acts = [util.actions_of(fx) for fx in fxs]
+    obs_steps = [{int(t): k for k, t in enumerate(fx["obs_steps"])} for fx in fxs]
+    n_obs = 0
+    for t in range(100):
+        res = mb.step([a[t] for a in acts])
+        rews = [mb.pick(i, res)[0].cpu().numpy() for i in range(len(fxs))]            # straight away, on the caller's stream
+        o = mb.obs_cutils()
+        forests = [mb.pick(i, o)["forest"].cpu().numpy() for i in range(len(fxs))]
+        m = mb.metrics()
+        assert int(m[2]) == sum(len(fx["init_dir"]) for fx in fxs) * (t + 1)
+        for i, fx in enumerate(fxs):
+            np.testing.assert_array_equal(rews[i], fx["s_reward"][t], err_msg=f"{names[i]} rewards, step {t}")
+            if (t + 1) in obs_steps[i]:
+                np.testing.assert_array_equal(forests[i], fx["o_forest"][obs_steps[i][t + 1]], err_msg=f"{names[i]} forest, step {t}")
+                n_obs += 1
+    torch.cuda.synchronize()
+    mb.check()
+    assert n_obs > 20
+    mb.close()

@@ -94,7 +94,8 @@ def test_plugin_inside_the_real_reference_railenv(cap, monkeypatch):
     A = env.get_num_agents()
     attr, (nodes, adj, no, eo) = obs
     assert (len(attr), len(attr[0]), len(nodes[0]), len(nodes[0][0]), len(adj[0]), len(no[0]), len(eo[0])) == (A, 83, 31, 12, 30, 31, 30)
-    assert len(rec.pushed) == 1 and rec.pushed[0][2] == 0
+    # reset() runs AgentsLoader::update itself (treeobs.cpp:22-28), then RailEnv.reset() asks for the observations: two reads, both at step 0
+    assert len(rec.pushed) == 2 and rec.pushed[0][2] == 0 and rec.pushed[1][2] == 0
     cfg, props, valid = builder.get_properties()
     assert cfg == dict(curr_step=0, n_agents=A, max_timesteps=int(fx["T"]), height=30, width=30) and len(valid) == A
     cols = [i for i, n in enumerate(util.STATE_NAMES) if n != "saved"]       # flatland_cutils does not read the saved action
@@ -103,7 +104,7 @@ def test_plugin_inside_the_real_reference_railenv(cap, monkeypatch):
         a = synth.uniform_actions(4, 0, t, A)
         env.step({i: int(a[i]) for i in range(A)})
         st, aux, el = rec.pushed[-1]
-        assert el == t + 1 and len(rec.pushed) == t + 2
+        assert el == t + 1 and len(rec.pushed) == t + 3
         np.testing.assert_array_equal(st[:, cols], util.golden_state(fx, t)[:, cols], err_msg=f"step {t}")
         np.testing.assert_array_equal(st[:, 7], fx["s_saved"][t], err_msg=f"saved action, step {t}")
         # the in_malfunction signal the reference module reads is the state machine's, as of this step (loader.cpp:16-18)
