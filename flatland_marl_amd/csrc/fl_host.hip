@@ -836,7 +836,7 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
 // second index, items in LDS, one pass B for both builders, compact upstream trees of the fused observation launch on this batch
 extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out11) {
     NEED_COMMIT(h);
-    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11);
+    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11, h->obs.n_cu > 0 && h->d.B >= OBS_WIDE_ENVS_PER_CU * h->obs.n_cu);
 }
 
 // diagnostic (not part of the public header): what the last fused observation launch (fl_obs_cutils_tree / fl_step_obs with a tree)
@@ -858,6 +858,16 @@ extern "C" int fl_debug_obs_config_of(int A, int Rcap, int Ucap, int tall, int m
     static uint16_t dummy_key;
     d.rkey = tall ? &dummy_key : nullptr;
     return fl_obs_config_of_fused(d, pred_depth, max_depth, tree_pred, out11);
+}
+// ... of a WIDE batch (several envs per CU)
+extern "C" int fl_debug_obs_config_of_wide(int A, int Rcap, int Ucap, int tall, int max_branch, int pred_depth, int max_depth, int tree_pred,
+                                           int *out11) {
+    FlDev d;
+    memset(&d, 0, sizeof d);
+    d.A = A; d.Rcap = Rcap; d.Ucap = Ucap; d.max_branch = max_branch;
+    static uint16_t dummy_key;
+    d.rkey = tall ? &dummy_key : nullptr;
+    return fl_obs_config_of_fused(d, pred_depth, max_depth, tree_pred, out11, 1);
 }
 
 double fl_algorithmic_bytes_per_agent_step(fl_batch *h, int with_cutils_obs, int tree_depth) {

@@ -7,6 +7,10 @@
 #define FL_OBS_MAX_NODES 32  /* all non-root nodes of a tree are evaluated by one 32-lane group */
 #define FL_OBS_MAX_PRED 500
 
+#ifndef OBS_WIDE_ENVS_PER_CU
+#define OBS_WIDE_ENVS_PER_CU 4   // a batch of at least this many envs per CU is "wide": small envs then run two workgroups a CU (class 5; same-box sweep: +3 % at 4 envs per CU, +7 % at 8, -10 % at 3, even at 2)
+#endif
+
 struct FlObsScratch {
     int pred_cap;      // waypoints kept per agent (pred_depth + 2)
     uint16_t *path;    // [B][A][pred_cap] predicted waypoints: rail state (rail index << 2 | direction)
@@ -35,4 +39,4 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
 // more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
 FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s);
-int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11]);  // diagnostic
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11], int wide = 0);  // diagnostic (wide: several envs per CU)

@@ -30,8 +30,14 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     if (hipMalloc(&p, (size_t)d.B * 4) != hipSuccess) return FL_ERR_HIP;
     o.cost = (uint32_t *)p; allocs.push_back(p);
     if (hipMemsetAsync(o.cost, 0, (size_t)d.B * 4, s) != hipSuccess) return FL_ERR_HIP;
+    // every scratch array starts out zeroed: what a kernel reads of them it has written before in the same launch, but a handle's
+    // behaviour must not depend on what a freed allocation of an earlier handle left in the memory it got
+    if (hipMemsetAsync(o.path, 0, BA * o.pred_cap * 2, s) != hipSuccess || hipMemsetAsync(o.cell_items, 0, (size_t)d.B * o.items_cap * 4, s) != hipSuccess ||
+        hipMemsetAsync(o.dbg, 0, (size_t)d.B * 64 * 8, s) != hipSuccess || hipMemsetAsync(o.bk_rel, 0, (size_t)d.B * (d.Rcap + 1) * OBS_BK_NB * 2 + 16, s) != hipSuccess ||
+        hipMemsetAsync(o.wl, 0, (size_t)d.B * o.wl_cap * 8, s) != hipSuccess) return FL_ERR_HIP;
     if (hipMalloc(&p, (size_t)d.B * 4) != hipSuccess) return FL_ERR_HIP;
     o.order = (int *)p; allocs.push_back(p);
+    if (hipMemsetAsync(o.order, 0, (size_t)d.B * 4, s) != hipSuccess) return FL_ERR_HIP;
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return FL_ERR_HIP;
     o.n_cu = n_cu;
@@ -122,6 +128,7 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
     else if (obs_fits_fixed<2>(d, P, o, L)) P.fix = 2;
     else if (obs_fits_fixed<3>(d, P, o, L)) P.fix = 3;
     else if (obs_fits_fixed<4>(d, P, o, L)) P.fix = 4;
+    else if (obs_fits_fixed<5>(d, P, o, L)) P.fix = 5;
 }
 
 static bool g_fix_allowed = false;  // the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
@@ -202,8 +209,12 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // Rounds of 16 agents on 512 threads and at most 80 KB of LDS (MODE 5): a CU then holds TWO workgroups, and one env's barriers
     // and L2 round trips are filled by the other's issue.  FL_OBS_ROUND16=0 / 1 overrides the default.
     static const int round16_env = getenv("FL_OBS_ROUND16") ? atoi(getenv("FL_OBS_ROUND16")) : -1;
-    // (FL_OBS_ROUND16=2: also for envs of 17 .. 32 agents -- two rounds instead of the one-round kernel, for batches of more envs than CUs)
-    const bool r16 = (d.A > 32 || (d.A > 16 && round16_env == 2)) && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
+    // Envs of at most 32 agents (rounds of 16 instead of the one-round kernel): when the batch has several envs per CU (P.wide) -- same-box
+    // sweep at the cfg2 shape, runtime carving on both sides: 512 envs +7 %, 1024 +13 %, 2048 +17 % with two workgroups a CU; at one
+    // env per CU the 512-thread workgroup alone takes 75 us against 53 (profiles/r05_cfg2_bsweep.json).  FL_OBS_ROUND16=2 forces it
+    // for any batch, =0 rules it out.
+    const bool r16_small = d.A <= 32 && (round16_env >= 0 ? round16_env == 2 : P.wide != 0);
+    const bool r16 = (r16_small || (d.A > 32 && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0))) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
     const int merged_nt = r16 ? 512 : OBS_NT;
     const size_t merged_limit = r16 ? std::min(lds_limit, (size_t)80 * 1024) : lds_limit;
     if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
@@ -217,12 +228,12 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         // list that overflows is handled cell by cell inside the classify loop (cfg3: 1.04 ms with 24 KB, 0.82 ms with 36 KB) -- so
         // 36 KB of LDS lists, or else the lists in HBM scratch (no cap); the items in LDS before anything else (cfg4: 0.45 against
         // 0.52 ms); lists grouped by 32-step time buckets where their offsets fit too (cfg4: 0.48 -> 0.45 ms, cfg3 neutral).
+        static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
+        static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
         struct Pref { int fb, wl, items; };
         static const Pref one_round[] = {{0, 24 * 1024, 1}, {0, 16 * 1024, 1}, {0, 0, 1}, {0, 24 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
         static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
                                       {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
-        static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
-        static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
         // rounds of 16 agents in 80 KB: half the trees a round meet half the cells -- 16 KB of LDS lists, else HBM scratch
         static const Pref rounds16[] = {{1, 16 * 1024, 1}, {0, 16 * 1024, 1}, {1, 0, 1}, {1, 12 * 1024, 1}, {0, 12 * 1024, 1}, {0, 0, 1}, {1, 16 * 1024, 0}, {1, 0, 0}, {0, 16 * 1024, 0},
                                         {0, 0, 0}, {0, 8 * 1024, 0}};
@@ -230,6 +241,29 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         static const Pref rounds16_small[] = {{0, 16 * 1024, 1}, {0, 12 * 1024, 1}, {1, 16 * 1024, 1}, {0, 0, 1}, {0, 16 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
         const Pref *prefs = P.merged == 1 ? one_round : P.merged == 3 ? (d.A <= 32 ? rounds16_small : rounds16) : rounds;
         const int n_prefs = P.merged == 1 ? (int)(sizeof one_round / sizeof one_round[0]) : P.merged == 3 ? (d.A <= 32 ? (int)(sizeof rounds16_small / sizeof rounds16_small[0]) : (int)(sizeof rounds16 / sizeof rounds16[0])) : (int)(sizeof rounds / sizeof rounds[0]);
+        // what a configuration of this branch sets in P (and the fixed launch class that has exactly these options, if the batch fits one)
+        auto accept = [&](const ObsOptions &oo, ObsLayout L) {
+            g_last_options = oo;
+            P.use_tmask = 1; P.dual_index = 1;
+            P.bk = oo.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
+            P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
+            // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
+            P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
+            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
+            obs_take_fixed_class(d, P, oo, L, g_fix_allowed);
+            P.L = L;
+        };
+        // Two workgroups a CU for small envs: what fits 80 KB depends on the batch's sizes, so the preference walk below lands on
+        // different options for different batches -- class 5's own options first: a batch that fits the class takes the class
+        // (compile-time carving: worth more than any option the walk could add)
+        if (P.merged == 3 && d.A <= 32 && !no_own && force.wl < 0 && force.items < 0 && force.nh < 0) {
+            const ObsOptions oc = ObsFixed<5>::opt;
+            const ObsLayout L = obs_layout(d, P, oc);
+            if (L.total <= merged_limit) {
+                accept(oc, L);
+                if (P.fix == 5) return true;
+            }
+        }
         for (int pk = 0; pk < n_prefs; pk++) {
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
@@ -246,15 +280,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                             o.items_cap = caps[ck];
                             ObsLayout L = obs_layout(d, P, o);
                             if (L.total > merged_limit) continue;
-                            g_last_options = o;
-                            P.use_tmask = 1; P.dual_index = 1;
-                            P.bk = o.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
-                            P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
-                            // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
-                            P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
-                            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
-                            obs_take_fixed_class(d, P, o, L, g_fix_allowed);
-                            P.L = L;
+                            accept(o, L);
                             return true;
                         }
         }
@@ -355,6 +381,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
+    P.wide = o.n_cu > 0 && d.B >= OBS_WIDE_ENVS_PER_CU * o.n_cu;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     const int n_split = obs_take_split_class(d, P, o.h_R);
     o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
@@ -375,6 +402,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     case 2: return fl_obs_launch_f2(d, u, P, s);
     case 3: return fl_obs_launch_f3(d, u, P, s);
     case 4: return fl_obs_launch_f4(d, u, P, s);
+    case 5: return fl_obs_launch_f5(d, u, P, s);
     default: break;
     }
     return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) :
@@ -395,8 +423,9 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
 
 // diagnostic: the configuration obs_pick_config chooses for the fused launch (cutils + upstream tree of max_depth):
 // threads, LDS bytes, static tables in LDS, next-hop in LDS, work-list bytes, time masks, second index, items in LDS
-int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11]) {
+int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11], int wide) {
     ObsArgs P = {};
+    P.wide = wide;
     P.pred_depth = pred_depth;
     P.max_nodes = 31;   // (the solution's tree size; the fixed launch classes are for exactly that)
     P.tw_c = N_WORDS_C * OBS_CAP_C;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // (every fixed launch class and every one-pass kernel runs on a known number of threads -- obs_pick_config launches MODE 3 / 4 on
     // OBS_NT, MODE 5 on 512: the strides of the workgroup-wide loops are constants there)
     const int b = MERGED == 1 ? (int)blockIdx.x : obs_env_of_workgroup(S), tid = threadIdx.x,
-              nt = (FIX != 0 || MERGED == 1 || MERGED == 2) ? OBS_NT : MERGED == 3 ? 512 : (int)blockDim.x;
+              nt = MERGED == 3 ? 512 : (FIX != 0 || MERGED == 1 || MERGED == 2) ? OBS_NT : (int)blockDim.x;
     const int A = (FIX != 0 && FixT::agents != 0) ? FixT::agents : d.A, R = d.R[b], NS = R * 4, K = d.K[b], U = d.U[b];
     const int Rcap = d.Rcap, Scap = Rcap * 4;
     const int lane = tid & 63, wave = tid >> 6;

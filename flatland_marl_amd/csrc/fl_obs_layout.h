@@ -220,13 +220,24 @@ template <> struct ObsFixed<4> {
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
+//   FIX 5: class 1's envs (at most 32 agents, 256 rail cells, depth 2) in rounds of 16 agents on 512 threads and at most 80 KB of LDS
+//   (MODE 5): TWO workgroups a CU.  For batches of several envs per CU -- there one env's barriers and round trips are filled by the
+//   other's issue (same-box sweep at the cfg2 shape, profiles/r05_cfg2_bsweep.json); a batch of at most one env per CU keeps class 1.
+template <> struct ObsFixed<5> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {256, 32, 0, 0};
+    static constexpr ObsShape shape = {3, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {512, 16 * 1024, 0, 0, 1, 1, 1, 1, 1, 0, 1, 0, 0, 2048};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
 // what obs_pick_config derives from a class's options for ObsArgs: ONE definition for the kernel (which has them as constants) and
 // for the host (obs_fits_fixed only takes the class when its own derivation for the batch gives the same values)
 template <int FIX> __host__ __device__ constexpr int obs_fixed_bk() { return ObsFixed<FIX>::shape.merged != 0 ? (ObsFixed<FIX>::opt.fb ? 2 : 0) : ObsFixed<FIX>::opt.bk_room; }
 template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (FIX == 2 || FIX == 3) ? 3 : OBS_WL_OCC_DIV; }
-template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return FIX == 1 ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return (FIX == 1 || FIX == 5) ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
 // kernel of a class: MODE 3 (one round) / 4 (rounds of 32 agents) / 2 (two stages), VAR 1 (static tables in LDS) / 2 (work lists in HBM scratch) / 0
-template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() { return ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : 2; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() { return ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : ObsFixed<FIX>::shape.merged == 3 ? 5 : 2; }
 template <int FIX> __host__ __device__ constexpr int obs_fixed_var() { return ObsFixed<FIX>::opt.tab ? 1 : ObsFixed<FIX>::opt.wl_bytes == 0 ? 2 : 0; }
 // (the next-hop tables in LDS are the one option a class may differ in from the batch's own choice: nh is the class's)
 __host__ __device__ constexpr bool obs_same_options(const ObsOptions &a, const ObsOptions &b) {
@@ -257,6 +268,7 @@ struct ObsArgs {
                        // of 32 agents, 3: rounds of 16 agents on 512 threads (at most 80 KB of LDS: two workgroups a CU)
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
+    int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
     int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
                        // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving
                        // body with L below; 0: every env of the launch fits the class
@@ -277,6 +289,7 @@ int fl_obs_launch_f1(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hi
 int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f5(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 // the same classes for a batch with larger maps among its envs (P.split): per env the class's body or the runtime-carving one
 int fl_obs_launch_s2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

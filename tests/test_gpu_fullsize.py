@@ -34,13 +34,16 @@ def _same(got, exp, msg):
     # with k_env_order and the per-env HBM work-list stride at B = 512, k_obs<2,2,4> with the masked rebuild at B = 256
     ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 0, 2, (3, 0)),
     ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 0, 3, (4, 0)),
+    # four envs per CU at the north-star shape: class 5 -- 512-thread workgroups in rounds of 16 agents, two a CU (the solo runs of the
+    # picks take class 1, the one-round kernel: two different kernels, the same bytes)
+    ("cfg2", 1024, 90, (0, 257, 766, 1018, 1023), (3, 5, 1022), False, 0, 2, (5, 0)),
 ])
 def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct, depth, klass):
     from flatland_marl_amd import synth, workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
     from oracle import orc
     envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
-    assert len({e["grid"].tobytes() for e in envs}) == max(distinct, 1)
+    assert len({e["grid"].tobytes() for e in envs}) == (distinct or len(wl.WORKLOADS[workload]["bases"]))
     # short episodes for some replicas, so that auto-resets (and the masked rebuild) happen inside the window
     for b in range(B):
         if b % 7 == 3:
@@ -57,7 +60,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         if t == 0:      # which kernel builds the batch: the class, for every env (split 0) or for the envs that fit it (split 1)
             fix, split, n_fit = env.last_obs_class()
             rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
-            cap = {2: 232, 3: 656, 4: 2688}[klass[0]]
+            cap = {2: 232, 3: 656, 4: 2688, 5: 256}[klass[0]]
             assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
             if split:   # both bodies are under test: replicas on either side of the class's capacity among the picks / shadows
                 assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]

@@ -13,10 +13,12 @@ from flatland_marl_amd import workload as wl
 KEYS = ("nt", "lds", "tab", "nh", "wl", "tmask", "dual", "items", "merged", "compact", "fix")
 
 
-def _config(A, R, U, depth, tall=0, max_branch=2, pred=500, tree_pred=30):
+def _config(A, R, U, depth, tall=0, max_branch=2, pred=500, tree_pred=30, wide=False):
+    """wide: a batch of several envs per CU (the launcher then prefers workgroups that fit two a CU for small envs)"""
     L = ctypes.CDLL(hb.LIB_PATH)       # plain dlopen: no torch, no GPU
     out = (ctypes.c_int * 11)()
-    assert L.fl_debug_obs_config_of(A, R, U, tall, max_branch, pred, depth, tree_pred, out) == 0
+    fn = L.fl_debug_obs_config_of_wide if wide else L.fl_debug_obs_config_of
+    assert fn(A, R, U, tall, max_branch, pred, depth, tree_pred, out) == 0
     return dict(zip(KEYS, out))
 
 
@@ -82,3 +84,17 @@ def test_fixed_launch_class_boundaries():
     assert _config(20, 213, 5, 2, tree_pred=60)["fix"] == 0   # 20 * 62 items of the second index exceed the class's 1024
     got = _config(20, 213, 20, 2)
     assert got["fix"] == 1 and got["lds"] <= 160 * 1024      # the next-hop tables (last in the carving) at the batch's size
+
+
+def test_wide_batches_of_small_envs_run_two_workgroups_a_cu():
+    """ObsFixed<5>: class 1's envs (at most 32 agents / 256 rail cells, depth 2) on 512 threads in at most 80 KB of LDS, so that a CU
+    holds two workgroups -- taken for a batch of several envs per CU (wide), whatever the batch's own sizes inside the class's
+    capacities are; a batch of at most one env per CU keeps class 1; beyond the capacities the runtime carving, still two a CU."""
+    for A, R, U in ((32, 256, 8), (20, 213, 5), (7, 138, 2), (17, 100, 3)):
+        got = _config(A, R, U, 2, wide=True)
+        assert got["fix"] == 5 and got["nt"] == 512 and got["merged"] == 3 and got["lds"] <= 80 * 1024, got
+        assert _config(A, R, U, 2)["fix"] == 1
+    got = _config(32, 257, 8, 2, wide=True)
+    assert got["fix"] == 0 and got["nt"] == 512 and got["lds"] <= 80 * 1024, got
+    assert _config(20, 213, 5, 3, wide=True)["fix"] == 0          # depth 3: not the class's
+    assert _config(80, 193, 10, 3, wide=True)["fix"] == 2         # envs of more than 32 agents: their own classes, one a CU

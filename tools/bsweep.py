@@ -5,8 +5,9 @@ workload's shape: how the throughput moves once a CU holds more than one env's w
 
   python tools/bsweep.py [--workload cfg2] [--bs 256,512,1024,2048] [--modes default,round16] [--out profiles/r05_cfg2_bsweep.json]
 
-modes: default (the launcher's own choice), round16 (FL_OBS_ROUND16=2: 512-thread workgroups in rounds of 16 agents, at most 80 KB
-of LDS, two workgroups a CU), nofix (FL_OBS_NO_FIX: runtime carving)."""
+modes: default (the launcher's own choice by B), one_a_cu (FL_OBS_ROUND16=0: the 1024-thread one-round kernel, class 1, for every B),
+two_a_cu (FL_OBS_ROUND16=2: 512-thread workgroups in rounds of 16 agents, at most 80 KB of LDS, two workgroups a CU: class 5, for every B),
+nofix / nofix_two_a_cu (the same two with the runtime carving, FL_OBS_NO_FIX)."""
 import argparse
 import json
 import os
@@ -14,7 +15,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODES = {"default": {}, "round16": {"FL_OBS_ROUND16": "2"}, "nofix": {"FL_OBS_NO_FIX": "1"}, "auto": {"FL_OBS_ROUND16": "auto"}}
+MODES = {"default": {}, "one_a_cu": {"FL_OBS_ROUND16": "0"}, "two_a_cu": {"FL_OBS_ROUND16": "2"}, "nofix": {"FL_OBS_NO_FIX": "1", "FL_OBS_ROUND16": "0"},
+         "nofix_two_a_cu": {"FL_OBS_NO_FIX": "1", "FL_OBS_ROUND16": "2"}}
 
 
 def child(workload, bs, depth, steps):
@@ -23,8 +25,7 @@ def child(workload, bs, depth, steps):
     out = {}
     for B in bs:
         r = bench.run_workload(workload, depth, 30, B, steps, 20, 0, 1, 0, event_steps=32)
-        cfg = None
-        out[str(B)] = dict(value=r["value"], ms_per_step=r["ms_per_step"], kernel_ms=r["kernel_ms"], on_map=r["on_map_agents_per_env"], obs_config=cfg)
+        out[str(B)] = dict(value=r["value"], ms_per_step=r["ms_per_step"], kernel_ms=r["kernel_ms"], on_map=r["on_map_agents_per_env"], launch_class=r.get("launch_class"))
         print("B=%d %.1f M agent-steps/s, %.3f ms/step, kernels %s" % (B, r["value"] / 1e6, r["ms_per_step"], r["kernel_ms"]), file=sys.stderr, flush=True)
     print("RESULT " + json.dumps(out))
 
@@ -33,7 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--bs", default="256,512,1024,2048")
-    ap.add_argument("--modes", default="default,round16")
+    ap.add_argument("--modes", default="one_a_cu,two_a_cu,default")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--out", default=None)
