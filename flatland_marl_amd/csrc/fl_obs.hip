@@ -102,9 +102,14 @@ static ObsLayout obs_layout(const FlDev &d, const ObsArgs &P, const ObsOptions &
 // A FIXED launch class (compile-time carving, ObsFixed<k> in fl_obs_layout.h) is taken when the batch fits the class's capacities
 // and the configuration just chosen for it has the class's options and shape; L becomes the class's carving (what the kernel has
 // compiled in) with the next-hop tables, last in the carving, at the batch's size.
+static bool obs_no_wl_head() {
+    static const bool v = getenv("FL_OBS_NO_WL_HEAD") != nullptr;   // diagnostic: HBM work lists without their LDS head (rules out the classes that have one)
+    return v;
+}
 template <int FIX>
 static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o, ObsLayout &L) {
     using F = ObsFixed<FIX>;
+    if (F::opt.wl_head && obs_no_wl_head()) return false;
     const size_t nh_bytes = F::opt.nh ? (((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15) : 0;
     if (!(d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) && P.merged == F::shape.merged &&
           P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
@@ -141,6 +146,7 @@ static int obs_var(const ObsArgs &P);
 template <int FIX>
 static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R) {
     using F = ObsFixed<FIX>;
+    if (F::opt.wl_head && obs_no_wl_head()) return 0;
     if (!h_R || F::opt.nh) return 0;   // (class 1 keeps the next-hop tables, sized by the batch, behind its carving: not split)
     if ((F::agents != 0 ? d.A != F::agents : d.A > F::dims.A) || d.rkey != nullptr || !P.compact_t) return 0;
     if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return 0;
@@ -228,11 +234,14 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         // list that overflows is handled cell by cell inside the classify loop (cfg3: 1.04 ms with 24 KB, 0.82 ms with 36 KB) -- so
         // 36 KB of LDS lists, or else the lists in HBM scratch (no cap); the items in LDS before anything else (cfg4: 0.45 against
         // 0.52 ms); lists grouped by 32-step time buckets where their offsets fit too (cfg4: 0.48 -> 0.45 ms, cfg3 neutral).
+        const bool no_head = obs_no_wl_head();
         static const bool no_own = getenv("FL_OBS_NO_OWN_FILTER") != nullptr;
         static const bool no_fb = getenv("FL_OBS_NO_FB") != nullptr;
         struct Pref { int fb, wl, items; };
         static const Pref one_round[] = {{0, 24 * 1024, 1}, {0, 16 * 1024, 1}, {0, 0, 1}, {0, 24 * 1024, 0}, {0, 0, 0}, {0, 8 * 1024, 0}};
-        static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
+        // (round 5) HBM lists without the LDS copy of the items BEFORE the copy: at 80 agents on 60 x 60 every env has more items than the
+        // 4 096 entries that fit beside the rest (the copy is dead weight there), and what it occupied becomes the lists' LDS head
+        static const Pref rounds[] = {{1, 36 * 1024, 1}, {0, 36 * 1024, 1}, {1, 0, 0}, {1, 0, 1}, {0, 0, 1}, {1, 24 * 1024, 1}, {0, 24 * 1024, 1},
                                       {0, 0, 0}, {0, 24 * 1024, 0}, {0, 8 * 1024, 0}};
         // rounds of 16 agents in 80 KB: half the trees a round meet half the cells -- 16 KB of LDS lists, else HBM scratch
         static const Pref rounds16[] = {{1, 16 * 1024, 1}, {0, 16 * 1024, 1}, {1, 0, 1}, {1, 12 * 1024, 1}, {0, 12 * 1024, 1}, {0, 0, 1}, {1, 16 * 1024, 0}, {1, 0, 0}, {0, 16 * 1024, 0},
@@ -253,17 +262,6 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             obs_take_fixed_class(d, P, oo, L, g_fix_allowed);
             P.L = L;
         };
-        // Two workgroups a CU for small envs: what fits 80 KB depends on the batch's sizes, so the preference walk below lands on
-        // different options for different batches -- class 5's own options first: a batch that fits the class takes the class
-        // (compile-time carving: worth more than any option the walk could add)
-        if (P.merged == 3 && d.A <= 32 && !no_own && force.wl < 0 && force.items < 0 && force.nh < 0) {
-            const ObsOptions oc = ObsFixed<5>::opt;
-            const ObsLayout L = obs_layout(d, P, oc);
-            if (L.total <= merged_limit) {
-                accept(oc, L);
-                if (P.fix == 5) return true;
-            }
-        }
         for (int pk = 0; pk < n_prefs; pk++) {
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
@@ -278,8 +276,15 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                         for (o.nh = nh_fit ? 1 : 0; o.nh >= 0; o.nh--) {
                             if (!ok(force.nh, o.nh)) continue;
                             o.items_cap = caps[ck];
+                            o.wl_head = 0;
                             ObsLayout L = obs_layout(d, P, o);
                             if (L.total > merged_limit) continue;
+                            if (o.wl_bytes == 0 && !no_head) {   // lists in HBM scratch: an LDS head of what the carving leaves
+                                const size_t room = (merged_limit - L.total) & ~(size_t)1023;
+                                o.wl_head = (int)std::min(room, (size_t)OBS_WL_HEAD_MAX);
+                                if (o.wl_head < OBS_WL_HEAD_MIN) o.wl_head = 0;
+                                if (o.wl_head) L = obs_layout(d, P, o);
+                            }
                             accept(o, L);
                             return true;
                         }
@@ -433,9 +438,9 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     if (getenv("FL_OBS_VERBOSE")) {   // diagnostic: the carving of the LDS, array by array (enum L_* of fl_obs_layout.h)
         const ObsOptions &q = g_last_options;
-        fprintf(stderr, "  options {nt %d, wl_bytes %d, tab %d, nh %d, tmask %d, dual %d, items %d, snext %d, partial %d, bk_room %d, own_filter %d, fb %d, raw %d, items_cap %d}; "
+        fprintf(stderr, "  options {nt %d, wl_bytes %d, tab %d, nh %d, tmask %d, dual %d, items %d, snext %d, partial %d, bk_room %d, own_filter %d, fb %d, raw %d, items_cap %d, wl_head %d}; "
                         "shape {merged %d, tw_c %d, tw_t %d, tpw_t %d, tree_pred %d}; bk %d tshift %d wl_occ_div %d\n",
-                q.nt, q.wl_bytes, q.tab, q.nh, q.tmask, q.dual, q.items, q.snext, q.partial, q.bk_room, q.own_filter, q.fb, q.raw, q.items_cap,
+                q.nt, q.wl_bytes, q.tab, q.nh, q.tmask, q.dual, q.items, q.snext, q.partial, q.bk_room, q.own_filter, q.fb, q.raw, q.items_cap, q.wl_head,
                 P.merged, P.tw_c, P.tw_t, P.tpw_t, P.tree_pred, P.bk, P.tshift, P.wl_occ_div);
         static const char *names[L_COUNT] = {"cellw", "nbr", "snext", "rkey", "slot_agent", "slot_ready", "cell_target", "a_speed", "a_vpos", "a_pos", "a_tslot",
             "a_target", "a_malf", "a_tpc", "a_tq", "a_tq2", "a_raw", "rtype", "a_lp", "a_n", "a_srank", "a_dir", "a_state", "a_free", "a_dead", "misc", "team_meta", "node_tables",

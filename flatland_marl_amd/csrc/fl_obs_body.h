@@ -281,6 +281,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.wl_occ = WL_HBM ? S.wl + (size_t)b * OBS_WL_HBM_ENTRIES : reinterpret_cast<uint2 *>(wl_lds);
     X.wl_occ_cap = X.tmask ? wl_entries / p_wl_occ_div : wl_entries;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;
+    {   // LDS head of HBM lists (one-pass kernels only; the launcher gives it what the carving leaves): split like the lists
+        const int head_entries = (WL_HBM && MERGED != 0 && L_OFF(L_WL) != L_ABSENT) ? L_FIELD(wl_head) / 8 : 0;
+        uint2 *head = head_entries > 0 ? LDS_AT(uint2, L_WL) : nullptr;
+        X.wl_head_occ = head; X.wl_head_occ_n = head_entries / p_wl_occ_div;
+        X.wl_head_cf = head + X.wl_head_occ_n; X.wl_head_cf_n = head_entries - X.wl_head_occ_n;
+    }
     X.wl_cnt = misc + 8;
     X.long_lists = misc + 11;
     X.tshift = X.Tn <= 64 ? 0 : P.tshift;  // bucket = tb_of(t, tshift)
@@ -1073,7 +1079,14 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         }
         __syncthreads();
 #ifdef FL_OBS_TIMING
-        if (STAGE != 2 && tid == 0) P.dbg[(size_t)b * 64 + 57] = (long long)wall_clock64();   // items filled
+        if (STAGE != 2 && tid == 0) {
+            P.dbg[(size_t)b * 64 + 57] = (long long)wall_clock64();   // items filled
+            // what this env keeps in scratch: prediction items of the first index, waypoints of the predicted paths
+            int wp = 0;
+            for (int i = 0; i < A; i++) wp += a_n[i];
+            P.dbg[(size_t)b * 64 + 58] = misc[2];
+            P.dbg[(size_t)b * 64 + 59] = wp;
+        }
 #endif
         if (bk) {  // LDS-resident offsets: the list of key k is [csr[k], csr[k + 1]) now and its bucket ends stay in LDS; bucket-major
                    // (large maps): the ends of the keys inside every bucket go to HBM (the node tables take their LDS back)

@@ -43,6 +43,10 @@ struct ObsCtx {
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
     bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
+    // LDS HEAD of HBM work lists (round 5): entries [0, wl_head_*_n) of a list live in LDS, the others in HBM scratch at the same
+    // index -- the entries a round pushes first never leave the CU (cfg4: the 16 KB an LDS copy of the items held without use)
+    uint2 *wl_head_occ, *wl_head_cf;
+    int wl_head_occ_n, wl_head_cf_n;   // 0: no head
     int *wl_cnt;                  // LDS [3] entries pushed to wl_occ / wl_cf, flag: some key needs the second conflict pass
     const int *long_lists;        // LDS flag: some key's list has more than CF_DIRECT items (else no conflict query needs chunks)
     const unsigned long long *tmask;  // LDS per key: time buckets tb_of(t, tshift) covered by some item; nullptr = none

@@ -101,6 +101,7 @@ struct ObsLayout {
     unsigned total;         // bytes of dynamic LDS
     int nt;                 // threads per workgroup
     int wl_bytes;           // size of the pass B work lists
+    int wl_head;            // work lists in HBM scratch (wl_bytes 0): bytes of their LDS head (L_WL), 0 = none
     int tab_lds;            // the env's dm / seg / nh / hop8 tables are staged in LDS (kernel template TAB_LDS)
     int items_cap, items2_cap;  // entries of the LDS copies of the prediction items (first / second index); an env with more
                                 // falls back to the items in HBM scratch / to the two stages
@@ -109,7 +110,7 @@ struct ObsLayout {
 // ---- the carving of the dynamic LDS, one function for the host (obs_pick_config: any env size) and for the kernels whose layout
 // is a compile-time constant (FIXED launch classes below: every LDS base is an immediate instead of a scalar register)
 // what a launch may keep in LDS besides the arrays every launch needs
-struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap; };
+struct ObsOptions { int nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap, wl_head; };
 struct ObsDims { int Rcap, A, Ucap, rkey; };                   // capacities of the batch (rkey: colliding prediction keys, H > W)
 struct ObsShape { int merged, tw_c, tw_t, tpw_t, tree_pred; };  // what of ObsArgs decides sizes
 
@@ -150,7 +151,8 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
     const unsigned long long i2 = A * (unsigned long long)(P.tree_pred + 2);  // an agent has at most tree_pred + 1 of them
     L.items2_cap = (int)(i2 < OBS_ITEMS2_CAP ? i2 : OBS_ITEMS2_CAP);
     if (o.items) OBS_PUT(L_ITEMS, (unsigned long long)L.items_cap * 4);
-    if (o.wl_bytes) OBS_PUT(L_WL, o.wl_bytes);       // 0: the work lists live in HBM scratch
+    if (o.wl_bytes) OBS_PUT(L_WL, o.wl_bytes);       // 0: the work lists live in HBM scratch ...
+    else if (o.wl_head) OBS_PUT(L_WL, o.wl_head);    // ... but for their first entries (LDS head)
     if (o.partial || !o.wl_bytes) OBS_PUT(L_PARTIAL, (unsigned long long)o.nt * 4);
     if (o.tmask) OBS_PUT(L_TMASK, K1 * 8);
     if (o.tmask && P.merged && o.own_filter) OBS_PUT(L_TMASK2, K1 * 8);
@@ -167,7 +169,7 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
     if (o.tab) { OBS_PUT(L_SEG, NS * 16); OBS_PUT(L_DM, U * NS * 2); OBS_PUT(L_HOP8, U * NS * 2); }
 #undef OBS_PUT
     L.total = off;
-    L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab;
+    L.nt = o.nt; L.wl_bytes = o.wl_bytes; L.tab_lds = o.tab; L.wl_head = o.wl_bytes ? 0 : o.wl_head;
     return L;
 }
 
@@ -180,6 +182,10 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 // A class is a BASELINE configuration: besides the capacities it fixes the builders' parameters (31 nodes, predictor depths 500 / 30,
 // the upstream tree's depth) and, for the larger ones, the exact number of agents -- all constants in its kernel.
 //   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells, depth 2 -- cfg1, cfg2 (BASELINE configs[0..1])
+#define OBS_FIX3_RCAP 680
+#define OBS_FIX3_WL_HEAD (10 * 1024)
+#define OBS_WL_HEAD_MAX (16 * 1024)   // LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
+#define OBS_WL_HEAD_MIN (4 * 1024)
 template <int FIX> struct ObsFixed;
 template <> struct ObsFixed<1> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;   // the builders' parameters of the class (tree_pred: shape)
@@ -191,7 +197,9 @@ template <> struct ObsFixed<1> {
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 //   FIX 2: rounds of 32 agents, work lists in LDS (MODE 4, VAR 0): 80 agents, at most 232 rail cells, depth 3 -- cfg3 (BASELINE configs[2])
-//   FIX 3: rounds of 32 agents, work lists in HBM scratch (MODE 4, VAR 2): 80 agents, at most 656 rail cells, depth 2 -- cfg4 (configs[3])
+//   FIX 3: rounds of 32 agents, work lists in HBM scratch with an LDS head (MODE 4, VAR 2): 80 agents, at most 680 rail cells -- every
+//          level of the Round-2 row (Test_8: 603 .. 677) --, depth 2 -- cfg4 (configs[3]).  No LDS copy of the items: every cfg4 env has
+//          more items than the 4 096 entries that fitted (round 4: the copy was dead weight); its 16 KB are the larger maps and the head.
 //   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): 400 agents, at most 2688 rail cells, depth 3 -- cfg5 (configs[4])
 // The LDS of these three is full to the last few hundred bytes (that is how obs_pick_config chose their options), so the classes
 // are the BASELINE maps' own sizes rounded up to a multiple of 8 / 16 rail cells; tests/test_obs_config.py checks that each class
@@ -207,9 +215,9 @@ template <> struct ObsFixed<2> {
 template <> struct ObsFixed<3> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr int agents = 80;   // agents per env, exactly (0 = any number up to dims.A)
-    static constexpr ObsDims dims = {656, 80, 0, 0};
+    static constexpr ObsDims dims = {OBS_FIX3_RCAP, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
-    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 4096};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 0, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, OBS_FIX3_WL_HEAD};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<4> {
@@ -239,11 +247,14 @@ template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { r
 // kernel of a class: MODE 3 (one round) / 4 (rounds of 32 agents) / 2 (two stages), VAR 1 (static tables in LDS) / 2 (work lists in HBM scratch) / 0
 template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() { return ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : ObsFixed<FIX>::shape.merged == 3 ? 5 : 2; }
 template <int FIX> __host__ __device__ constexpr int obs_fixed_var() { return ObsFixed<FIX>::opt.tab ? 1 : ObsFixed<FIX>::opt.wl_bytes == 0 ? 2 : 0; }
-// (the next-hop tables in LDS are the one option a class may differ in from the batch's own choice: nh is the class's)
+// The batch's own choice `a` (obs_pick_config's preference walk at the batch's sizes) is the class's kind of configuration: the same
+// structure, and of everything that is "whatever LDS the carving leaves" -- the next-hop tables, the agents' raw words, the
+// capacity of the items' copy, the head of HBM work lists -- at least what the class `b` has (a smaller batch inside the class's
+// capacities affords more of those than the class at its full size; the class's own options then fit it a fortiori).
 __host__ __device__ constexpr bool obs_same_options(const ObsOptions &a, const ObsOptions &b) {
     return a.nt == b.nt && a.wl_bytes == b.wl_bytes && a.tab == b.tab && (a.nh == b.nh || !b.nh) && a.tmask == b.tmask && a.dual == b.dual &&
            a.items == b.items && a.snext == b.snext && a.partial == b.partial && a.bk_room == b.bk_room &&
-           a.own_filter == b.own_filter && a.fb == b.fb && a.raw == b.raw && a.items_cap == b.items_cap;
+           a.own_filter == b.own_filter && a.fb == b.fb && a.raw >= b.raw && (!b.items || a.items_cap >= b.items_cap) && a.wl_head >= b.wl_head && (a.wl_head == 0) == (b.wl_head == 0);
 }
 
 // outputs of the flatland_cutils builder and of the upstream dense tree builder (k_obs MODE 0 / 1 / 2 = both)

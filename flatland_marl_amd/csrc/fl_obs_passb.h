@@ -95,26 +95,34 @@ __device__ __forceinline__ void conflict_event(const ObsCtx &X, bool cu, int *sc
     if (conflict_hit(conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, d, pt, R, 0, R.n))) atomicMin(&nt_w(sc, cap, N_PC, node), tot);
 }
 
-// flag word of a conflict work-list entry (other lanes OR their bits into it)
-__device__ __forceinline__ uint32_t wl_flags(const ObsCtx &X, const uint2 *e) {
-    if (X.wl_hbm) return __hip_atomic_load(&e->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return e->y;
+// Entry i of the occupant / conflict work list.  Lists in HBM scratch may have an LDS HEAD (ObsCtx::wl_head_*): entry i < head
+// entries lives in LDS, any other in HBM at the same index (separate accesses: each pointer keeps its static address space).
+__device__ __forceinline__ uint2 wl_occ_get(const ObsCtx &X, int i) { return i < X.wl_head_occ_n ? X.wl_head_occ[i] : X.wl_occ[i]; }
+__device__ __forceinline__ void wl_occ_put(const ObsCtx &X, int i, uint2 e) { if (i < X.wl_head_occ_n) X.wl_head_occ[i] = e; else X.wl_occ[i] = e; }
+__device__ __forceinline__ uint2 wl_cf_get(const ObsCtx &X, int i) { return i < X.wl_head_cf_n ? X.wl_head_cf[i] : X.wl_cf[i]; }
+__device__ __forceinline__ void wl_cf_put(const ObsCtx &X, int i, uint2 e) { if (i < X.wl_head_cf_n) X.wl_head_cf[i] = e; else X.wl_cf[i] = e; }
+__device__ __forceinline__ void wl_cf_set_y(const ObsCtx &X, int i, uint32_t y) { if (i < X.wl_head_cf_n) X.wl_head_cf[i].y = y; else X.wl_cf[i].y = y; }
+__device__ __forceinline__ void wl_cf_or_y(const ObsCtx &X, int i, uint32_t bits) { if (i < X.wl_head_cf_n) atomicOr(&X.wl_head_cf[i].y, bits); else atomicOr(&X.wl_cf[i].y, bits); }
+// flag word of a conflict work-list entry (other lanes OR their bits into it): HBM lists merge them with L2 atomics, read them past the L1
+__device__ __forceinline__ uint32_t wl_cf_flags(const ObsCtx &X, int i) {
+    if (i < X.wl_head_cf_n) return X.wl_head_cf[i].y;
+    if (X.wl_hbm) return __hip_atomic_load(&X.wl_cf[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return X.wl_cf[i].y;
 }
 
-// append e to a work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
-__device__ __forceinline__ bool wl_push(uint2 *list, int cap, int *count, bool want, uint2 e, int *idx_out = nullptr) {
+// append e to the conflict work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
+__device__ __forceinline__ bool wl_push_cf(const ObsCtx &X, bool want, uint2 e) {
     const unsigned long long m = __ballot(want);
     if (m == 0) return true;
     const int lane = (int)__lane_id();
     // the first ACTIVE lane reserves the slots for the wavefront; its result is broadcast with v_readfirstlane (a shuffle
     // would be another LDS round trip)
     int base = 0;
-    if (lane == __ffsll((long long)__ballot(1)) - 1) base = atomicAdd(count, __popcll(m));
+    if (lane == __ffsll((long long)__ballot(1)) - 1) base = atomicAdd(&X.wl_cnt[1], __popcll(m));
     base = __builtin_amdgcn_readfirstlane(base);
     const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (want && idx < cap) list[idx] = e;
-    if (idx_out) *idx_out = idx;
-    return !want || idx < cap;
+    if (want && idx < X.wl_cf_cap) wl_cf_put(X, idx, e);
+    return !want || idx < X.wl_cf_cap;
 }
 
 // Slots in BOTH work lists with one LDS atomic per wavefront (the two counters are the halves of one 64-bit word), split in
@@ -436,11 +444,11 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             int i_occ, i_cf;
             wl_reserve2_finish(resv, m_occ, m_cf, i_occ, i_cf);
             if (occ) {
-                if (i_occ < X.wl_occ_cap) X.wl_occ[i_occ] = entry;
+                if (i_occ < X.wl_occ_cap) wl_occ_put(X, i_occ, entry);
                 else occ_event(X, e_cu, sc, e_cap, e_node, sl, e_dd, e_tot);  // list full
             }
             if (to_cf) {
-                if (i_cf < X.wl_cf_cap) X.wl_cf[i_cf] = entry;
+                if (i_cf < X.wl_cf_cap) wl_cf_put(X, i_cf, entry);
                 else conflict_event<PB, ITL, TWO>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);  // list full
             } else if (cand) {
                 conflict_event<PB, ITL, TWO>(X, e_cu, sc, e_cap, e_node, e_handle, e_cell, e_dd, e_tot, pt);
@@ -469,7 +477,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     if (X.dbg && tid == 0) { X.dbg[X.dbg_base + 9] += n_occ; X.dbg[X.dbg_base + 10] += n_cf; }
 #endif
     for (int e = tid; e < n_occ; e += nt) {
-        const uint2 w = X.wl_occ[e];
+        const uint2 w = wl_occ_get(X, e);
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         constexpr int cap = PB == 2 ? 32 : CAP;
         int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
@@ -478,7 +486,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     WAVE_MARK(X, 12, -1);
     if (*X.long_lists == 0) {  // every list is short: one pass, every lane scans the list of its entry
         for (int e = tid; e < n_cf; e += nt) {
-            const uint2 w = X.wl_cf[e];
+            const uint2 w = wl_cf_get(X, e);
             const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
             const int handle = pb_handle<PB>(X, team_meta, team), tot = (int)(w.y & 511u);
             const bool cu = pb_cu<PB>(X, team);
@@ -522,7 +530,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         bool cu = PB == 1;
         uint2 w = make_uint2(0u, 0u);
         if (e < n_cf) {
-            w = X.wl_cf[e];
+            w = wl_cf_get(X, e);
             cell = (int)((w.x & 0xFFFFFFu) >> 2);
             const int team = (int)(w.x >> 24);
             handle = pb_handle<PB>(X, team_meta, team);
@@ -548,15 +556,15 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                     atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
                 }
             } else {
-                X.wl_cf[e].y = w.y | ((uint32_t)nch << 9) | ((f & 63u) << 15);
+                wl_cf_set_y(X, e, w.y | ((uint32_t)nch << 9) | ((f & 63u) << 15));
                 any_multi = true;
             }
         }
         for (int j = 1; __any(j < nch); j++) {
-            if (!wl_push(X.wl_cf, X.wl_cf_cap, &X.wl_cnt[1], j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
+            if (!wl_push_cf(X, j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
                 // list full: this chunk is scanned here
                 const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, j * CF_CHUNK, j == 62 ? R.n : min(R.n, (j + 1) * CF_CHUNK));
-                if (f & 63u) atomicOr(&X.wl_cf[e].y, (f & 63u) << 15);
+                if (f & 63u) wl_cf_or_y(X, e, (f & 63u) << 15);
             }
         }
     }
@@ -568,23 +576,23 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     if (X.wl_cnt[2] == 0) return;   // (workgroup-uniform) every list fitted one chunk
     const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
     for (int e = n_cf + tid; e < n_cf2; e += nt) {  // the further chunks
-        const uint2 w = X.wl_cf[e];
+        const uint2 w = wl_cf_get(X, e);
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
         const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u);
-        const uint32_t fy = wl_flags(X, &X.wl_cf[first]);
+        const uint32_t fy = wl_cf_flags(X, first);
         const int tot = (int)(fy & 511u);
         const int handle = pb_handle<PB>(X, team_meta, team);
         const bool cu = pb_cu<PB>(X, team);
         const int pt = pt_of<PB>(X, cu, handle, tot);
         const ListRange R = list_range<PB>(X, cu, cell, pt);
         const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, chunk * CF_CHUNK, chunk == 62 ? R.n : min(R.n, (chunk + 1) * CF_CHUNK));
-        if (f & 63u) atomicOr(&X.wl_cf[first].y, (f & 63u) << 15);
+        if (f & 63u) wl_cf_or_y(X, first, (f & 63u) << 15);
     }
     __syncthreads();
     {  // keys with more than one chunk: the first entry has collected all flags
         for (int e = tid; e < n_cf; e += nt) {
-            uint2 w = X.wl_cf[e];
-            w.y = wl_flags(X, &X.wl_cf[e]);
+            uint2 w = wl_cf_get(X, e);
+            w.y = wl_cf_flags(X, e);
             if (((w.y >> 9) & 63u) <= 1u) continue;
             if (conflict_hit((w.y >> 15) & 63u)) {
                 constexpr int cap = PB == 2 ? 32 : CAP;

@@ -28,7 +28,7 @@ def _same(got, exp, msg):
     ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10, 3, (2, 0)),
     # the per-GPU shard of cfg4 as the bench runs it: rounds of 32 agents, pass-B work lists in HBM scratch (per-env stride) AND
     # the longest-first workgroup order of k_env_order (more envs than CUs)
-    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2, (3, 1)),
+    ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2, (3, 0)),      # (class 3 holds every level of the row: 603 .. 677 rail cells)
     ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3, (4, 1)),
     # the SINGLE-map shards of bench.py's EXTRA_WORKLOADS and of the profiles of record: every env fits its class -- k_obs<4,2,3>
     # with k_env_order and the per-env HBM work-list stride at B = 512, k_obs<2,2,4> with the masked rebuild at B = 256
@@ -60,7 +60,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         if t == 0:      # which kernel builds the batch: the class, for every env (split 0) or for the envs that fit it (split 1)
             fix, split, n_fit = env.last_obs_class()
             rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
-            cap = {2: 232, 3: 656, 4: 2688, 5: 256}[klass[0]]
+            cap = {2: 232, 3: 680, 4: 2688, 5: 256}[klass[0]]
             assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
             if split:   # both bodies are under test: replicas on either side of the class's capacity among the picks / shadows
                 assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]
@@ -103,13 +103,29 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         s_env.check()
 
 
-def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2, want_class=None):
+def _big_cfg4_env():
+    """the Round-2 row of cfg4 (Test_8) with 20 cities instead of 17: 695 rail cells (the row's own levels: 603 .. 677)"""
+    from flatland_marl_amd import generators as gen, workload as wl
+    p = wl.round2_params("Test_8")
+    rg = gen.sparse_rail_generator(max_num_cities=20, grid_mode=p["grid_mode"], max_rails_between_cities=p["max_rails_between_cities"],
+                                   max_rail_pairs_in_city=p["max_rail_pairs_in_city"])
+    lg = gen.sparse_line_generator(dict(zip(p["speed_values"], p["speed_probs"])))
+    st = gen.np_random(3).get_state()
+    e = gen.generate_env(60, 60, 80, rg, lg, st[1], st[2], 1.0 / p["malfunction_interval"], p["malfunction_duration_min"], p["malfunction_duration_max"])
+    assert int((np.asarray(e["grid"]) != 0).sum()) == 695
+    return e
+
+
+def _cfg4_digest(steps=24, workload="cfg4", B=512, distinct=4, depth=2, want_class=None, big=False):
     """sha256 over the state, rewards and both observations of every step of the full cfg4 shard (or of another workload);
     want_class: (fixed launch class, split) the launches must have taken"""
     import hashlib
     from flatland_marl_amd import workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
     envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
+    if big:        # every seventh env: a 60 x 60 / 80-agent map of 695 rail cells, beyond class 3's 680
+        for b in range(5, B, 7):
+            envs[b] = dict(_big_cfg4_env(), mt_key=envs[b]["mt_key"], mt_pos=envs[b]["mt_pos"])
     env = BatchedRailEnv(envs)
     h = hashlib.sha256()
     for t in range(steps):
@@ -138,13 +154,15 @@ def _child(switches, *argv):
 
 
 def test_workgroup_order_and_the_split_of_a_launch_do_not_change_the_results_at_cfg4():
-    """The cfg4 shard on four distinct maps, two of them beyond class 3's rail cells: the default launch is the class's SPLIT kernel
-    (class body / runtime-carving body per env) with the envs handed to the workgroups longest first by k_env_order (B > CUs).
-    FL_OBS_NO_ORDER (read once per process, hence the children) makes workgroup k build env k; FL_OBS_NO_SPLIT runs every env on
-    the runtime-carving kernel k_obs<4,2,0>.  Same bytes all three ways."""
-    want = _cfg4_digest(want_class=(3, 1))
+    """The cfg4 shard on four levels of its Round-2 row plus a larger map (695 rail cells, beyond class 3's 680) in every seventh env:
+    the default launch is the class's SPLIT kernel (class body / runtime-carving body per env) with the envs handed to the
+    workgroups longest first by k_env_order (B > CUs).  FL_OBS_NO_ORDER (read once per process, hence the children) makes workgroup
+    k build env k; FL_OBS_NO_SPLIT runs every env on the runtime-carving kernel k_obs<4,2,0>; FL_OBS_NO_WL_HEAD keeps every
+    work-list entry in HBM scratch (no LDS head; the class then does not apply either).  Same bytes all four ways."""
+    want = _cfg4_digest(want_class=(3, 1), big=True)
     assert _child(("FL_OBS_NO_ORDER",), "cfg4", "3", "1") == {"cfg4": want}
     assert _child(("FL_OBS_NO_SPLIT",), "cfg4", "0", "0") == {"cfg4": want}
+    assert _child(("FL_OBS_NO_WL_HEAD",), "cfg4", "0", "0") == {"cfg4": want}
 
 
 CASES = {"cfg3": dict(steps=60, workload="cfg3", B=24, distinct=3, depth=3), "cfg2": dict(steps=80, workload="cfg2", B=16, distinct=4, depth=2)}
@@ -169,4 +187,4 @@ if __name__ == "__main__":
             klass = (0, 0) if sys.argv[2] == "0" or k == "cfg3" else CLASS_OF[k]
             print("DIGEST", k, _cfg4_digest(want_class=klass, **kw))
     else:
-        print("DIGEST cfg4", _cfg4_digest(want_class=(int(sys.argv[2]), int(sys.argv[3]))))
+        print("DIGEST cfg4", _cfg4_digest(want_class=(int(sys.argv[2]), int(sys.argv[3])), big=True))

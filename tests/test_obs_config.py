@@ -38,7 +38,7 @@ def _sizes(workload):
     ("cfg1", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
     ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
     ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=2)),
-    ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=3)),
+    ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=0, merged=2, compact=1, fix=3)),      # (round 5: no LDS copy of the items, an LDS head of the HBM lists)
     ("cfg3", 2, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=0)),   # not BASELINE's depth: runtime carving
     ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=0)),
     ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=4)),   # round 2: 512 threads (85-slot tables)
@@ -61,7 +61,7 @@ def test_grids_with_three_way_cells_take_the_dfs_slot_tables():
     assert got["merged"] == 0 and got["compact"] == 1, got
 
 
-@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 656, 24, 2), (4, 400, 2688, 53, 3)])
+@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 680, 24, 2), (4, 400, 2688, 53, 3)])
 def test_every_fixed_launch_class_is_the_choice_at_its_own_capacities(fix, A, R, U, depth):
     """ObsFixed<k>::opt is hand-written; this keeps it honest: at the class's capacities obs_pick_config's own preference walk
     lands on exactly those options (otherwise the class is never taken and `fix` stays 0), the carving fits 160 KiB, and one

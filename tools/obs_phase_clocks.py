@@ -21,19 +21,46 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 from flatland_marl_amd import workload as wl  # noqa: E402
 
-envs, seed = wl.make_envs(workload)
+distinct = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+envs, seed = wl.make_envs(workload, distinct=distinct)
 env = hb.BatchedRailEnv(envs, device=0)
 L = hb.lib()
 L.fl_debug_obs_clocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 acc = []
-warm = int(os.environ.get("WARM", "200"))
-for t in range(warm + 100):
+# The clocks are taken in the BENCH's regime (round 5): the replicas are de-phased exactly as bench.py does before its timed region
+# (env b starts over once at an offset drawn from [0, T_b) by the same generator; the last 64 de-phasing steps with the observations),
+# then the bench's default warm-up -- the same steady-state mix of episode phases, the same number of agents on the map.
+# NO_DEPHASE=1: from a synchronised reset (what rounds 1 - 4 printed), WARM steps before the clocks are read.
+B = env.B
+if os.environ.get("NO_DEPHASE"):
+    warm = int(os.environ.get("WARM", "200"))
+else:
+    rs = np.random.RandomState(12345)
+    offs = np.array([rs.randint(0, int(e["T"])) for e in envs])
+    dephase_steps = int(max(int(e["T"]) for e in envs))
+    by_step = {}
+    for b, o in enumerate(offs):
+        by_step.setdefault(int(o), []).append(b)
+    for s in range(dephase_steps):
+        env.step_synth(seed, 0, 0, auto_reset=True)
+        if s >= dephase_steps - 64:
+            env.obs_both(depth, 30)
+        if s in by_step:
+            m = np.zeros(B, dtype=np.uint8)
+            m[by_step[s]] = 1
+            env.reset(m, fresh=True)
+    warm = int(os.environ.get("WARM", "20"))
+n_clock = int(os.environ.get("STEPS", "100"))
+on_map = []
+for t in range(warm + n_clock):
     env.step_synth(seed, 0, 0, auto_reset=True)
     env.obs_both(depth, 30)
     if t >= warm:
         out = np.zeros((env.B, 64), dtype=np.int64)
         assert L.fl_debug_obs_clocks(env.h, out.ctypes.data) == 0
         acc.append(out)
+        if t % 10 == 0:
+            on_map.append((env.state()[0][:, :, 0] >= 0).sum(1).mean())
 c = np.stack(acc).astype(np.float64)  # [steps, B, 64]
 # the kernels that build the trees of both builders in stage 1 have no stage 2: the kernel ends with stage 1's last stamp
 c[:, :, 37] = np.where(c[:, :, 37] > 0, c[:, :, 37], c[:, :, 5])
@@ -49,7 +76,9 @@ def dur(k):
 
 def report():
 
-    print("%s, upstream depth %d: on-map agents %.1f of %d" % (workload, depth, (env.state()[0][:, :, 0] >= 0).sum(1).mean(), env.A))
+    print("%s, upstream depth %d%s, %s: on-map agents %.1f of %d (mean over the clocked steps), launch class %s" %
+          (workload, depth, ", %d distinct maps" % distinct if distinct else "", "synchronised reset + %d steps" % warm if os.environ.get("NO_DEPHASE") else "de-phased like bench.py",
+           float(np.mean(on_map)), env.A, env.last_obs_class()))
     print("stage 1 (cutils):")
     print("  p0 stage %.1f  p1 %.1f  p2a walk|phase1|passA + count %.1f  p2b scan/fill %.1f" % (seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4)))
     print("     since p2a start: deadlock wavefront done %.1f, walkers done %.1f, hoisted pass A done %.1f, rest of phase 1 done %.1f" % (seg(2, 20), seg(2, 21), seg(2, 19), seg(2, 22)))
@@ -81,6 +110,11 @@ def report():
             (c[:, :, 27].mean(), c[:, :, 59].mean(), c[:, :, 28].mean(), c[:, :, 60].mean(), c[:, :, 29].mean(), c[:, :, 61].mean(), c[:, :, 30].mean(), c[:, :, 62].mean(), c[:, :, 31].mean(), c[:, :, 63].mean()))
     print("work-list entries (sum over rounds): occupant %.0f / %.0f, conflict %.0f / %.0f  (cutils / upstream)" %
           (c[:, :, 9].mean(), c[:, :, 41].mean(), c[:, :, 10].mean(), c[:, :, 42].mean()))
+    if c[:, :, 58].max() > 0:
+        # scratch an env writes and reads back per launch, by kind (requested bytes): a work-list entry is 8 B, an item 4 B, a waypoint 2 B
+        ent = c[:, :, 9].mean() + c[:, :, 10].mean() + (c[:, :, 41].mean() + c[:, :, 42].mean() if c[:, :, 32].max() > 0 else 0)
+        print("scratch per env-step (requested bytes): prediction items %.0f (%.1f KB), predicted waypoints %.0f (%.1f KB), work-list entries %.0f (%.1f KB)" %
+              (c[:, :, 58].mean(), c[:, :, 58].mean() * 4 / 1024, c[:, :, 59].mean(), c[:, :, 59].mean() * 2 / 1024, ent, ent * 8 / 1024))
 
 
 report()
