@@ -812,6 +812,14 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
     return FL_OK;
 }
 
+int fl_obs_set_mode(fl_batch *h, int flags) {
+    NEED_COMMIT(h);
+    if (flags & ~FL_OBS_KEEP_TREE_ROWS) { set_err("fl_obs_set_mode: unknown flag"); return FL_ERR_ARG; }
+    h->obs.keep_rows = (flags & FL_OBS_KEEP_TREE_ROWS) != 0;
+    h->obs.rows_out = nullptr;      // the next launch fills its whole slab and starts the row masks afresh
+    return FL_OK;
+}
+
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     NEED_COMMIT(h);
     if (max_depth < 1 || max_depth > 3 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {

@@ -24,6 +24,10 @@ struct FlObsScratch {
     int *order;        // [B] env of workgroup k, longest first (k_env_order), or null: env k (batches of at most one env per CU)
     int n_cu;          // CUs of the device
     unsigned order_age;  // ordered launches so far: the order is recomputed every OBS_ORDER_EVERY-th (host side)
+    uint4 *rowmask;    // [B][A] the rows of the agent's upstream tree that were real nodes in the previous launch (x, y, z: bits 0 .. 95 of the
+                       // DFS row index; w: 1 = valid) -- see FL_OBS_KEEP_TREE_ROWS
+    const double *rows_out; int rows_depth;   // host side: buffer and depth the masks describe (null: none yet)
+    int keep_rows;     // host side: fl_obs_set_mode(FL_OBS_KEEP_TREE_ROWS)
     const int *h_R;    // HOST [B] rail cells of every env (the handle's copy; null: unknown) -- which envs of a batch fit a fixed launch class
     int last_fix, last_split, last_fit;  // host side, diagnostic: class of the last fused launch (0 = runtime carving), whether the class
                                          // served only the envs that fit it, and how many envs took the class's body

@@ -27,6 +27,10 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.wl_cap = OBS_WL_HBM_ENTRIES;
     if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
     o.wl = (uint2 *)p; allocs.push_back(p);
+    if (hipMalloc(&p, BA * sizeof(uint4)) != hipSuccess) return FL_ERR_HIP;
+    o.rowmask = (uint4 *)p; allocs.push_back(p);
+    if (hipMemsetAsync(o.rowmask, 0, BA * sizeof(uint4), s) != hipSuccess) return FL_ERR_HIP;
+    o.rows_out = nullptr; o.rows_depth = 0; o.keep_rows = 0;
     if (hipMalloc(&p, (size_t)d.B * 4) != hipSuccess) return FL_ERR_HIP;
     o.cost = (uint32_t *)p; allocs.push_back(p);
     if (hipMemsetAsync(o.cost, 0, (size_t)d.B * 4, s) != hipSuccess) return FL_ERR_HIP;
@@ -110,6 +114,7 @@ template <int FIX>
 static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o, ObsLayout &L) {
     using F = ObsFixed<FIX>;
     if (F::opt.wl_head && obs_no_wl_head()) return false;
+    if ((FIX == 1 || FIX == 5) && P.keep_mode) return false;   // (the small-env classes carry no row-mask code: FL_OBS_KEEP_TREE_ROWS runs the runtime carving there)
     const size_t nh_bytes = F::opt.nh ? (((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15) : 0;
     if (!(d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) && P.merged == F::shape.merged &&
           P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
@@ -387,7 +392,14 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
     P.wide = o.n_cu > 0 && d.B >= OBS_WIDE_ENVS_PER_CU * o.n_cu;
+    P.keep_mode = o.keep_rows;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    // FL_OBS_KEEP_TREE_ROWS: the row masks of the previous launch describe this very buffer at this depth -> no pre-fill of the slab
+    P.keep_rows = o.keep_rows && o.rows_out == tree_out && o.rows_depth == max_depth;
+    o.rows_out = tree_out; o.rows_depth = max_depth;
+    uint4 *const rowmask = o.rowmask;
+    if (!o.keep_rows) o.rowmask = nullptr;   // (mode off: the kernels keep no row masks; restored below -- `u` is a copy of o)
+    struct Restore { FlObsScratch &o; uint4 *m; ~Restore() { o.rowmask = m; } } restore{o, rowmask};
     const int n_split = obs_take_split_class(d, P, o.h_R);
     o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
     obs_verbose(P);
@@ -421,6 +433,11 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     P.dbg = o.dbg;
     obs_tree_args(d, P, max_depth, pred_depth, out);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
+    P.keep_rows = o.keep_rows && o.rows_out == out && o.rows_depth == max_depth;
+    o.rows_out = out; o.rows_depth = max_depth;
+    uint4 *const rowmask = o.rowmask;
+    if (!o.keep_rows) o.rowmask = nullptr;   // (mode off: the kernels keep no row masks)
+    struct Restore { FlObsScratch &o; uint4 *m; ~Restore() { o.rowmask = m; } } restore{o, rowmask};
     o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);
     return fl_obs_launch_m1(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);

@@ -216,8 +216,9 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const int nw_walk0 = min((nt >> 6) - ((nt >> 6) > 4 ? 1 : 0), max(2, (A + 7) / 8));
         // (a slice of the pre-fill in every round of the first stage's trees instead measured slower at cfg5, 1.73 against 1.65 ms:
         // the next global load of a wavefront waits for its stores)
-        bg_prefill = CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6);
-        if ((!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill) {
+        // (FL_OBS_KEEP_TREE_ROWS: the buffer still holds the previous launch's rows -- no pre-fill, upstream_rows sets the stale ones)
+        bg_prefill = CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6) && !P.keep_rows;
+        if ((!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill && !P.keep_rows) {
             // the upstream trees of the env: every row that is not a real node is -inf (observations.py:247, 489); the builders
             // only write the real rows later.  Coalesced 16-byte stores beside the staging.  The wait below (before the barrier
             // that ends this phase) lets them reach the L2 ahead of any later store of this workgroup to the same rows -- same CU,
@@ -1112,20 +1113,20 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (merged) {
-        if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
-        else trees_merged<false, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs);
+        if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
+        else trees_merged<false, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
     } else if (p_compact_t) {
-        if (items_in_lds) tree_upstream<16, OBS_CAP_T_COMPACT, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
-        else tree_upstream<16, OBS_CAP_T_COMPACT, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        if (items_in_lds) tree_upstream<16, OBS_CAP_T_COMPACT, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
+        else tree_upstream<16, OBS_CAP_T_COMPACT, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
     } else if (P.max_depth <= 2) {
-        if (items_in_lds) tree_upstream<32, 32, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
-        else tree_upstream<32, 32, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        if (items_in_lds) tree_upstream<32, 32, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
+        else tree_upstream<32, 32, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
     } else {
-        if (items_in_lds) tree_upstream<64, 88, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
-        else tree_upstream<64, 88, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta);
+        if (items_in_lds) tree_upstream<64, 88, false, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
+        else tree_upstream<64, 88, false, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
     }
     OBS_STAMP(5);
 #undef LDS_AT

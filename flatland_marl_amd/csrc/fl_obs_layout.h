@@ -279,6 +279,10 @@ struct ObsArgs {
                        // of 32 agents, 3: rounds of 16 agents on 512 threads (at most 80 KB of LDS: two workgroups a CU)
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
+    int keep_mode;     // host side: FL_OBS_KEEP_TREE_ROWS is on for this handle (the kernels keep row masks; classes 1 and 5 -- the headline
+                       // kernels, which carry no code for it -- are not taken)
+    int keep_rows;     // upstream tree: the output buffer still holds the previous launch's rows (FL_OBS_KEEP_TREE_ROWS and the same buffer and
+                       // depth as that launch): no -inf pre-fill of the slab, only the rows that were real nodes then and are not now
     int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
     int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
                        // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving

@@ -148,12 +148,49 @@ template <bool COMPACT>
 __device__ __forceinline__ int upstream_slots(const ObsArgs &P) { return COMPACT ? (2 << P.max_depth) - 2 : P.n_tree_nodes; }
 
 // the real rows of one upstream tree: the root (observations.py:217-229) and the nodes of its table; the rest of the slab is -inf already
+// Which rows are real nodes is kept per agent (rowmask: 96 bits, depth <= 3) from launch to launch: a caller that hands over the SAME
+// output buffer again, untouched (FL_OBS_KEEP_TREE_ROWS), gets no pre-fill of the slab -- 63 % of cfg5's output bytes are that
+// constant -- only the rows that were real then and are not now are set to -inf.  All lanes of the team take part (shuffles).
 template <int TEAM, int CAP, bool COMPACT, int STRIDE = CAP>
-__device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P, int b, int i, bool have, int tl, const int *scr) {
-    if (!have) return;
+__device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P, int b, int i, bool have, int tl, const int *scr, uint4 *rowmask) {
     const int NN = P.n_tree_nodes;
-    double *out = P.tree_out + (size_t)(b * X.A + i) * NN * 12;
     const int ns = upstream_slots<COMPACT>(P);
+    if (rowmask) {
+        uint32_t m0 = 0, m1 = 0, m2 = 0;
+        if (have) {
+            if (tl == 0) m0 = 1u;   // the root
+            for (int k = tl; k < ns; k += TEAM) {
+                if (nt_start((uint32_t)nt_r(scr, STRIDE, N_SE, k)) < 0) continue;
+                const int row = nt_row((uint32_t)nt_r(scr, STRIDE, N_UF, k));
+                if (row < 32) m0 |= 1u << row; else if (row < 64) m1 |= 1u << (row - 32); else m2 |= 1u << (row - 64);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < TEAM; off <<= 1) {
+            m0 |= (uint32_t)__shfl_xor((int)m0, off, TEAM); m1 |= (uint32_t)__shfl_xor((int)m1, off, TEAM); m2 |= (uint32_t)__shfl_xor((int)m2, off, TEAM);
+        }
+        if (have) {
+            uint4 *mk = rowmask + (size_t)b * X.A + i;
+            if (P.keep_rows) {
+                const uint4 old = *mk;      // (every lane of the team: one broadcast load)
+                uint32_t st[3] = {old.x & ~m0, old.y & ~m1, old.z & ~m2};
+                double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)(b * X.A + i) * NN * 12);
+                const double2 ninf = make_double2(-INFINITY, -INFINITY);
+                int n = 0;
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+                    for (uint32_t m = st[w]; m; m &= m - 1, n++)
+                        if (n % TEAM == tl) {
+                            const int row = w * 32 + __ffs((int)m) - 1;
+#pragma unroll
+                            for (int q = 0; q < 6; q++) o2[row * 6 + q] = ninf;
+                        }
+            }
+            if (tl == 0) *mk = make_uint4(m0, m1, m2, 1u);
+        }
+    }
+    if (!have) return;
+    double *out = P.tree_out + (size_t)(b * X.A + i) * NN * 12;
     if (tl == TEAM - 1) {  // (a lane without a slot in the compact tables)
         const int vpos = X.a_vpos[i];
         const uint16_t dv = X.dm[X.a_tslot[i] * X.SS + vpos * 4 + (int)X.a_dir[i]];
@@ -177,7 +214,7 @@ __device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P,
 
 template <int TEAM, int CAP, bool COMPACT, bool ITL>
 __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
-                                              int nwaves, int *wave_scr0, int *team_meta) {
+                                              int nwaves, int *wave_scr0, int *team_meta, uint4 *rowmask) {
     constexpr int TPW = 64 / TEAM;  // teams per wavefront
     constexpr int TW = N_WORDS_T * CAP;
     const int A = X.A;
@@ -199,7 +236,7 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
         }
         wg_pass_b<0, CAP, ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr0, TW, team_meta);
         TREE_STAMP(X, 7);
-        upstream_rows<TEAM, CAP, COMPACT>(X, P, b, i, have, tl, scr);
+        upstream_rows<TEAM, CAP, COMPACT>(X, P, b, i, have, tl, scr, rowmask);
         team_sync();
         TREE_STAMP(X, 8);
     }
@@ -415,7 +452,7 @@ template <bool ITL, bool MULTI, int ROUND, typename LATE>
 __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane, int nwaves,
                                              int *wave_scr, int *team_meta, const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot, float max_dist,
-                                             const LATE &late) {
+                                             const LATE &late, uint4 *rowmask) {
     constexpr int CT = OBS_CAP_T_COMPACT;
     const int A = X.A;
     const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;   // (ct covers 0 .. ROUND - 1)
@@ -453,7 +490,7 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
         if (base == 0) late();  // (whatever the queue still holds)
         TREE_STAMP(X, 7);
         if (ct < ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
-        if (wave_has_u) upstream_rows<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u);
+        if (wave_has_u) upstream_rows<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u, rowmask);
         team_sync();
         TREE_STAMP(X, 16);
     }

@@ -26,7 +26,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
+           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
         L.fl_scores.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        if hasattr(L, "fl_obs_set_mode"):             # (an older build loaded through bench.py --lib for a same-box A/B run has none)
+            L.fl_obs_set_mode.argtypes = [vp, i32]
         L.fl_step_obs.argtypes = [vp, vp, u32, u32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 7 + [i32, i32, vp]
         L.fl_obs_cutils_tree.argtypes = [vp, i32, i32] + [vp] * 7 + [i32, i32, vp]
         L.fl_info.argtypes = [vp, vp, vp, vp, vp]
@@ -94,7 +96,8 @@ def lib():
         L.fl_distance_map.argtypes = [vp, i32, C.POINTER(i32), vp, vp]
         L.fl_distance_map_rebuild.argtypes = [vp]
         L.fl_positions_map.argtypes = [vp, i32, vp]
-        L.fl_debug_last_obs_class.argtypes = [vp, vp]       # diagnostic, not part of the public header
+        if hasattr(L, "fl_debug_last_obs_class"):
+            L.fl_debug_last_obs_class.argtypes = [vp, vp]       # diagnostic, not part of the public header
         L.fl_algorithmic_bytes_per_agent_step.argtypes = [vp, i32, i32]
         L.fl_algorithmic_bytes_per_agent_step.restype = C.c_double
         _lib = L
@@ -354,6 +357,11 @@ class BatchedRailEnv:
                                       o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr(),
                                       max_depth, pred_depth, out.data_ptr()))
         return o, out
+
+    def keep_tree_rows(self, on=True):
+        """FL_OBS_KEEP_TREE_ROWS: the upstream-tree tensor this object hands out is its own buffer, the same from call to call -- as long
+        as the caller does not write into it, the builder only updates the rows that change (no -inf pre-fill of the slab per call)."""
+        _chk(lib().fl_obs_set_mode(self.h, 1 if on else 0))
 
     def policy_inputs(self, obs=None):
         """(agents_attr f32[B,A,83], forest f32[B,A,N,12], adjacency i64[B,A,N-1,3], node_order i64[B,A,N],

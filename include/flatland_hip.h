@@ -177,6 +177,14 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
 /* upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)); pred_depth < 0: no predictor.
  * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);
+/* Opt-in modes of the observation launches of this handle (flags: OR of the values below, 0 = defaults).
+ * FL_OBS_KEEP_TREE_ROWS: the caller promises that the upstream-tree output buffer handed to fl_obs_tree / fl_obs_cutils_tree /
+ *   fl_step_obs is the buffer of the previous such call with the same max_depth, NOT modified in between.  The builder then stops
+ *   re-writing the constant part of its output -- the -inf rows of missing subtrees (observations.py:247, 489: 63 % of the bytes of
+ *   a depth-3 tree at 400 agents) -- and only sets the rows that were real nodes in the previous call and are not now.  Same
+ *   tensors, bit for bit.  A call with another buffer or depth (or the first one) fills the whole slab as without the flag. */
+#define FL_OBS_KEEP_TREE_ROWS 1
+int fl_obs_set_mode(fl_batch *h, int flags);
 
 /* RailEnv.get_info_dict (rail_env.py:452-468) as device tensors: action_required u8[B][A], malfunction i32[B][A],
  * state u8[B][A] (any may be NULL), and the evaluator's scores of each env's last finished episode

@@ -103,6 +103,55 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         s_env.check()
 
 
+@pytest.mark.parametrize("workload,B,steps,depth,rebuild", [("cfg5", 48, 60, 3, True), ("cfg3", 96, 100, 3, False), ("cfg2", 64, 160, 2, False)])
+def test_keep_tree_rows_mode_gives_the_same_tensors(workload, B, steps, depth, rebuild):
+    """FL_OBS_KEEP_TREE_ROWS (fl_obs_set_mode): the upstream-tree buffer is the previous call's, untouched -- the builder writes the
+    real rows and sets only the rows that were real and are not any more, instead of pre-filling the whole slab with -inf per call.
+    Two batches of the same envs in lock step, one with the mode: identical tensors (bit patterns) on every step -- through
+    auto-resets, the separate fl_obs_tree launch, a launch at another depth in between (another buffer: a full fill, and the masks
+    then describe THAT buffer) and a switch of the mode off and on."""
+    import torch
+    from flatland_marl_amd import workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    envs, seed = wl.make_envs(workload, B=B, distinct=2)
+    for b in range(B):
+        if b % 5 == 3:
+            envs[b] = dict(envs[b])
+            envs[b]["T"] = np.int32(19 + b % 13)
+    plain, keep = BatchedRailEnv(envs), BatchedRailEnv(envs)
+    keep.keep_tree_rows()
+    other = 2 if depth == 3 else 3
+    changed = 0
+    prev = None
+    for t in range(steps):
+        for e in (plain, keep):
+            e.step_synth(seed, 0, 2 if t % 40 < 30 else 0, auto_reset=True)
+        if t == steps // 2:
+            keep.keep_tree_rows(False)
+        if t == steps // 2 + 3:
+            keep.keep_tree_rows(True)
+        res = []
+        for e in (plain, keep):
+            if t % 7 == 5:
+                e.obs_cutils()
+                tree = e.obs_tree(depth, 30)
+            else:
+                _, tree = e.obs_both(depth, 30)
+            if t % 11 == 10:                      # another depth in between: its own buffer
+                e.obs_tree(other, 30)
+            if rebuild:
+                e.rebuild_distance_maps(e.done_all)
+            res.append(tree)
+        assert torch.equal(res[0].view(torch.int64), res[1].view(torch.int64)), f"step {t}"
+        cur = torch.isinf(res[0][..., 0]) & (res[0][..., 0] < 0)
+        if prev is not None:
+            changed += int((cur != prev).sum())
+        prev = cur.clone()
+    assert changed > 100            # rows did appear and disappear
+    plain.check(); keep.check()
+    assert plain.metrics().cpu().numpy()[3] >= B // 5
+
+
 def _big_cfg4_env():
     """the Round-2 row of cfg4 (Test_8) with 20 cities instead of 17: 695 rail cells (the row's own levels: 603 .. 677)"""
     from flatland_marl_amd import generators as gen, workload as wl
