@@ -21,7 +21,7 @@
 // order.  The table kernels loop over (listed env, piece of work) pairs with a grid that does not depend on the count, so
 // a masked rebuild in the step loop -- usually no env or one -- costs four near-empty launches, not four launches of
 // B * Ucap * ... workgroups that exit at once.
-__global__ __launch_bounds__(1024) void k_env_list(int B, const uint8_t *__restrict__ mask, int *__restrict__ list, int *__restrict__ count) {
+__global__ __launch_bounds__(1024) void k_env_list(int B, const uint8_t *__restrict__ mask, const int *__restrict__ tab, int *__restrict__ list, int *__restrict__ count) {
     __shared__ int wave_tot[16];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(1024) void k_env_list(int B, const uint8_t *__restr
         __syncthreads();
         int off = base;
         for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = tab ? tab[b] : b;   // (tab: the owner of env b's tables)
         __syncthreads();
         if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; w++) t += wave_tot[w]; base += t; }
         __syncthreads();
@@ -342,8 +342,8 @@ static unsigned table_grid(const FlDev &d, bool masked, size_t per_env) {
     return (unsigned)(g > 0x7fffffffull ? 0x7fffffffull : g);
 }
 
-void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {
-    hipLaunchKernelGGL(k_env_list, dim3(1), dim3(1024), 0, s, d.B, mask_dev, d.env_list, d.env_list + d.B);
+void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s, bool through_tab) {
+    hipLaunchKernelGGL(k_env_list, dim3(1), dim3(1024), 0, s, d.B, mask_dev, through_tab ? d.tab : (const int *)nullptr, d.env_list, d.env_list + d.B);
 }
 
 void fl_launch_distance_maps(const FlDev &d, const uint8_t *mask_dev, hipStream_t s) {

@@ -56,6 +56,12 @@ struct fl_batch {
     std::vector<uint8_t> h_loaded, h_dirty;  // dirty: loaded since the last commit
     std::vector<uint8_t> h_rtype;
     uint8_t *mask_dev;   // [B] staging of host-side env masks (fl_reset, fl_commit after a live replacement)
+    uint8_t *need_dev;   // [B] the envs whose slabs a commit / full rebuild (re)builds: the OWNERS of shared static tables (FlDev::tab)
+    // shared static tables: h_key = content id of env b's map side (rail grid + unique targets), h_tab = the owner of its tables,
+    // h_built = content id of what env b's slabs hold on the device (0 = nothing yet)
+    std::vector<uint64_t> h_key, h_built;
+    std::vector<int> h_tab;
+    std::vector<uint8_t> h_need;
     FlObsScratch obs;
 };
 
@@ -111,6 +117,8 @@ int fl_create(int B, int A, int H, int W, int device, fl_batch **out) {
     h->h_malf_min.assign(B, 0); h->h_malf_max.assign(B, 0); h->h_thr.assign(B, 0);
     h->h_mt.assign((size_t)B * 624, 0);
     h->h_loaded.assign(B, 0); h->h_dirty.assign(B, 0);
+    h->h_key.assign(B, 0); h->h_built.assign(B, 0); h->h_tab.assign(B, 0); h->h_need.assign(B, 0);
+    h->need_dev = nullptr;
     memset(&h->obs, 0, sizeof h->obs);
     *out = h;
     return FL_OK;
@@ -333,6 +341,57 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
     return FL_OK;
 }
 
+// content id of env b's map side: FNV-1a over the rail grid and the unique targets (what the static tables are a function of)
+static uint64_t map_content_key(const fl_batch *h, int b) {
+    const size_t HW = (size_t)h->H * h->W;
+    uint64_t k = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *c = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) { k ^= c[i]; k *= 1099511628211ull; }
+    };
+    mix(&h->h_grid[b * HW], HW * 2);
+    const int U = h->h_U[b];
+    mix(&U, sizeof U);
+    mix(&h->h_ut[(size_t)b * h->A], (size_t)U * sizeof(int));
+    return k ? k : 1;
+}
+static bool same_map_content(const fl_batch *h, int a, int b) {
+    const size_t HW = (size_t)h->H * h->W;
+    return h->h_U[a] == h->h_U[b] && memcmp(&h->h_grid[a * HW], &h->h_grid[b * HW], HW * 2) == 0 &&
+           memcmp(&h->h_ut[(size_t)a * h->A], &h->h_ut[(size_t)b * h->A], (size_t)h->h_U[a] * sizeof(int)) == 0;
+}
+// owners of the static tables (h_tab -> FlDev::tab) and the owners whose slabs have to be (re)built (h_need -> need_dev)
+static int share_tables(fl_batch *h) {
+    static const bool no_share = getenv("FL_NO_SHARED_TABLES") != nullptr;   // diagnostic: every env reads its own slabs
+    const int B = h->B;
+    for (int b = 0; b < B; b++)
+        if (h->h_dirty[b]) h->h_key[b] = map_content_key(h, b);
+    std::vector<std::pair<uint64_t, int>> order(B);
+    for (int b = 0; b < B; b++) order[b] = {h->h_key[b], b};
+    std::sort(order.begin(), order.end());
+    for (int i = 0; i < B;) {
+        int j = i;
+        while (j < B && order[j].first == order[i].first) j++;
+        // envs of one key, ascending: the first env with identical content is the owner (a hash collision keeps its own tables)
+        for (int k = i; k < j; k++) {
+            const int b = order[k].second;
+            int owner = b;
+            if (!no_share)
+                for (int q = i; q < k; q++)
+                    if (h->h_tab[order[q].second] == order[q].second && same_map_content(h, order[q].second, b)) { owner = order[q].second; break; }
+            h->h_tab[b] = owner;
+        }
+        i = j;
+    }
+    for (int b = 0; b < B; b++) {
+        h->h_need[b] = h->h_tab[b] == b && h->h_built[b] != h->h_key[b];
+        if (h->h_need[b]) h->h_built[b] = h->h_key[b];
+    }
+    HIPCHK(hipMemcpyAsync(h->d.tab, h->h_tab.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->need_dev, h->h_need.data(), B, hipMemcpyHostToDevice, h->stream));
+    return FL_OK;
+}
+
 int fl_commit(fl_batch *h) {
     if (!h) return FL_ERR_ARG;
     for (int b = 0; b < h->B; b++)
@@ -351,6 +410,8 @@ int fl_commit(fl_batch *h) {
             h->d.B = B0; h->d.A = A0; h->d.H = H0; h->d.W = W0;
             memset(&h->obs, 0, sizeof h->obs);
             h->mask_dev = nullptr;
+            h->need_dev = nullptr;
+            std::fill(h->h_built.begin(), h->h_built.end(), 0);
         }
         int Ucap = h->reserve_U > 1 ? h->reserve_U : 1, Rcap = h->reserve_R > 1 ? h->reserve_R : 1;
         for (int b = 0; b < B; b++) {
@@ -380,7 +441,7 @@ int fl_commit(fl_batch *h) {
         DALLOC(d.earliest, BA); DALLOC(d.latest, BA); DALLOC(d.tslot, BA);
         DALLOC(d.spk, BA); DALLOC(d.speed, BA);
         DALLOC(d.pos, BA); DALLOC(d.old_pos, BA); DALLOC(d.arrival, BA); DALLOC(d.malf, BA); DALLOC(d.pk, BA);
-        DALLOC(h->mask_dev, B);
+        DALLOC(h->mask_dev, B); DALLOC(h->need_dev, B); DALLOC(d.tab, B);
         if (fl_step_prepare() != FL_OK) { set_err("fl_commit: hipFuncSetAttribute failed"); return FL_ERR_HIP; }
         int rc = fl_obs_alloc(h->obs, d, h->stream, h->allocs);
         if (rc != FL_OK) { set_err("fl_commit: observation scratch allocation failed"); return rc; }
@@ -408,14 +469,21 @@ int fl_commit(fl_batch *h) {
     const bool all = !h->committed;
     if (!all) HIPCHK(hipMemcpyAsync(h->mask_dev, h->h_dirty.data(), B, hipMemcpyHostToDevice, h->stream));
     const uint8_t *mask = all ? nullptr : h->mask_dev;
-    fl_launch_env_list(d, mask, h->stream);
-    fl_launch_distance_maps(d, mask, h->stream);
+    // Shared static tables (FlDev::tab): envs with the same rail grid and the same unique targets read ONE set of tables, the
+    // slabs of the first such env (the owner).  Built here: the owners whose slabs do not hold their content yet -- a new map, or
+    // an env that becomes an owner because the previous one was replaced.
+    {
+        int rc_t = share_tables(h);
+        if (rc_t != FL_OK) return rc_t;
+    }
+    fl_launch_env_list(d, h->need_dev, h->stream);
+    fl_launch_distance_maps(d, h->need_dev, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_segments(d, mask, h->stream);
+    fl_launch_segments(d, h->need_dev, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_nexthop(d, mask, h->stream);
+    fl_launch_nexthop(d, h->need_dev, h->stream);
     HIPCHK(hipGetLastError());
-    fl_launch_hop8(d, mask, h->stream);
+    fl_launch_hop8(d, h->need_dev, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_reset(d, mask, 1, h->stream);
     HIPCHK(hipGetLastError());
@@ -725,7 +793,7 @@ int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *t
     if (target_slot) memcpy(target_slot, &h->h_tslot[(size_t)b * h->A], (size_t)h->A * 4);
     if (dm) {  // the resident map holds rail states only: expand it to the reference's dense [U][H][W][4]
         std::vector<uint16_t> rs((size_t)U * Scap);
-        HIPCHK(hipMemcpyAsync(rs.data(), h->d.dm + (size_t)b * h->d.Ucap * Scap, rs.size() * 2, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(rs.data(), h->d.dm + (size_t)h->h_tab[b] * h->d.Ucap * Scap, rs.size() * 2, hipMemcpyDeviceToHost, h->stream));   // (the owner's slab)
         HIPCHK(hipStreamSynchronize(h->stream));
         const uint32_t *rcell = &h->h_rcell[(size_t)b * h->d.Rcap];
         for (size_t k = 0; k < (size_t)U * HW * 4; k++) dm[k] = FL_INF16;
@@ -737,7 +805,14 @@ int fl_distance_map(fl_batch *h, int b, int *n_targets, uint16_t *dm, int32_t *t
 }
 
 static int rebuild_tables(fl_batch *h, const uint8_t *mask_dev) {
-    fl_launch_env_list(h->d, mask_dev, h->stream);
+    // every env: each OWNER once (host mask); a device mask of envs: the owners of the masked envs (FlDev::tab), an owner once per
+    // masked env that reads it -- DistanceMap.reset() + _compute() of every env that resets, as the reference does it
+    if (!mask_dev) {
+        for (int b = 0; b < h->B; b++) h->h_need[b] = h->h_tab[b] == b;
+        HIPCHK(hipMemcpyAsync(h->need_dev, h->h_need.data(), h->B, hipMemcpyHostToDevice, h->stream));
+    }
+    fl_launch_env_list(h->d, mask_dev ? mask_dev : h->need_dev, h->stream, mask_dev != nullptr);
+    mask_dev = mask_dev ? mask_dev : h->need_dev;
     fl_launch_distance_maps(h->d, mask_dev, h->stream);
     HIPCHK(hipGetLastError());
     fl_launch_segments(h->d, mask_dev, h->stream);

@@ -76,6 +76,10 @@ struct FlDev {
     int *U;    // [B] unique targets
     int *R;    // [B] rail cells
     int *K;    // [B] prediction keys (R, or the distinct col * W + row values of the rail cells when H > W)
+    int *tab;  // [B] the env whose slabs hold THIS env's static tables (grid, ridx, rgrid, rtype, nbr, snext, rkey, ut_r, dm, seg, nh, hop8):
+               // envs with the same rail grid and the same unique targets share one set (round 5) -- a batch is usually many
+               // replicas over a pool of a few maps, and one set per map stays in the L2 where one per env streams from HBM.
+               // tab[b] <= b; tab[b] == b: the env holds its own.  Every env has its slabs; only the owners' are built and read.
     int *err;  // [B] first error code raised by a kernel for env b (0 = none)
     int *env_list;  // [B + 1] scratch of the table (re)builds: the envs being rebuilt, their number at [B] (k_env_list)
     long long *metrics;  // [B][4] running sums: terminal rewards, arrived agents, agent-steps, finished episodes
@@ -152,7 +156,8 @@ __host__ __device__ inline uint32_t synth_action(uint32_t seed, uint32_t b, uint
 
 // kernel launchers (defined in the .hip files).  mask_dev: u8[B] or nullptr (= every env): only the envs with a non-zero
 // entry are rebuilt.  fl_launch_env_list turns the mask into d.env_list and goes first.
-void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
+// (through_tab: list the OWNERS of the masked envs' tables, FlDev::tab -- duplicates allowed, a table is then rebuilt with the same values by several workgroups)
+void fl_launch_env_list(const FlDev &d, const uint8_t *mask_dev, hipStream_t s, bool through_tab = false);
 void fl_launch_distance_maps(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);
 void fl_launch_segments(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);   // seg + snext
 void fl_launch_nexthop(const FlDev &d, const uint8_t *mask_dev, hipStream_t s);

@@ -124,10 +124,12 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     uint4 *seg_lds = TAB_LDS ? LDS_AT(uint4, L_SEG) : nullptr;
     uint16_t *dm_lds = TAB_LDS ? LDS_AT(uint16_t, L_DM) : nullptr;
     uint16_t *hop8_lds = TAB_LDS ? LDS_AT(uint16_t, L_HOP8) : nullptr;
-    const uint4 *gseg = d.seg + (size_t)b * Scap;
-    const uint16_t *gdm = d.dm + (size_t)b * d.Ucap * Scap;
-    const uint16_t *ghop8 = d.hop8 + (size_t)b * d.Ucap * Scap;
-    const uint16_t *gnh = d.nh + (size_t)b * d.Ucap * Rcap;
+    // the env whose slabs hold this env's static tables (FlDev::tab: envs of the same map and targets share one set)
+    const int tb = __builtin_amdgcn_readfirstlane(d.tab[b]);
+    const uint4 *gseg = d.seg + (size_t)tb * Scap;
+    const uint16_t *gdm = d.dm + (size_t)tb * d.Ucap * Scap;
+    const uint16_t *ghop8 = d.hop8 + (size_t)tb * d.Ucap * Scap;
+    const uint16_t *gnh = d.nh + (size_t)tb * d.Ucap * Rcap;
 
     const int T = d.T[b], tnow = d.t[b];
 #ifdef FL_OBS_TIMING
@@ -149,7 +151,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (STAGE != 2) {
         // per-agent snapshot first, on the LAST lanes: its two dependent HBM reads (state, then the rail index of the position)
         // overlap with the staging of the tables by everybody else
-        const uint16_t *gridx = d.ridx + (size_t)b * d.H * d.W;
+        const uint16_t *gridx = d.ridx + (size_t)tb * d.H * d.W;
         for (int i = nt - 1 - tid; i < A; i += nt) {
             const int g = b * A + i;
             const uint32_t pk = d.pk[g];
@@ -179,19 +181,19 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (CUTILS && STAGE == 1 && p_dual_index) { a_tpc2[i] = (uint16_t)(int)(1.0 / speed); a_tq2[i] = 1.0 / speed; }  // the upstream predictor's (predictions.py:139)
         }
         {
-            const uint16_t *grg = d.rgrid + (size_t)b * Rcap;
+            const uint16_t *grg = d.rgrid + (size_t)tb * Rcap;
             for (int r = tid; r < R; r += nt) cellw[r] = (uint32_t)grg[r] | 0xFFFF0000u;
             // u16 tables: two entries per load (every base is 4-byte aligned: Scap is a multiple of 4, Rcap * U pairs up below)
-            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(d.nbr + (size_t)b * Scap);
+            const uint32_t *g2 = reinterpret_cast<const uint32_t *>(d.nbr + (size_t)tb * Scap);
             uint32_t *l2 = reinterpret_cast<uint32_t *>(nbr);
             for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
             if (snext) {
-                g2 = reinterpret_cast<const uint32_t *>(d.snext + (size_t)b * Scap);
+                g2 = reinterpret_cast<const uint32_t *>(d.snext + (size_t)tb * Scap);
                 l2 = reinterpret_cast<uint32_t *>(snext);
                 for (int c = tid; c < NS / 2; c += nt) l2[c] = g2[c];
             }
             if (rkey) {
-                const uint16_t *gk = d.rkey + (size_t)b * Rcap;
+                const uint16_t *gk = d.rkey + (size_t)tb * Rcap;
                 for (int r = tid; r < R; r += nt) rkey[r] = gk[r];
             }
             if (TAB_LDS) {
@@ -207,7 +209,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (nh_in_lds)
                 for (int c = tid; c < U * Rcap; c += nt) nh_lds[c] = gnh[c];
             if (rtype_lds) {
-                const uint8_t *grt = d.rtype + (size_t)b * Rcap;
+                const uint8_t *grt = d.rtype + (size_t)tb * Rcap;
                 for (int r = tid; r < R; r += nt) rtype_lds[r] = grt[r];
             }
         }
@@ -402,7 +404,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             r.init_r = d.init_r[g];
         }
         // static per rail cell (fl_host.hip)
-        r.road_type = pos < 0 ? 0 : rtype_lds ? (int)rtype_lds[pos] : (int)d.rtype[(size_t)b * Rcap + pos];
+        r.road_type = pos < 0 ? 0 : rtype_lds ? (int)rtype_lds[pos] : (int)d.rtype[(size_t)tb * Rcap + pos];
         return r;
     };
     auto phase1b = [&](int i, int gl, const AgentRaw &raw) __attribute__((always_inline)) {

@@ -183,7 +183,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
     // the MT19937 block (the early exit below comes after the loads are on their way)
     int t = d.t[b];
     int was_done = d.done_all[b];
-    const uint32_t *grid = d.grid + (size_t)b * HW;
+    const int tb = d.tab[b];      // the env whose slabs hold this env's static tables (FlDev::tab)
+    const uint32_t *grid = d.grid + (size_t)tb * HW;
     const int T = d.T[b];
     const int pos0 = d.mt_pos[b];
     const uint64_t thr = d.malf_thr[b];
@@ -289,8 +290,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
                 const uint32_t bits = nibble(cell, dir);
                 raw = ACT_FORWARD;
                 if (__popc(bits) != 1) {
-                    const uint16_t *dm_t = d.dm + ((size_t)b * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4);
-                    const uint16_t *ridx = d.ridx + (size_t)b * HW;
+                    const uint16_t *dm_t = d.dm + ((size_t)tb * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4);
+                    const uint16_t *ridx = d.ridx + (size_t)tb * HW;
                     uint32_t best = 0xFFFFFFFFu;
                     for (uint32_t act3 = ACT_LEFT; act3 <= ACT_RIGHT; act3++) {
                         const uint32_t nd = (dir + act3 + 2u) & 3u;
@@ -379,8 +380,8 @@ __device__ __forceinline__ bool step_body(const FlDev &d, const uint8_t *__restr
         else {
             // len(shortest path) = distance-map value at (position, direction) + 1 waypoints, 0 if unreachable
             // (greedy strict descent of rail_env_shortest_paths.py:203-274 on a consistent BFS map)
-            const uint32_t rr = is_off_map(state) ? (uint32_t)d.init_r[g] : (uint32_t)d.ridx[(size_t)b * HW + pos];
-            const uint16_t dv = d.dm[((size_t)b * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4) + rr * 4u + dir];
+            const uint32_t rr = is_off_map(state) ? (uint32_t)d.init_r[g] : (uint32_t)d.ridx[(size_t)tb * HW + pos];
+            const uint16_t dv = d.dm[((size_t)tb * d.Ucap + d.tslot[g]) * ((size_t)d.Rcap * 4) + rr * 4u + dir];
             const int len = (dv == FL_INF16) ? 0 : (int)dv + 1;
             const int travel = (int)ceil((double)len / d.speed[g]);  // agent_utils.py:129-136
             reward = is_off_map(state) ? -travel : (latest - t) - travel;
