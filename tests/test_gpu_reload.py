@@ -141,3 +141,66 @@ def test_masked_rebuild_touches_only_the_masked_envs_and_reset_takes_a_device_ma
     same = (a[:, 5] == 0) & (b[:, 5] == 0)
     _same(a[same][:, :4], b[same][:, :4], "env 1 after the masked reset")
     env.check()
+
+
+def test_envs_of_one_map_share_their_static_tables_through_replacements():
+    """Envs with the same rail grid and unique targets read ONE set of device tables, the slabs of the first of them (FlDev::tab).
+    Six envs on two maps (own RNG streams); the owner of a map's tables is replaced by a third map while its dependents keep
+    running (one of them becomes the owner: its slabs are built at that commit), an env joins an existing map, and the masked
+    distance-map rebuild goes through the owners.  Every env matches its oracle throughout; FL_NO_SHARED_TABLES is the same
+    batch with one set of tables per env (a child process: the switch is read once)."""
+    import torch
+    from oracle import orc
+    from flatland_marl_amd import synth
+    bases = [util.load("base_cfg2_L%d" % k) for k in range(1, 8)]
+    U = max(len(fx["dm_targets"]) for fx in bases)
+    R = max(int((fx["grid"] != 0).sum()) for fx in bases)
+    which = [0, 1, 0, 1, 0, 1]
+    envs = []
+    for b, m in enumerate(which):
+        key, pos = _rng(1700 + b)
+        envs.append(util.static_of(bases[m], key, pos))
+    env = _env(envs, reserve=(U, R))
+    oracles = [orc.OracleEnv(e) for e in envs]
+    A, seed = env.A, 47
+    tc = [0] * len(envs)
+
+    def run(n, tag, rebuild=False):
+        for it in range(n):
+            rew, done, done_all = env.step_synth(seed, 70, 1, auto_reset=True)
+            if rebuild:
+                env.rebuild_distance_maps(env.done_all)
+            rew, done_all = rew.cpu().numpy(), done_all.cpu().numpy()
+            for b, oe in enumerate(oracles):
+                r_o, d_o, da = oe.step(synth.forward_biased_actions(seed, 70 + b, tc[b], A))
+                tc[b] += 1
+                _same(rew[b], r_o, f"{tag} it {it} env {b} rewards")
+                if da:
+                    key, pos = oe.get_rng()
+                    oracles[b] = orc.OracleEnv(envs[b])
+                    oracles[b].set_rng(key, pos)
+                    tc[b] = 0
+            if it % 5 == 4 or it == n - 1:
+                _compare(env, oracles, f"{tag} it {it}")
+
+    def replace(b, m, k):
+        key, pos = _rng(k)
+        envs[b] = util.static_of(bases[m], key, pos)
+        env.replace_env(b, envs[b])
+        oracles[b] = orc.OracleEnv(envs[b])
+        tc[b] = 0
+
+    run(40, "shared")
+    replace(0, 2, 1800)          # the owner of map 0's tables gets map 2: env 2 now owns map 0's (never built so far)
+    run(40, "owner replaced")
+    for b in (2, 4):
+        _same(env.distance_map(b)[0], bases[0]["dm_u16"], f"distance map of dependent {b}")
+    replace(3, 2, 1801)          # env 3 joins map 2 (owner: env 0)
+    replace(2, 1, 1802)          # the new owner of map 0 leaves too: env 4 is the last one on it
+    run(40, "joined", rebuild=True)
+    _same(env.distance_map(4)[0], bases[0]["dm_u16"], "distance map of the last env on map 0")
+    _same(env.distance_map(3)[0], bases[2]["dm_u16"], "distance map of the env that joined map 2")
+    env.rebuild_distance_maps(torch.tensor([0, 0, 0, 1, 1, 0], dtype=torch.uint8, device="cuda"))
+    env.rebuild_distance_maps()
+    run(20, "after rebuilds")
+    env.check()
