@@ -293,7 +293,7 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
         if (grid[(size_t)ir * W + ic] == 0 || grid[(size_t)tr * W + tc] == 0) { set_err("fl_load_env: agent %d starts or ends on a cell without rail", i); return FL_ERR_ARG; }
         if (!(speed[i] > 0.0) || speed[i] > 1.0) { set_err("fl_load_env: agent %d speed %g not in (0, 1]", i, speed[i]); return FL_ERR_ARG; }
         const int max_count = (int)(1.0 / speed[i]) - 1;  // SpeedCounter.max_count (step_utils/speed_counter.py:39-41)
-        if (max_count < 0 || max_count > 15) { set_err("fl_load_env: agent %d speed %g unsupported (max_count %d)", i, speed[i], max_count); return FL_ERR_ARG; }
+        if (max_count < 0 || max_count > FL_MAX_SPEED_COUNT) { set_err("fl_load_env: agent %d speed %g unsupported (max_count %d)", i, speed[i], max_count); return FL_ERR_ARG; }
         // unique targets in first-seen order (distance_map.py:71-79)
         const int tcell = tr * W + tc;
         size_t u = 0;
@@ -559,9 +559,9 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
     NEED_COMMIT(h);
     if (!rewards_dev || !dones_dev || !done_all_dev || kind < 0 || kind > 2) { set_err("fl_step_obs: bad step argument"); return FL_ERR_ARG; }
     if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED || tree_max_depth < 0 ||
-        tree_max_depth > 3 || (tree_max_depth > 0 && (tree_pred_depth < 0 || tree_pred_depth > pred_depth || !tree_out_dev))) {
-        set_err("fl_step_obs: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [0,3], 0 <= tree_pred_depth <= pred_depth",
-                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        tree_max_depth > FL_MAX_TREE_DEPTH || (tree_max_depth > 0 && (tree_pred_depth < 0 || tree_pred_depth > pred_depth || !tree_out_dev))) {
+        set_err("fl_step_obs: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [0,%d], 0 <= tree_pred_depth <= pred_depth",
+                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED, FL_MAX_TREE_DEPTH);
         return FL_ERR_ARG;
     }
     if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev) {
@@ -572,6 +572,8 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
     // one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
     fl_launch_step(h->d, actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags, h->stream);
     HIPCHK(hipGetLastError());
+    if (tree_max_depth > 3) return fl_obs_cutils_tree(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
+                                                      valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev);
     const int rc = tree_max_depth > 0 ? fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                                            edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth,
                                                            tree_out_dev, h->stream)
@@ -701,7 +703,7 @@ int fl_set_state(fl_batch *h, const int32_t *state, const int32_t *aux, const in
         const int r = o[0], c = o[1], dir = o[2], st = o[3], mf = o[4], nmf = o[5], sc = o[6], sv = o[7], orow = o[9], ocol = o[10], od = o[11];
         const bool on = r >= 0;
         if ((on && (r >= H || c < 0 || c >= W)) || dir < 0 || dir > 3 || st < ST_WAITING || st > ST_DONE || mf < 0 || mf > 0xFFFF ||
-            nmf < 0 || nmf > 0xFFFF || sc < 0 || sc > 15 || sv < 0 || sv > 3 || od < -1 || od > 3 ||
+            nmf < 0 || nmf > 0xFFFF || sc < 0 || sc > FL_MAX_SPEED_COUNT || sv < 0 || sv > 3 || od < -1 || od > 3 ||
             (orow >= 0 && (orow >= H || ocol < 0 || ocol >= W))) {
             set_err("fl_set_state: env %zu agent %zu: value out of range", g / h->A, g % h->A);
             return FL_ERR_ARG;
@@ -871,14 +873,18 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
                        int tree_max_depth, int tree_pred_depth, double *tree_out_dev) {
     NEED_COMMIT(h);
     if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED || tree_max_depth < 1 ||
-        tree_max_depth > 3 || tree_pred_depth < 0 || tree_pred_depth > pred_depth) {
-        set_err("fl_obs_cutils_tree: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [1,3], 0 <= tree_pred_depth <= pred_depth",
-                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        tree_max_depth > FL_MAX_TREE_DEPTH || tree_pred_depth < 0 || tree_pred_depth > pred_depth) {
+        set_err("fl_obs_cutils_tree: max_nodes in [4,%d], pred_depth in [1,%d], tree depth in [1,%d], 0 <= tree_pred_depth <= pred_depth",
+                FL_OBS_MAX_NODES, FL_OBS_MAX_PRED, FL_MAX_TREE_DEPTH);
         return FL_ERR_ARG;
     }
     if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev || !tree_out_dev) {
         set_err("fl_obs_cutils_tree: null output buffer");
         return FL_ERR_ARG;
+    }
+    if (tree_max_depth > 3) {   // beyond the fused kernels' node tables: the two builders one after the other (same outputs)
+        int rc2 = fl_obs_cutils(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev, valid_actions_dev, props_dev);
+        return rc2 != FL_OK ? rc2 : fl_obs_tree(h, tree_max_depth, tree_pred_depth, tree_out_dev);
     }
     int rc = fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                 edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev, h->stream);
@@ -897,8 +903,12 @@ int fl_obs_set_mode(fl_batch *h, int flags) {
 
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     NEED_COMMIT(h);
-    if (max_depth < 1 || max_depth > 3 || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
-        set_err("fl_obs_tree: max_depth must be in [1,3], pred_depth <= %d", FL_OBS_MAX_PRED);
+    if (max_depth < 1 || max_depth > FL_MAX_TREE_DEPTH || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
+        set_err("fl_obs_tree: max_depth must be in [1,%d], pred_depth <= %d", FL_MAX_TREE_DEPTH, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (max_depth > 3 && h->d.max_branch > 2) {
+        set_err("fl_obs_tree: max_depth 4 needs a grid on which no direction of a cell has more than two transitions (every Flatland rail cell type); this batch has %d", h->d.max_branch);
         return FL_ERR_ARG;
     }
     int rc = fl_launch_obs_tree(h->obs, h->d, max_depth, pred_depth, out_dev, h->stream);

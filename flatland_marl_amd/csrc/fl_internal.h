@@ -47,18 +47,19 @@ enum { ACT_NOTHING = 0, ACT_LEFT = 1, ACT_FORWARD = 2, ACT_RIGHT = 3, ACT_STOP =
 #define PK_STATE(pk) (((pk) >> 5) & 7u)
 #define PK_PREV(pk) (((pk) >> 8) & 7u) /* 7 = None */
 #define PK_SAVED(pk) (((pk) >> 11) & 3u)
-#define PK_SCOUNT(pk) (((pk) >> 13) & 15u)
-#define PK_SIGMALF(pk) (((pk) >> 17) & 1u)
-#define PK_DEADLOCK(pk) (((pk) >> 18) & 1u)
-#define PK_DONE(pk) (((pk) >> 19) & 1u)
+#define PK_SCOUNT(pk) (((pk) >> 13) & 63u) /* SpeedCounter.counter: 0 .. max_count <= 63 (speeds down to 1/64) */
+#define PK_SIGMALF(pk) (((pk) >> 19) & 1u)
+#define PK_DEADLOCK(pk) (((pk) >> 20) & 1u)
+#define PK_DEADLOCK_BIT (1u << 20)
+#define PK_DONE(pk) (((pk) >> 21) & 1u)
 __host__ __device__ inline uint32_t pk_make(uint32_t dir, uint32_t old_dir, uint32_t state, uint32_t prev, uint32_t saved,
                                             uint32_t scount, uint32_t sig, uint32_t dead, uint32_t done) {
-    return dir | (old_dir << 2) | (state << 5) | (prev << 8) | (saved << 11) | (scount << 13) | (sig << 17) | (dead << 18) |
-           (done << 19);
+    return dir | (old_dir << 2) | (state << 5) | (prev << 8) | (saved << 11) | (scount << 13) | (sig << 19) | (dead << 20) |
+           (done << 21);
 }
-// spk: init_dir bits 0-1, max_count bits 2-5
+// spk: init_dir bits 0-1, max_count bits 2-7
 #define SPK_INIT_DIR(s) ((s)&3u)
-#define SPK_MAX_COUNT(s) (((s) >> 2) & 15u)
+#define SPK_MAX_COUNT(s) (((s) >> 2) & 63u)
 
 struct FlDev {
     int B, A, H, W;

@@ -364,7 +364,8 @@ static void obs_tree_args(const FlDev &d, ObsArgs &P, int max_depth, int tree_pr
     P.n_tree_nodes = n;
     static const bool no_compact = getenv("FL_OBS_NO_COMPACT") != nullptr;
     P.compact_t = d.max_branch <= 2 && !no_compact;
-    if (P.compact_t) { P.tw_t = N_WORDS_T * OBS_CAP_T_COMPACT; P.tpw_t = 4; }
+    if (P.compact_t && max_depth >= 4) { P.tw_t = N_WORDS_T * 32; P.tpw_t = 2; }   // depth 4: 30 compact slots on a 32-lane team (the stand-alone tree launch)
+    else if (P.compact_t) { P.tw_t = N_WORDS_T * OBS_CAP_T_COMPACT; P.tpw_t = 4; }
     else { P.tw_t = max_depth <= 2 ? N_WORDS_T * 32 : N_WORDS_T * 88; P.tpw_t = max_depth <= 2 ? 2 : 1; }
 }
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -428,15 +429,19 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
 
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
-    if (max_depth > 3) return FL_ERR_ARG;  // one lane per node of the deepest level: 4^3 = 64
+    if (max_depth > FL_MAX_TREE_DEPTH) return FL_ERR_ARG;
+    // depth 4: compact node tables only (level L of the tree has at most 2^L nodes when no direction of a cell has more than two
+    // transitions -- every Flatland rail cell type): 30 slots; the DFS-slot tables of other grids stop at depth 3 (85 slots)
+    if (max_depth > 3 && d.max_branch > 2) return FL_ERR_ARG;
     ObsArgs P = {};
     P.dbg = o.dbg;
     obs_tree_args(d, P, max_depth, pred_depth, out);
+    if (max_depth > 3 && !P.compact_t) return FL_ERR_ARG;   // (FL_OBS_NO_COMPACT)
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     P.keep_rows = o.keep_rows && o.rows_out == out && o.rows_depth == max_depth;
     o.rows_out = out; o.rows_depth = max_depth;
     uint4 *const rowmask = o.rowmask;
-    if (!o.keep_rows) o.rowmask = nullptr;   // (mode off: the kernels keep no row masks)
+    if (!o.keep_rows || max_depth > 3) { o.rowmask = nullptr; P.keep_rows = 0; o.rows_out = nullptr; }   // (mode off, or more rows than the masks' 96 bits: no row masks)
     struct Restore { FlObsScratch &o; uint4 *m; ~Restore() { o.rowmask = m; } } restore{o, rowmask};
     o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);

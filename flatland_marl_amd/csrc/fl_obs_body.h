@@ -381,7 +381,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int g = b * A + i;
             if (is_on_map(a_state[i]) && !a_dead[i] && !a_free[i]) {
                 a_dead[i] = 1;
-                d.pk[g] |= (1u << 18);
+                d.pk[g] |= PK_DEADLOCK_BIT;
             }
             P.attr[(size_t)g * FL_CUTILS_ATTR + 41] = (float)a_dead[i];
             if (P.props) P.props[(size_t)g * 3 + 1] = (double)a_dead[i];
@@ -991,8 +991,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         atomicOr(&tmask[key], ((2ull << m2) - 1ull) & ~((1ull << m1) - 1ull));
                     }
                     const uint32_t dnext = k < lp ? (wnx & 3u) : (w & 3u), dprev = k > 0 ? (wpv & 3u) : (w & 3u);
-                    const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
-                                          ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                    const uint32_t item = IT_MAKE(i, tlo, to_end, span, dprev, dnext, w & 3u);
                     const int kb = bb * K1 + key + 1;
                     const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                     csr_items[gbase + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
@@ -1044,8 +1043,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         atomicOr(&tmask[key], bits);
                     }
                 }
-                const uint32_t item = ((uint32_t)i << 20) | ((uint32_t)tlo << 11) | ((uint32_t)to_end << 10) |
-                                      ((uint32_t)(span - 1) << 6) | (dprev << 4) | (dnext << 2) | (w & 3u);
+                const uint32_t item = IT_MAKE(i, tlo, to_end, span, dprev, dnext, w & 3u);
                 if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
                     const int thi = to_end ? tlast : tlo + span - 1;
                     int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);
@@ -1074,8 +1072,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         }
                     }
                     const int slot2 = atomicAdd(&csr2[key], 1);
-                    items2[slot2] = ((uint32_t)i << 20) | ((uint32_t)tlo2 << 11) | ((uint32_t)to_end2 << 10) |
-                                    ((uint32_t)(tpc2 - 1) << 6) | (dprev << 4) | (dnext2 << 2) | (w & 3u);
+                    items2[slot2] = IT_MAKE(i, tlo2, to_end2, tpc2, dprev, dnext2, w & 3u);
                 }
             }
             }
@@ -1120,6 +1117,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+    } else if (p_compact_t && STAGE == 0 && FIX == 0 && P.max_depth >= 4) {
+        // depth 4 (341 rows): 30 compact slots, a team of 32 lanes, two trees a wavefront -- the stand-alone tree launch only
+        if (items_in_lds) tree_upstream<32, 32, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, nullptr);
+        else tree_upstream<32, 32, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, nullptr);
     } else if (p_compact_t) {
         if (items_in_lds) tree_upstream<16, OBS_CAP_T_COMPACT, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);
         else tree_upstream<16, OBS_CAP_T_COMPACT, true, false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, S.rowmask);

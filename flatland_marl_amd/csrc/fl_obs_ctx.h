@@ -218,7 +218,7 @@ __device__ __forceinline__ int nt_tot(uint32_t tv) { return (int)(tv & 0xFFFFu);
 __device__ __forceinline__ int nt_vis(uint32_t tv) { return (int)(tv >> 16); }
 __device__ __forceinline__ int nt_unus(uint32_t uf) { const uint32_t u = uf & 0xFFFFu; return u == 0xFFFFu ? -1 : (int)u; }
 __device__ __forceinline__ uint32_t nt_flags(uint32_t uf) { return (uf >> 16) & 63u; }
-__device__ __forceinline__ int nt_row(uint32_t uf) { return (int)((uf >> 22) & 127u); }
+__device__ __forceinline__ int nt_row(uint32_t uf) { return (int)((uf >> 22) & 1023u); }   // (341 rows at depth 4)
 // descriptor of a node into its slot; err: latched when a distance does not fit 16 bits (no Flatland map comes close)
 __device__ __forceinline__ void nt_store_desc(int *scr, int cap, int k, const NodeDesc &nd, int row, int *err) {
     if ((uint32_t)(nd.tot0 + nd.nvis) > 0xFFFEu && err) atomicCAS(err, 0, FL_ERR_CAPACITY);

@@ -51,20 +51,22 @@
 
 // prediction item: one (agent, waypoint) with the closed time interval during which the agent is predicted there
 //   bits 0-1 direction at the waypoint, 2-3 direction at the next waypoint, 4-5 at the previous one,
-//   6-9 interval length - 1, 10 "until the end of the horizon", 11-19 t_lo, 20-29 agent
+//   6-11 interval length - 1 (= time steps per cell - 1 <= 63: speeds down to 1/64), 12 "until the end of the horizon", 13-21 t_lo, 22-31 agent
 #define IT_DIR(it) ((it)&3u)
 #define IT_DNEXT(it) (((it) >> 2) & 3u)
 #define IT_DPREV(it) (((it) >> 4) & 3u)
-#define IT_THI(it, tlast) ((((it) >> 10) & 1u) ? (uint32_t)(tlast) : IT_TLO(it) + (((it) >> 6) & 15u))
-#define IT_TLO(it) (((it) >> 11) & 511u)
-#define IT_TOEND(it) (((it) >> 10) & 1u)
-#define IT_AGENT(it) ((int)((it) >> 20))
+#define IT_THI(it, tlast) ((((it) >> 12) & 1u) ? (uint32_t)(tlast) : IT_TLO(it) + (((it) >> 6) & 63u))
+#define IT_TLO(it) (((it) >> 13) & 511u)
+#define IT_TOEND(it) (((it) >> 12) & 1u)
+#define IT_AGENT(it) ((int)((it) >> 22))
+#define IT_MAKE(agent, tlo, to_end, span, dprev, dnext, dir) \
+    (((uint32_t)(agent) << 22) | ((uint32_t)(tlo) << 13) | ((uint32_t)(to_end) << 12) | ((uint32_t)((span) - 1) << 6) | ((uint32_t)(dprev) << 4) | ((uint32_t)(dnext) << 2) | (uint32_t)(dir))
 
 // Node table of one tree (= one pass B team) in LDS: field-major, CAP entries per 32-bit word-field.  Descriptor words are
 // written by pass A, the accumulators are merged by the event handlers of pass B with LDS atomics.
 //   N_SE    start state (lo16, 0xFFFF = no node) | end state (hi16)
 //   N_TV    tot_dist at the first visited cell (lo16) | number of visited cells (hi16)
-//   N_UF    tot_dist of the first unusable switch (lo16, 0xFFFF = none) | ND_* flags (bits 16-21) | DFS row of the node (bits 22-28, upstream)
+//   N_UF    tot_dist of the first unusable switch (lo16, 0xFFFF = none) | ND_* flags (bits 16-21) | DFS row of the node (bits 22-31, upstream)
 //   N_INCL  inclusive prefix of the visit counts (24 bits) | next node with cells << 24 (0xFF = none)   (team_prepare)
 //   N_OA, N_PC   min tot_dist of "other agent encountered" / "potential conflict" (0x7fffffff = none)
 //   N_CNT   agents in the same direction (lo16) | in the opposite direction (hi16)

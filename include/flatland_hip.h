@@ -55,22 +55,25 @@ enum {
 
 /* Limits of this build (FL_ERR_ARG / FL_ERR_CAPACITY beyond them):
  *   FL_MAX_AGENTS          agents per env (one lane per agent in the step kernel)
- *   FL_MAX_SPEED_COUNT     SpeedCounter.max_count = int(1 / speed) - 1 (4 bits of the packed agent word), i.e. speed >= 1/16
+ *   FL_MAX_SPEED_COUNT     SpeedCounter.max_count = int(1 / speed) - 1 (6 bits of the packed agent word and of a prediction item's
+ *                          interval), i.e. speed >= 1/64 (Flatland's own speed maps stop at 1/4)
  *   FL_MAX_RAIL_CELLS      rail cells per env: rail states r * 4 + orientation are u16 (0xFFFF, 0xFFFE reserved).  In practice the
  *                          LDS sets the limit: the distance-map kernel holds an env's neighbour table, bitmaps and queues
  *                          (about 10 900 cells; fl_reserve / fl_commit say so), the observation kernels its rail-cell index
  *                          (about 6 000 cells with 400 agents; the largest Round-2 map, 158 x 158 / 41 cities, has 2 710)
  *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (one 32-lane team per tree; the solution uses 31)
  *   FL_MAX_PRED_DEPTH      predictor depth of either builder (the solution uses 500 / 30)
- *   FL_MAX_TREE_DEPTH      max_depth of the upstream TreeObsForRailEnv (85 nodes at depth 3)
+ *   FL_MAX_TREE_DEPTH      max_depth of the upstream TreeObsForRailEnv (85 rows at depth 3, 341 at depth 4; depth 4 on grids whose cells
+ *                          have at most two transitions per direction -- every Flatland rail cell type --, the builders then run as
+ *                          two launches)
  *   every env of one batch shares (A, H, W); an env loaded into a live batch has to fit the capacities of the first
  *   commit (fl_reserve). */
 #define FL_MAX_AGENTS 1024
-#define FL_MAX_SPEED_COUNT 15
+#define FL_MAX_SPEED_COUNT 63
 #define FL_MAX_RAIL_CELLS 16383
 #define FL_MAX_CUTILS_NODES 32
 #define FL_MAX_PRED_DEPTH 500
-#define FL_MAX_TREE_DEPTH 3
+#define FL_MAX_TREE_DEPTH 4
 
 #define FL_STEP_AUTO_RESET 1
 #define FL_STEP_FILTER_REQUIRED 2

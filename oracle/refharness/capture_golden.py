@@ -203,9 +203,11 @@ def sp_follow_actions(env, rng, p_stop=0.03):
 
 
 def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=1,
-                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False, dims=None):
-    """stream in {"uniform", "sparse", "spfollow", "fwd"}."""
+                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False, dims=None, speed_ratios=None):
+    """stream in {"uniform", "sparse", "spfollow", "fwd"}.  speed_ratios: {speed: probability} instead of the CSV row's."""
     row = csv_row(test_id, level)
+    if speed_ratios is not None:
+        row["speed_ratios"] = dict(speed_ratios)
     env, mp = make_env(row, malfunction_interval, dims=dims)
     obs0, _ = env.reset()
     A = env.get_num_agents()
@@ -446,6 +448,13 @@ JOBS = {
     # the largest Round-2 map: Test_14 = 158x158, 425 agents, 41 cities; first 320 steps of a shortest-path-following stream
     "test14_spfollow_head": lambda: run_episode("test14_spfollow_head", "Test_14", "Level_0", "spfollow", seed=71, max_steps=320,
                                                 obs_every=80, pytree=[(3, 30)], pytree_every=160),
+    # round 5: beyond the solution's builder sizes -- a depth-4 upstream tree (341 rows an agent), and trains slower than 1/16
+    # (SpeedCounter.max_count = int(1 / speed) - 1 up to 49; speed_counter.py:41 takes any speed)
+    "cfg2_depth4": lambda: run_episode("cfg2_depth4", "Test_2", "Level_3", "spfollow", seed=81, max_steps=260, obs_every=64,
+                                       pytree=[(4, 30), (4, 10)], pytree_every=64),
+    "cfg2_slow_trains": lambda: run_episode("cfg2_slow_trains", "Test_2", "Level_4", "spfollow", seed=82, obs_every=16, max_steps=900,
+                                            pytree=[(2, 30)], pytree_every=128,
+                                            speed_ratios={1.0: 0.25, 1.0 / 20.0: 0.25, 1.0 / 33.0: 0.25, 1.0 / 50.0: 0.25}),
 }
 for lv in range(1, 8):
     JOBS[f"base_cfg2_L{lv}"] = (lambda lv=lv: static_only(f"base_cfg2_L{lv}", "Test_2", f"Level_{lv}"))

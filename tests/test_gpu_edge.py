@@ -40,7 +40,7 @@ def test_cutils_other_sizes_match_oracle(max_nodes, pred_depth):
     env.check()
 
 
-@pytest.mark.parametrize("depth,pred", [(1, 30), (2, -1), (3, -1), (3, 10), (2, 500), (2, 0), (2, 1)])
+@pytest.mark.parametrize("depth,pred", [(1, 30), (2, -1), (3, -1), (3, 10), (2, 500), (2, 0), (2, 1), (4, 30), (4, -1), (4, 500)])
 def test_upstream_tree_variants_match_oracle(depth, pred):
     from oracle import orc
     from flatland_marl_amd import synth
@@ -289,7 +289,8 @@ def test_action_required_filter_info_and_scores_match_reference():
 
 @pytest.mark.parametrize("name,B,depth,pred", [("cfg2_spfollow", 6, 2, 30), ("cfg0_tall_spfollow", 3, 3, 30),
                                                ("cfg3_uniform", 3, 2, 500), ("cfg5_fwd_head", 1, 2, 30),
-                                               ("cfg2_spfollow", 2, 2, 500), ("cfg1_spfollow", 2, 3, 200)])
+                                               ("cfg2_spfollow", 2, 2, 500), ("cfg1_spfollow", 2, 3, 200),
+                                               ("cfg3_uniform", 3, 4, 30)])      # depth 4: the fused entry points run the two builders one after the other
 def test_fused_observation_launch_equals_separate_launches(name, B, depth, pred):
     fx = util.load(name)
     st = util.static_of(fx)
@@ -369,3 +370,33 @@ def test_fused_step_after_episode_end_raises_like_the_reference():
     env.step_obs(np.zeros((1, env.A), dtype=np.uint8))
     with pytest.raises(EpisodeDoneError):
         env.check()
+
+
+def test_builder_sizes_beyond_the_limits_are_refused_with_a_message():
+    """max_depth 5, max_depth 4 on a grid with a three-way cell (DFS-slot node tables stop at depth 3), 33 cutils nodes, a speed below
+    1/64: FL_ERR_ARG with a message that names the limit, nothing launched"""
+    from flatland_marl_amd.hip_backend import FlatlandHipError
+    fx = util.load("cfg1_uniform")
+    st = util.static_of(fx)
+    env = _env([st])
+    env.step_synth(1, 0, 0)
+    assert env.obs_tree(4, 30).shape == (1, env.A, 341, 12)
+    with pytest.raises(FlatlandHipError, match=r"max_depth must be in \[1,4\]"):
+        env.obs_tree(5, 30)
+    env.max_nodes = 33
+    env._obs = None
+    with pytest.raises(FlatlandHipError, match="max_nodes"):
+        env.obs_cutils()
+    slow = dict(st)
+    slow["speed"] = np.array(st["speed"], dtype=np.float64)
+    slow["speed"][0] = 1.0 / 65.0
+    with pytest.raises(FlatlandHipError, match="max_count 64"):
+        _env([slow])
+    slow["speed"][0] = 1.0 / 64.0            # the slowest train this build takes
+    _env([slow]).step_synth(1, 0, 0)
+    tw = util.load("threeway_cfg2")
+    e3 = _env([util.static_of(tw)])
+    e3.step_synth(1, 0, 0)
+    with pytest.raises(FlatlandHipError, match="more than two transitions"):
+        e3.obs_tree(4, 30)
+    assert e3.obs_tree(3, 30).shape[2] == 85

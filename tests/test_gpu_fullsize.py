@@ -221,11 +221,13 @@ CLASS_OF = {"cfg3": (2, 0), "cfg2": (1, 0)}
 def test_other_launch_paths_give_the_same_bytes():
     """The launcher's alternative paths, each selected by an environment switch that is read once per process (hence children):
     the runtime LDS carving instead of the fixed launch classes (FL_OBS_NO_FIX) and the 512-thread kernel in rounds of 16 agents,
-    two workgroups a CU (FL_OBS_ROUND16, MODE 5) -- on cfg3 (depth 3) and cfg2 (depth 2) batches in dense traffic.  Same bytes
+    two workgroups a CU (FL_OBS_ROUND16, MODE 5), one set of static tables per env instead of one per map (FL_NO_SHARED_TABLES) -- on
+    cfg3 (depth 3) and cfg2 (depth 2) batches in dense traffic.  Same bytes
     as the default path, and every run asserts the launch class it took (default: classes 2 / 1; with a switch: none)."""
     want = {k: _cfg4_digest(want_class=CLASS_OF[k], **kw) for k, kw in CASES.items()}
     assert _child(("FL_OBS_NO_FIX",), "paths", "0") == want
     assert _child(("FL_OBS_ROUND16",), "paths", "r16") == want
+    assert _child(("FL_NO_SHARED_TABLES",), "paths", "own") == want       # one set of static tables per env instead of one per map
 
 
 if __name__ == "__main__":
@@ -233,7 +235,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "paths":
         for k, kw in CASES.items():
             # rounds of 16 agents apply to envs of more than 32 agents only: cfg2 keeps its class there
-            klass = (0, 0) if sys.argv[2] == "0" or k == "cfg3" else CLASS_OF[k]
+            klass = CLASS_OF[k] if sys.argv[2] == "own" else (0, 0) if sys.argv[2] == "0" or k == "cfg3" else CLASS_OF[k]
             print("DIGEST", k, _cfg4_digest(want_class=klass, **kw))
     else:
         print("DIGEST cfg4", _cfg4_digest(want_class=(int(sys.argv[2]), int(sys.argv[3])), big=True))

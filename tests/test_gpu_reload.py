@@ -147,8 +147,8 @@ def test_envs_of_one_map_share_their_static_tables_through_replacements():
     """Envs with the same rail grid and unique targets read ONE set of device tables, the slabs of the first of them (FlDev::tab).
     Six envs on two maps (own RNG streams); the owner of a map's tables is replaced by a third map while its dependents keep
     running (one of them becomes the owner: its slabs are built at that commit), an env joins an existing map, and the masked
-    distance-map rebuild goes through the owners.  Every env matches its oracle throughout; FL_NO_SHARED_TABLES is the same
-    batch with one set of tables per env (a child process: the switch is read once)."""
+    distance-map rebuild goes through the owners.  Every env matches its oracle throughout.  (FL_NO_SHARED_TABLES -- one set of
+    tables per env -- gives the same bytes: tests/test_gpu_fullsize.py::test_other_launch_paths_give_the_same_bytes.)"""
     import torch
     from oracle import orc
     from flatland_marl_amd import synth
