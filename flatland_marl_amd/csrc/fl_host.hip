@@ -868,6 +868,45 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
     return FL_OK;
 }
 
+int fl_obs_cutils_handles(fl_batch *h, int max_nodes, int pred_depth, const int32_t *handles, int n_handles, float *attr_dev,
+                          float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
+                          uint8_t *valid_actions_dev, double *props_dev) {
+    NEED_COMMIT(h);
+    const int A = h->A;
+    if (!handles || n_handles < 1 || n_handles > A) { set_err("fl_obs_cutils_handles: 1 <= n_handles <= %d agents", A); return FL_ERR_ARG; }
+    // the reference's conflict test erases position `agent.handle` from a list of len(handles) entries (tool.h:428-434): a listed
+    // handle >= len(handles) is undefined behaviour there; what remains are the permutations of 0 .. n-1
+    std::vector<int16_t> label(A, (int16_t)-1);
+    bool identity = n_handles == A;
+    for (int j = 0; j < n_handles; j++) {
+        const int a = handles[j];
+        if (a < 0 || a >= n_handles || label[a] >= 0) {
+            set_err("fl_obs_cutils_handles: handles has to be a permutation of 0 .. %d (handle %d at position %d): the reference's get_many is undefined for any other strict subset "
+                    "(treeobs.cpp:393-401 erases list position `handle`)", n_handles - 1, a, j);
+            return FL_ERR_ARG;
+        }
+        label[a] = (int16_t)j;
+        identity = identity && a == j;
+    }
+    if (identity)
+        return fl_obs_cutils(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev, valid_actions_dev, props_dev);
+    if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED) {
+        set_err("fl_obs_cutils_handles: max_nodes must be in [4,%d] and pred_depth in [1,%d]", FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev) {
+        set_err("fl_obs_cutils_handles: null output buffer");
+        return FL_ERR_ARG;
+    }
+    HIPCHK(hipMemcpyAsync(h->obs.label, label.data(), (size_t)A * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // (the staging vector is a local)
+    int rc = fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
+                                  edge_order_dev, valid_actions_dev, props_dev, h->stream, h->obs.label);
+    if (rc != FL_OK) { set_err("fl_obs_cutils_handles: no launch configuration"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev, int32_t *adjacency_dev,
                        int32_t *node_order_dev, int32_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev,
                        int tree_max_depth, int tree_pred_depth, double *tree_out_dev) {

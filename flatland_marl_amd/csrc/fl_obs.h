@@ -28,6 +28,7 @@ struct FlObsScratch {
                        // DFS row index; w: 1 = valid) -- see FL_OBS_KEEP_TREE_ROWS
     const double *rows_out; int rows_depth;   // host side: buffer and depth the masks describe (null: none yet)
     int keep_rows;     // host side: fl_obs_set_mode(FL_OBS_KEEP_TREE_ROWS)
+    int16_t *label;    // [A] get_many(handles) with a strict subset: position of agent i in the list or -1 (fl_obs_cutils_handles uploads it per call)
     const int *h_R;    // HOST [B] rail cells of every env (the handle's copy; null: unknown) -- which envs of a batch fit a fixed launch class
     int last_fix, last_split, last_fit;  // host side, diagnostic: class of the last fused launch (0 = runtime carving), whether the class
                                          // served only the envs that fit it, and how many envs took the class's body
@@ -36,7 +37,7 @@ struct FlObsScratch {
 int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<void *> &allocs);
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                         hipStream_t s);
+                         hipStream_t s, const int16_t *label_dev = nullptr);
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);

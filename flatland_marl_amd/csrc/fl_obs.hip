@@ -27,6 +27,8 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     o.wl_cap = OBS_WL_HBM_ENTRIES;
     if (hipMalloc(&p, (size_t)d.B * o.wl_cap * 8) != hipSuccess) return FL_ERR_HIP;
     o.wl = (uint2 *)p; allocs.push_back(p);
+    if (hipMalloc(&p, (size_t)d.A * sizeof(int16_t) + 16) != hipSuccess) return FL_ERR_HIP;
+    o.label = (int16_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, BA * sizeof(uint4)) != hipSuccess) return FL_ERR_HIP;
     o.rowmask = (uint4 *)p; allocs.push_back(p);
     if (hipMemsetAsync(o.rowmask, 0, BA * sizeof(uint4), s) != hipSuccess) return FL_ERR_HIP;
@@ -370,9 +372,10 @@ static void obs_tree_args(const FlDev &d, ObsArgs &P, int max_depth, int tree_pr
 }
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                         hipStream_t s) {
+                         hipStream_t s, const int16_t *label_dev) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
     ObsArgs P = {};
+    P.label = label_dev;
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * OBS_CAP_C;

@@ -143,6 +143,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #endif
     OBS_STAMP(0);
 
+    // get_many(handles) with a strict subset: the stand-alone flatland_cutils launch only
+    const int16_t *lab = (CUTILS && STAGE == 0 && MERGED == 0 && FIX == 0) ? P.label : nullptr;
     const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
     const bool any_pred = STAGE == 0 ? my_pred_depth >= 0 : true;
     const bool nh_in_lds = nh_lds != nullptr && any_pred;
@@ -622,7 +624,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             // anyway; the one item whose interval runs to the end of the horizon, the last one of the path, is only known after the
             // walk and is corrected then.  With hundreds of agents the walk IS the critical path and two LDS atomics per hop doubled
             // it (166 -> 382 us at cfg5): those lists are counted in a pass of their own below, all lanes at once)
-            const int hz1 = (bk && !bk_lds) ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
+            const bool listed = !lab || lab[ia] >= 0;   // (an agent that is not in `handles` has no entry in predicted_pos)
+            const int hz1 = ((bk && !bk_lds) || !listed) ? -1 : max(0, CUTILS ? (X.Tn - 2) / (int)a_tpc[ia] + 1 : (X.Tn - 1) / (int)a_tpc[ia]);
             const int tpc_w = a_tpc[ia], tlast_w = X.Tn - 1;
             uint32_t st_hz = 0;
             const int hz2 = dual ? max(0, min(P.tree_pred - 1, (Tn2 - 1) / (int)a_tpc2[ia])) : -1;
@@ -663,7 +666,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             const int my_last = TAB_LDS ? walk8(hop8_lds + u * Scap) : walk8(ghop8 + (size_t)u * Scap);
             int m = my_last;
             m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
-            if (bk_lds && have) {
+            if (bk_lds && have && listed) {
                 // the last indexed waypoint lp stays occupied until the end of the horizon: from its time bucket(s) to the bucket of
                 // such items
                 const int lp = max(0, min(m, hz1));
@@ -734,6 +737,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                               // touches (cutils: w(t) = 0 for t = 0, min((t-1)/tpc + 1, lp)); four waypoints per lane a round trip
             __syncthreads();
             for (int i = wave; i < A; i += (nt >> 6)) {
+                if (lab && lab[i] < 0) continue;
                 const uint16_t *path = S.path + ((size_t)b * A + i) * OBS_PRED_CAP;
                 const int lp = a_lp[i];
                 const int tpc = a_tpc[i], tlast = X.Tn - 1;
@@ -942,7 +946,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                     const int k_lo = min((t0 + tpc - 1) / tpc, lp);              // first waypoint still occupied at t0 (thi = k * tpc)
                     const int k_hi = min(t1 >= 1 ? (t1 - 1) / tpc + 1 : 0, lp);  // last waypoint entered by t1 (tlo = (k - 1) * tpc + 1)
                     klo16[ia] = (uint16_t)k_lo;
-                    pre16[ia + 1] = (uint16_t)(k_hi - k_lo + 1);
+                    pre16[ia + 1] = (lab && lab[ia] < 0) ? (uint16_t)0 : (uint16_t)(k_hi - k_lo + 1);
                 }
                 if (tid == 0) pre16[0] = 0;
                 __syncthreads();
@@ -991,7 +995,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         atomicOr(&tmask[key], ((2ull << m2) - 1ull) & ~((1ull << m1) - 1ull));
                     }
                     const uint32_t dnext = k < lp ? (wnx & 3u) : (w & 3u), dprev = k > 0 ? (wpv & 3u) : (w & 3u);
-                    const uint32_t item = IT_MAKE(i, tlo, to_end, span, dprev, dnext, w & 3u);
+                    const uint32_t item = IT_MAKE(lab ? (int)lab[i] : i, tlo, to_end, span, dprev, dnext, w & 3u);
                     const int kb = bb * K1 + key + 1;
                     const uint32_t old = atomicAdd(&bkc[kb >> 1], (kb & 1) ? 0x10000u : 1u);
                     csr_items[gbase + (int)((kb & 1) ? (old >> 16) : (old & 0xFFFFu))] = item;
@@ -1002,7 +1006,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         prefetch(bk_major ? A : wave);
         for (int i = wave; !reuse && !bk_major && i < A; i += (nt >> 6)) {
             const uint16_t *path = S.path + ((size_t)b * A + i) * OBS_PRED_CAP;
-            const int lp = a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;
+            const int lp = (lab && lab[i] < 0) ? -1 : (int)a_lp[i], tpc = a_tpc[i], tlast = X.Tn - 1;   // (not listed: no items)
             const int lp2 = dual_fill ? (int)a_lp2[i] : -1, tpc2 = dual_fill ? (int)a_tpc2[i] : 1;
             uint32_t wv[FU], wnx[FU], wpv[FU];
 #pragma unroll
@@ -1043,7 +1047,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                         atomicOr(&tmask[key], bits);
                     }
                 }
-                const uint32_t item = IT_MAKE(i, tlo, to_end, span, dprev, dnext, w & 3u);
+                const uint32_t item = IT_MAKE(lab ? (int)lab[i] : i, tlo, to_end, span, dprev, dnext, w & 3u);
                 if (bk) {  // csr[key] stays the START of the key's list; the bucket's running offset is bumped
                     const int thi = to_end ? tlast : tlo + span - 1;
                     int b1 = min(tlo >> bk_shift, bk_nb - 1), b2 = min(thi >> bk_shift, bk_nb - 1);

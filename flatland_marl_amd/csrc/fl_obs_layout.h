@@ -281,6 +281,9 @@ struct ObsArgs {
                        // of 32 agents, 3: rounds of 16 agents on 512 threads (at most 80 KB of LDS: two workgroups a CU)
     int wl_occ_div;    // the occupant work list gets 1 / wl_occ_div of the work-list entries, the conflict list the rest
     int fix;           // FIXED launch class of this launch (ObsFixed<fix>: the kernel's layout is a compile-time constant), 0 = none
+    const int16_t *label;  // flatland_cutils get_many(handles) with a strict subset (MODE 0 only; null: every agent): label[i] = position of agent i in
+                       // the list or -1.  Only the listed agents' predictions enter the index, under their list POSITION -- the conflict test
+                       // then leaves out position `handle` and reads the state of agent `position` (treeobs.cpp:50-62, 393-465, tool.h:428-434)
     int keep_mode;     // host side: FL_OBS_KEEP_TREE_ROWS is on for this handle (the kernels keep row masks; classes 1 and 5 -- the headline
                        // kernels, which carry no code for it -- are not taken)
     int keep_rows;     // upstream tree: the output buffer still holds the previous launch's rows (FL_OBS_KEEP_TREE_ROWS and the same buffer and

@@ -26,7 +26,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
+           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_handles", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
         L.fl_scores.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        if hasattr(L, "fl_obs_cutils_handles"):
+            L.fl_obs_cutils_handles.argtypes = [vp, i32, i32, vp, i32] + [vp] * 7
         if hasattr(L, "fl_obs_set_mode"):             # (an older build loaded through bench.py --lib for a same-box A/B run has none)
             L.fl_obs_set_mode.argtypes = [vp, i32]
         L.fl_step_obs.argtypes = [vp, vp, u32, u32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 7 + [i32, i32, vp]
@@ -336,9 +338,17 @@ class BatchedRailEnv:
                 props=t.zeros((B, A, 3), dtype=t.float64, device=dev))
         return self._obs
 
-    def obs_cutils(self):
-        """flatland_cutils.TreeObsForRailEnv.get_many + get_properties for every agent of every env."""
+    def obs_cutils(self, handles=None):
+        """flatland_cutils.TreeObsForRailEnv.get_many + get_properties for every agent of every env.  handles: get_many(handles)
+        with a strict subset (a permutation of 0 .. n-1, the same list for every env; fl_obs_cutils_handles): the tensors still
+        hold every agent's rows, the trees computed against the predictions of the listed agents only."""
         o = self._obs_buffers()
+        if handles is not None:
+            hs = np.ascontiguousarray(handles, dtype=np.int32)
+            _chk(lib().fl_obs_cutils_handles(self.h, self.max_nodes, self.pred_depth, _p(hs), len(hs), o["agent_attr"].data_ptr(),
+                                             o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
+                                             o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
+            return o
         _chk(lib().fl_obs_cutils(self.h, self.max_nodes, self.pred_depth, o["agent_attr"].data_ptr(),
                                  o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
                                  o["edge_order"].data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))

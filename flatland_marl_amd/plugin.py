@@ -22,9 +22,10 @@ again on every call, duck-typed:
 Everything is computed by the HIP kernels through the C-ABI; there is no CPU path (BatchedRailEnv raises without a GPU).
 The env's own `distance_map` is not read: the reference's is the BFS of `env.rail.grid` towards the agents' targets
 (distance_map.py:57-160), which is what the GPU builds; `verify_distance_map=True` compares the two at reset().
-`handles`: the observation is computed for the whole env and the rows of `handles` are returned; `RailEnv` always passes every
-handle (rail_env.py:665).  (With a strict subset the reference leaves the other agents' predictions out of the conflict test,
-treeobs.cpp:50-62: not reproduced.)
+`handles`: `RailEnv` always passes every handle (rail_env.py:665).  With a strict subset the flatland_cutils builder of the reference
+keeps only the listed agents' predictions, indexed by list position (treeobs.cpp:50-62): reproduced (fl_obs_cutils_handles;
+goldens from the reference in tests/golden/subset_cfg2.npz); lists for which the reference's behaviour is undefined -- a handle >=
+len(handles), tool.h:428-434 -- raise ValueError.  The upstream builder computes with every agent and returns the listed rows.
 
 Cost of a call (tools/plugin_latency.py, profiles/r05_plugin_latency.json): the per-call host work is the reference's own -- one
 pass over the agents' attributes -- and nothing that grows with the map: the grid is read and hashed at reset() only, the per-call
@@ -157,11 +158,11 @@ class TreeObsForRailEnv(_re.TreeObsForRailEnv):
         self._compute()                          # AgentsLoader::update inside reset() (treeobs.cpp:22-28): the checker sees the state
                                                  # at reset, and get_properties() is valid straight after it
 
-    def _compute(self):
+    def _compute(self, handles=None):
         b = self._bind
         b.push_dynamic(self.env)
         t0 = time.perf_counter() if b.profile is not None else 0.0
-        o = b.batch.obs_cutils()
+        o = b.batch.obs_cutils(handles)
         b.batch.check()                          # (synchronises: the kernel has run)
         t0 = b.lap("kernel", t0)
         self._last = {k: v[0].cpu().numpy() for k, v in o.items()}
@@ -177,12 +178,15 @@ class TreeObsForRailEnv(_re.TreeObsForRailEnv):
             return super().get_many(handles)
         if self._bind.batch is None:
             raise RuntimeError("TreeObsForRailEnv.get_many() before reset()")
-        L = self._compute()
         h = list(handles)
+        # a strict subset: the reference's conflict test then sees the listed agents' predictions only, by list position
+        # (treeobs.cpp:50-62) -- fl_obs_cutils_handles; lists the reference has no defined behaviour for raise ValueError
+        L = self._compute(_re.cutils_handle_list(h, self._bind.batch.A))
+        # the attribute rows of ALL agents (feature_parser.cpp:100-118), the trees of the listed ones in list order (treeobs.cpp:93-101)
         if as_arrays:
-            return (L["agent_attr"][h], (L["forest"][h], L["adjacency"][h], L["node_order"][h], L["edge_order"][h]))
+            return (L["agent_attr"], (L["forest"][h], L["adjacency"][h], L["node_order"][h], L["edge_order"][h]))
         t0 = time.perf_counter() if self._bind.profile is not None else 0.0
-        out = (L["agent_attr"][h].tolist(),
+        out = (L["agent_attr"].tolist(),
                (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(), L["edge_order"][h].tolist()))
         self._bind.lap("tolist", t0)
         return out

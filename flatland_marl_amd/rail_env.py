@@ -174,6 +174,19 @@ class ObservationBuilder:
         return self.get_many([handle])[handle]
 
 
+def cutils_handle_list(handles, n_agents):
+    """get_many(handles) of flatland_cutils: None for "every agent in order" (the usual call, rail_env.py:665), else the list for
+    fl_obs_cutils_handles -- a strict subset makes the reference's conflict test work on list POSITIONS (treeobs.cpp:50-62, 393-465),
+    which is only defined when the list is a permutation of 0 .. n-1 (tool.h:428-434 erases position `handle`)."""
+    h = [int(x) for x in handles]
+    if h == list(range(n_agents)):
+        return None
+    if not h or sorted(h) != list(range(len(h))):
+        raise ValueError("get_many(handles=%r): the reference's behaviour is undefined for this list -- its conflict test erases list position "
+                         "`handle` (flatland_cutils tool.h:428-434), so a strict subset has to be a permutation of 0 .. len(handles)-1" % (h,))
+    return h
+
+
 class TreeObsForRailEnv(ObservationBuilder):
     """Drop-in for flatland_cutils.TreeObsForRailEnv(max_nodes, max_pred_depth) (treeobs.h:133-169)."""
     checks_errors = True
@@ -192,18 +205,21 @@ class TreeObsForRailEnv(ObservationBuilder):
     def get_many(self, handles):
         """-> (agent_attr [A][83], (nodes [A][N][12], adjacency [A][N-1][3], node_order [A][N], edge_order [A][N-1]))
         as nested lists, like the pybind11 STL casters return them (treeobs.h:160-161)."""
-        o = self.env._batch.obs_cutils()
+        h = list(handles)
+        o = self.env._batch.obs_cutils(cutils_handle_list(h, self.env.get_num_agents()))
         self.env._batch.check()       # the one synchronising error check of a step (RailEnv.step leaves it to the builder)
         self._last = {k: v[0].cpu().numpy() for k, v in o.items()}
-        h = list(handles)
         L = self._last
-        return (L["agent_attr"][h].tolist(),
+        # (the attribute rows of ALL agents, the trees of the listed ones in list order: feature_parser.cpp:100-118, treeobs.cpp:93-101)
+        return (L["agent_attr"].tolist(),
                 (L["forest"][h].tolist(), L["adjacency"][h].tolist(), L["node_order"][h].tolist(),
                  L["edge_order"][h].tolist()))
 
     def get(self, handle=0):
-        attr, (nodes, adj, node_order, edge_order) = self.get_many([handle])
-        return attr[0], (nodes[0], adj[0], node_order[0], edge_order[0])
+        """ONE agent's observation as RailEnv would see it: its row of get_many(every handle) (the pybind11 class has no get();
+        get_many([handle]) alone would be the reference's strict-subset semantics, see cutils_handle_list)"""
+        attr, (nodes, adj, node_order, edge_order) = self.get_many(range(self.env.get_num_agents()))
+        return attr[handle], (nodes[handle], adj[handle], node_order[handle], edge_order[handle])
 
     def get_properties(self):
         """treeobs.cpp:612-640"""

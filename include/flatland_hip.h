@@ -177,6 +177,15 @@ int fl_check(fl_batch *h);
 int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev,
                   int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
                   uint8_t *valid_actions_dev, double *props_dev);
+/* flatland_cutils get_many(handles) with a STRICT SUBSET of the handles (flatland_cutils/src/treeobs.cpp:50-62): the conflict test of
+ * every tree then sees the predictions of the listed agents only, indexed by their POSITION in the list -- it leaves out position
+ * `handle` (tool.h:428-434) and reads agents[position].state (treeobs.cpp:413, 435, 455); reproduced as it is.  handles: host
+ * int32[n_handles], the same list for every env of the batch; it has to be a permutation of 0 .. n_handles-1 (any other subset is
+ * undefined behaviour in the reference: FL_ERR_ARG).  The outputs are those of fl_obs_cutils for ALL agents (row i = agent i;
+ * the reference returns the attribute rows of all agents and the trees of the listed ones in list order: the caller gathers). */
+int fl_obs_cutils_handles(fl_batch *h, int max_nodes, int pred_depth, const int32_t *handles, int n_handles, float *attr_dev,
+                          float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
+                          uint8_t *valid_actions_dev, double *props_dev);
 /* upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)); pred_depth < 0: no predictor.
  * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);

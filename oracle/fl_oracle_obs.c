@@ -56,6 +56,12 @@ typedef struct {
     int T;          /* number of time entries = depth + 1 */
     int *pos;       /* [T][A] */
     int *dir;       /* [T][A] */
+    /* get_many(handles) with a strict subset (treeobs.cpp:50-62): predicted_pos / predicted_dir hold one entry per LISTED handle, in
+     * the order of the list; entry j belongs to agent list[j].  The conflict test then works on list positions: it leaves out
+     * position `agent.handle` (tool.h:428-434) and reads agents[position].state (treeobs.cpp:413, 435, 455) -- reproduced as it is.
+     * list == NULL: every agent, position = handle. */
+    int n;
+    const int *list;
 } Pred;
 
 /* cutils: get_shortest_paths (predictions.cpp:78-144) -- strict greedy descent, <= max_depth iterations,
@@ -241,23 +247,27 @@ static void explore_branch(const OrcEnv *e, const CellMaps *m, const Pred *p, in
                 int int_position = c * W + r;
                 int pre = predicted_time - 1 < 0 ? 0 : predicted_time - 1;
                 int post = predicted_time + 1 > p->T - 1 ? p->T - 1 : predicted_time + 1;
-                int times[3], k, a, sel = -1;
+                int times[3], k, a, j, sel = -1;
+                const int n_list = p->list ? p->n : A;
                 times[0] = predicted_time; times[1] = pre; times[2] = post;
                 for (k = 0; k < 3 && sel < 0; k++) /* "in np.delete(predicted_pos[t], handle)" */
-                    for (a = 0; a < A; a++)
-                        if (a != handle && p->pos[times[k] * A + a] == int_position) { sel = k; break; }
+                    for (j = 0; j < n_list; j++) {
+                        a = p->list ? p->list[j] : j;
+                        if (j != handle && p->pos[times[k] * A + a] == int_position) { sel = k; break; }
+                    }
                 if (sel >= 0) {
                     int ts = times[sel];
                     /* cutils indexes predicted_dir with predicted_time in all three branches (treeobs.cpp:429-433,
                      * 449-453); python uses the matching step (observations.py:351-363) */
                     int td = cutils ? predicted_time : ts;
-                    for (a = 0; a < A; a++) {
+                    for (j = 0; j < n_list; j++) {
+                        a = p->list ? p->list[j] : j;
                         if (p->pos[ts * A + a] != int_position) continue;
                         {
                             int cd = p->dir[td * A + a];
                             if (d != cd && ((bits >> (3 - ((cd + 2) % 4))) & 1) && (double)tot_dist < pot_conflict)
                                 pot_conflict = tot_dist;
-                            if (e->state[a] == ST_DONE && (double)tot_dist < pot_conflict) pot_conflict = tot_dist;
+                            if (e->state[j] == ST_DONE && (double)tot_dist < pot_conflict) pot_conflict = tot_dist;   /* agents[list position] */
                         }
                     }
                 }
@@ -451,6 +461,14 @@ typedef struct { int r, c, d, action_dir, parent, tot_dist, is_null; } QCell;
 
 int orc_obs_cutils(OrcEnv *e, int max_nodes, int pred_depth, float *attr, float *forest, int32_t *adjacency,
                    int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props) {
+    return orc_obs_cutils_handles(e, max_nodes, pred_depth, NULL, 0, attr, forest, adjacency, node_order, edge_order, valid, props);
+}
+
+/* get_many(handles) (treeobs.cpp:30-108): handles == NULL: every agent.  A strict subset has to be a permutation of 0 .. n-1 (every
+ * handle below the length of the list: get_possible_conflicting erases position `handle`, tool.h:428-434 -- undefined behaviour
+ * otherwise); the trees of ALL agents are written (row i = agent i), the caller picks the listed ones. */
+int orc_obs_cutils_handles(OrcEnv *e, int max_nodes, int pred_depth, const int32_t *handles, int n_handles, float *attr, float *forest,
+                           int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props) {
     int A = e->A, i, rc = ORC_OK;
     Pred p;
     CellMaps m;
@@ -472,6 +490,7 @@ int orc_obs_cutils(OrcEnv *e, int max_nodes, int pred_depth, float *attr, float 
     p.depth = pred_depth; p.T = pred_depth + 1;
     p.pos = (int *)malloc(sizeof(int) * (size_t)p.T * A);
     p.dir = (int *)malloc(sizeof(int) * (size_t)p.T * A);
+    p.n = n_handles; p.list = handles;
     cutils_predict(e, &p);
     build_maps(e, &m, 1);
 
@@ -647,6 +666,7 @@ int orc_obs_pytree(OrcEnv *e, int max_depth, int pred_depth, double *out) {
     CellMaps m;
     if (pred_depth >= 0) {
         p.depth = pred_depth; p.T = pred_depth + 1;
+        p.n = 0; p.list = NULL;
         p.pos = (int *)malloc(sizeof(int) * (size_t)p.T * A);
         p.dir = (int *)malloc(sizeof(int) * (size_t)p.T * A);
         py_predict(e, &p);

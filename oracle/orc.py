@@ -45,6 +45,7 @@ def lib():
         _lib.orc_motion_check.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_obs_cutils_reset.argtypes = [C.c_void_p]
         _lib.orc_obs_cutils.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        _lib.orc_obs_cutils_handles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7
         _lib.orc_obs_pytree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_mt_seed_by_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
@@ -125,14 +126,22 @@ class OracleEnv:
         lib().orc_get_distance_map(self.h, _p(dm), _p(slot))
         return dm, slot
 
-    def obs_cutils(self, max_nodes=31, pred_depth=500):
+    def obs_cutils(self, max_nodes=31, pred_depth=500, handles=None):
+        """handles: get_many(handles) with a strict subset (a permutation of 0 .. n-1, treeobs.cpp:50-62): the trees of ALL agents are
+        returned (row i = agent i), computed against the predictions of the listed handles only"""
         A, N = self.A, max_nodes
         out = dict(attr=np.zeros((A, 83), np.float32), forest=np.zeros((A, N, 12), np.float32),
                    adjacency=np.zeros((A, N - 1, 3), np.int32), node_order=np.zeros((A, N), np.int32),
                    edge_order=np.zeros((A, N - 1), np.int32), valid=np.zeros((A, 5), np.uint8),
                    props=np.zeros((A, 3), np.float64))
-        rc = lib().orc_obs_cutils(self.h, N, pred_depth, *[_p(out[k]) for k in
-                                  ("attr", "forest", "adjacency", "node_order", "edge_order", "valid", "props")])
+        if handles is not None:
+            hs = np.ascontiguousarray(handles, dtype=np.int32)
+            assert sorted(hs.tolist()) == list(range(len(hs))), "a strict subset has to be a permutation of 0 .. n-1"
+            rc = lib().orc_obs_cutils_handles(self.h, N, pred_depth, _p(hs), len(hs), *[_p(out[k]) for k in
+                                              ("attr", "forest", "adjacency", "node_order", "edge_order", "valid", "props")])
+        else:
+            rc = lib().orc_obs_cutils(self.h, N, pred_depth, *[_p(out[k]) for k in
+                                      ("attr", "forest", "adjacency", "node_order", "edge_order", "valid", "props")])
         if rc != 0:
             raise RuntimeError("orc_obs_cutils rc=%d %s" % (rc, lib().orc_last_error().decode()))
         return out

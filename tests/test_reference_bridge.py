@@ -63,7 +63,7 @@ class _Recorder:
     def set_state(self, state, aux, elapsed):
         self.pushed.append((state[0].copy(), aux[0].copy(), int(elapsed[0])))
 
-    def obs_cutils(self):
+    def obs_cutils(self, handles=None):
         t, A, N = self._t, self.A, self.max_nodes
         return dict(agent_attr=t.zeros(1, A, 83), forest=t.zeros(1, A, N, 12), adjacency=t.zeros(1, A, N - 1, 3, dtype=t.int32),
                     node_order=t.zeros(1, A, N, dtype=t.int32), edge_order=t.zeros(1, A, N - 1, dtype=t.int32),

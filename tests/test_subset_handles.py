@@ -1,0 +1,64 @@
+"""get_many(handles) with a STRICT SUBSET of the handles (flatland_cutils/src/treeobs.cpp:50-62): the conflict test then sees the
+predictions of the listed handles only, indexed by their position in the list.  Goldens from the real reference
+(oracle/refharness/capture_subset.py -> tests/golden/subset_cfg2.npz): the oracle (CPU) and the HIP path (GPU, through the plug-in's
+get_many) reproduce the reference's forests for every captured list, and the lists the reference has no defined behaviour for
+(a handle >= len(handles), tool.h:428-434) are refused."""
+import numpy as np
+import pytest
+
+from tests import util
+
+
+def _lists(fx):
+    return [fx["handles_%d" % k].tolist() for k in range(int(fx["n_lists"]))]
+
+
+def test_oracle_reproduces_the_reference_on_handle_subsets():
+    from oracle import orc
+    fx = util.load("subset_cfg2")
+    e = orc.OracleEnv(fx)
+    snap = {int(t): k for k, t in enumerate(fx["snap_steps"])}
+    n_diff = 0
+    for t, a in enumerate(fx["actions"]):
+        e.step(a)
+        full = e.obs_cutils(31, 500)           # (every step: the deadlock flags are sticky)
+        if t + 1 not in snap:
+            continue
+        k = snap[t + 1]
+        np.testing.assert_array_equal(e.state(), fx["snaps"][k], err_msg=f"state at step {t + 1}")
+        for j, hs in enumerate(_lists(fx)):
+            o = full if hs == list(range(e.A)) else e.obs_cutils(31, 500, handles=hs)
+            np.testing.assert_array_equal(o["forest"][hs], fx["forest_%d" % j][k], err_msg=f"step {t + 1} list {hs} forest")
+            np.testing.assert_array_equal(o["adjacency"][hs], fx["adjacency_%d" % j][k], err_msg=f"step {t + 1} list {hs} adjacency")
+            np.testing.assert_array_equal(o["attr"], fx["attr_%d" % j][k], err_msg=f"step {t + 1} list {hs} attr (all agents)")
+            n_diff += int((o["forest"][hs] != full["forest"][hs]).any())
+    assert n_diff >= 10            # the subsets do change the trees
+
+
+@pytest.mark.gpu
+def test_plugin_get_many_with_handle_subsets_matches_the_reference():
+    from flatland_marl_amd.plugin import TreeObsForRailEnv
+    fx = util.load("subset_cfg2")
+    class _Fx(dict):                      # (what DuckEnv reads of an .npz fixture)
+        files = property(lambda self: list(self))
+    st = {k: fx[k] for k in ("grid", "init_pos", "init_dir", "target", "speed", "earliest", "latest", "T")}
+    env = util.DuckEnv(_Fx(st, **{"s_" + k: fx["snaps"][:, :, i] for i, k in enumerate(util.STATE_NAMES)}))
+    b = TreeObsForRailEnv(31, 500)
+    b.set_env(env)
+    b.reset()
+    A = env.get_num_agents()
+    for k, T in enumerate(fx["snap_steps"]):
+        # the agents as the reference had them at the snapshot; the in_malfunction signals and the checker's flags as captured
+        env.goto(k + 1)
+        env._elapsed_steps = int(T)
+        for i, ag in enumerate(env.agents):
+            ag.state_machine.st_signals.in_malfunction = bool(fx["sig"][k][i])
+        b._bind.dead = fx["deadlocked"][k].astype(np.int32)
+        for j, hs in enumerate(_lists(fx)):
+            attr, (nodes, adj, no, eo) = b.get_many(hs, as_arrays=True)
+            np.testing.assert_array_equal(nodes, fx["forest_%d" % j][k], err_msg=f"T={T} list {hs} forest")
+            np.testing.assert_array_equal(adj, fx["adjacency_%d" % j][k], err_msg=f"T={T} list {hs} adjacency")
+            np.testing.assert_array_equal(attr, fx["attr_%d" % j][k], err_msg=f"T={T} list {hs} attr (all agents)")
+    for bad in ([5], [0, 2], [1, 1], [0, 1, A]):
+        with pytest.raises(ValueError, match="undefined"):
+            b.get_many(bad)
