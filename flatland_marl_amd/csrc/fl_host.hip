@@ -572,7 +572,7 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
     // one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
     fl_launch_step(h->d, actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags, h->stream);
     HIPCHK(hipGetLastError());
-    if (tree_max_depth > 3) return fl_obs_cutils_tree(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
+    if (tree_max_depth > 3 || (tree_max_depth > 0 && max_nodes > 32)) return fl_obs_cutils_tree(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
                                                       valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev);
     const int rc = tree_max_depth > 0 ? fl_launch_obs_both(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev,
                                                            edge_order_dev, valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth,
@@ -921,7 +921,7 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
         set_err("fl_obs_cutils_tree: null output buffer");
         return FL_ERR_ARG;
     }
-    if (tree_max_depth > 3) {   // beyond the fused kernels' node tables: the two builders one after the other (same outputs)
+    if (tree_max_depth > 3 || max_nodes > 32) {   // beyond the fused kernels' node tables: the two builders one after the other (same outputs)
         int rc2 = fl_obs_cutils(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev, valid_actions_dev, props_dev);
         return rc2 != FL_OK ? rc2 : fl_obs_tree(h, tree_max_depth, tree_pred_depth, tree_out_dev);
     }

@@ -4,7 +4,7 @@
 
 #include "fl_internal.h"
 
-#define FL_OBS_MAX_NODES 32  /* all non-root nodes of a tree are evaluated by one 32-lane group */
+#define FL_OBS_MAX_NODES 64  /* a tree's nodes are the lanes of one team: 32 lanes (two trees a wavefront) up to 32 nodes, a whole wavefront up to 64 */
 #define FL_OBS_MAX_PRED 500
 
 #ifndef OBS_WIDE_ENVS_PER_CU

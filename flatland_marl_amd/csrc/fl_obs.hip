@@ -378,7 +378,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.label = label_dev;
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
-    P.tw_c = N_WORDS_C * OBS_CAP_C;
+    P.tw_c = N_WORDS_C * (max_nodes > OBS_CAP_C ? 64 : OBS_CAP_C);   // (more than 32 nodes: 64-slot tables, one tree a wavefront)
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);
@@ -388,7 +388,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s) {
-    if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
+    if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > OBS_CAP_C) return FL_ERR_ARG;   // (the fused kernels: 32-lane teams)
     if (max_depth > 3 || tree_pred > pred_depth || tree_pred < 0) return FL_ERR_ARG;  // the upstream path must be a prefix
     ObsArgs P = {};
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;

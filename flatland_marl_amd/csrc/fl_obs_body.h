@@ -709,7 +709,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #ifdef FL_OBS_TIMING
             const long long t_pa0 = (long long)wall_clock64();
 #endif
-            if (CUTILS && (!bk || bk_lds)) {  // pass A of the team's first tree (not while the node tables hold the bucket counters)
+            if (CUTILS && (!bk || bk_lds) && P.max_nodes <= OBS_CAP_C) {  // pass A of the team's first tree (not while the node tables hold the bucket counters; 32-lane teams)
                 int node_base, levels;
                 const bool have = team_id < A;
                 cutils_pass_a(X, d, P, b, team_id, have, grp, gl,
@@ -1118,6 +1118,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (merged) {
         if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
         else trees_merged<false, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
+    } else if (CUTILS && STAGE == 0 && FIX == 0 && P.max_nodes > OBS_CAP_C) {
+        // more than 32 nodes a tree (the stand-alone flatland_cutils launch only): a team of 64 lanes, one tree a wavefront
+        if (items_in_lds) trees_cutils<true, 64>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
+        else trees_cutils<false, 64>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
     } else if (CUTILS) {
         if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
         else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);

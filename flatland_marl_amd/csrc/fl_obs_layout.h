@@ -88,7 +88,8 @@ enum { ND_TARGET = 1, ND_SWITCH = 2, ND_DEAD_END = 4, ND_TERMINAL = 8, ND_ZERO =
 
 // LDS words of the trees' node tables: one slot per team that can hold an agent plus one dummy slot that the idle teams share
 __host__ __device__ constexpr int obs_scr_words(int nwaves, int A, int tw_c, int tw_t, int tpw_t) {
-    const int n_c = 2 * nwaves <= A ? 2 * nwaves : A + 1, n_t = tpw_t * nwaves <= A ? tpw_t * nwaves : A + 1;
+    const int tpw_c = tw_c > N_WORDS_C * OBS_CAP_C ? 1 : 2;   // (64-slot tables of max_nodes > 32: one flatland_cutils tree a wavefront)
+    const int n_c = tpw_c * nwaves <= A ? tpw_c * nwaves : A + 1, n_t = tpw_t * nwaves <= A ? tpw_t * nwaves : A + 1;
     const int w_c = n_c * tw_c, w_t = n_t * tw_t;
     return w_c > w_t ? w_c : w_t;
 }

@@ -245,12 +245,15 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 // Pass A of one flatland_cutils tree (treeobs.cpp:154-256): root row, node topology level by level (BFS), one team of 32
 // lanes per agent, two teams per wavefront.  Only wave-level synchronisation, so a wavefront can run it whenever the
 // rail bitmap and the agent snapshot are in LDS (the workgroup overlaps it with the path walk of phase 2).
+// TC = lanes of the team = slots of its node table: 32 (two trees a wavefront; max_nodes <= 32, the solution's 31) or 64 (one tree a
+// wavefront; max_nodes up to 64, the stand-alone flatland_cutils launch only)
+template <int TC = OBS_CAP_C>
 __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
                                               int gl, int *scr, const uint16_t *a_vpos, const int *a_pos,
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
                                               const uint16_t *a_tslot, float max_dist, uint32_t spk, uint32_t malfw,
                                               int &node_base_out, int &levels_out) {
-    constexpr int CAP = OBS_CAP_C;
+    constexpr int CAP = TC;
     const int A = X.A, N = P.max_nodes;
     const int ia = have ? i : 0;
     const int g = b * A + ia;
@@ -289,17 +292,17 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
             ch0 = child_state(nd, 0); ch1 = child_state(nd, 1); ch2 = child_state(nd, 2);
             nt_store_desc(scr, CAP, idx_node, nd, 0, &d.err[b]);
         }
-        const uint32_t exp_mask = (uint32_t)(__ballot(explored) >> (grp * 32));
-        const int n_next = 3 * __popc(exp_mask);
+        const unsigned long long exp_mask = TC == 64 ? __ballot(explored) : ((__ballot(explored) >> (grp * 32)) & 0xFFFFFFFFull);
+        const int n_next = 3 * __popcll(exp_mask);
         if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
-            const int fc = explored ? node_base + m + 3 * __popc(exp_mask & ((1u << gl) - 1u)) : 0;
+            const int fc = explored ? node_base + m + 3 * __popcll(exp_mask & ((1ull << gl) - 1ull)) : 0;
             nt_w(scr, CAP, N_PH, idx_node) = (c_parent + 2) | (((fc << 2) | (c_act + 1)) << 8);
         }
         // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
         const int src_rank = gl / 3, which = gl - 3 * src_rank;
         const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
-        const int s_c0 = __shfl(ch0, src, 32), s_c1 = __shfl(ch1, src, 32), s_c2 = __shfl(ch2, src, 32);
-        const int s_tot = __shfl(ch_tot, src, 32);
+        const int s_c0 = __shfl(ch0, src, TC), s_c1 = __shfl(ch1, src, TC), s_c2 = __shfl(ch2, src, TC);
+        const int s_tot = __shfl(ch_tot, src, TC);
         if (active) {
             const int parent_base = node_base;
             node_base += m;
@@ -331,15 +334,16 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
 }
 
 // rows, adjacency and evaluation orders of one flatland_cutils tree from its node table (after pass B); lane gl of the team
+template <int TC = OBS_CAP_C>
 __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int gl,
                                                    const int *scr, int node_base, int levels, float max_dist) {
-    constexpr int CAP = OBS_CAP_C;
+    constexpr int CAP = TC;
     const int A = X.A, N = P.max_nodes;
     const int g = b * A + (have ? i : 0);
     float *F = P.forest + (size_t)g * N * 12;
     int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
     if (have) {  // rows: lane gl writes node gl + 1
-        for (int idx = gl + 1; idx < N; idx += 32) {
+        for (int idx = gl + 1; idx < N; idx += TC) {
             int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
             if (idx < node_base) {
                 const uint32_t ph = (uint32_t)nt_r(scr, CAP, N_PH, idx);
@@ -369,17 +373,17 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
         const int nchild = fc > 0 ? max(0, min(3, node_base - fc)) : 0;  // children beyond max_nodes were never popped
         // `levels` counted the rounds of pass A including the one that found nothing left: a tree of L levels below the root
         // needs L rounds here (a leaf is 0, every round carries the heights one level up)
-        const int max_levels = max(__builtin_amdgcn_readlane(levels, 0), __builtin_amdgcn_readlane(levels, 32));
+        const int max_levels = TC == 64 ? __builtin_amdgcn_readlane(levels, 0) : max(__builtin_amdgcn_readlane(levels, 0), __builtin_amdgcn_readlane(levels, 32));
         int h = 0;
         for (int it = 0; it + 1 < max_levels; it++) {
-            const int h0 = __shfl(h, fc, 32), h1 = __shfl(h, fc + 1, 32), h2 = __shfl(h, fc + 2, 32);
+            const int h0 = __shfl(h, fc, TC), h1 = __shfl(h, fc + 1, TC), h2 = __shfl(h, fc + 2, TC);
             int hn = 0;
             if (nchild > 0) hn = h0 + 1;
             if (nchild > 1) hn = max(hn, h1 + 1);
             if (nchild > 2) hn = max(hn, h2 + 1);
             h = hn;
         }
-        const int hp = __shfl(h, parent < 0 ? 0 : parent, 32);
+        const int hp = __shfl(h, parent < 0 ? 0 : parent, TC);
         if (have) {
             int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
             if (gl < N) {
@@ -391,38 +395,38 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
 }
 
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
-template <bool ITL>
+template <bool ITL, int TC = OBS_CAP_C>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                              int nwaves, int *wave_scr, int *team_meta,
                                              const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot,
                                              float max_dist, bool hoisted) {
-    constexpr int CAP = OBS_CAP_C, TW = N_WORDS_C * OBS_CAP_C;
+    constexpr int CAP = TC, TW = N_WORDS_C * TC, TPW = 64 / TC;   // teams (trees) per wavefront
     const int A = X.A;
-    const int grp = lane >> 5, gl = lane & 31;
+    const int grp = TC == 64 ? 0 : lane >> 5, gl = lane & (TC - 1);
     // team t's node table is slot t (wg_pass_b); teams that can never hold an agent share the dummy slot behind the real ones
-    int *scr = wave_scr + min(wave * 2 + grp, min(nwaves * 2, A)) * TW;
-    for (int base = 0; base < A; base += nwaves * 2) {
-        const int i = base + wave * 2 + grp;
+    int *scr = wave_scr + min(wave * TPW + grp, min(nwaves * TPW, A)) * TW;
+    for (int base = 0; base < A; base += nwaves * TPW) {
+        const int i = base + wave * TPW + grp;
         const bool have = i < A;
         int node_base, levels;
-        if (hoisted && base == 0) {  // pass A of the first round already ran beside the path walk
-            node_base = team_meta[64 + wave * 2 + grp];
-            levels = team_meta[192 + wave * 2 + grp];
+        if (hoisted && base == 0) {  // pass A of the first round already ran beside the path walk (32-lane teams only)
+            node_base = team_meta[64 + wave * TPW + grp];
+            levels = team_meta[192 + wave * TPW + grp];
         } else {
-            cutils_pass_a(X, d, P, b, i, have, grp, gl, scr, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist,
-                          d.spk[b * A + (have ? i : 0)], d.malf[b * A + (have ? i : 0)], node_base, levels);
+            cutils_pass_a<TC>(X, d, P, b, i, have, grp, gl, scr, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist,
+                              d.spk[b * A + (have ? i : 0)], d.malf[b * A + (have ? i : 0)], node_base, levels);
         }
         TREE_STAMP(X, 6);
         {
             int first;
-            const int tot_cells = team_prepare<32, CAP, false>(have, gl, have ? node_base : 1, scr, first);
-            const int team_id = wave * 2 + grp;
+            const int tot_cells = team_prepare<TC, CAP, false>(have, gl, have ? node_base : 1, scr, first);
+            const int team_id = wave * TPW + grp;
             if (gl == 0) { team_meta[team_id] = have ? tot_cells : 0; team_meta[64 + team_id] = have ? node_base : 1; team_meta[128 + team_id] = have ? i : -1; team_meta[256 + team_id] = first; }
         }
-        wg_pass_b<1, CAP, ITL, NoLateWork, !ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * 2, wave_scr, TW, team_meta);   // (items in HBM: a query may be two pieces)
+        wg_pass_b<1, CAP, ITL, NoLateWork, !ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr, TW, team_meta);   // (items in HBM: a query may be two pieces)
         TREE_STAMP(X, 7);
-        cutils_rows_orders(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
+        cutils_rows_orders<TC>(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
         team_sync();
         TREE_STAMP(X, 16);
     }

@@ -61,7 +61,8 @@ enum {
  *                          LDS sets the limit: the distance-map kernel holds an env's neighbour table, bitmaps and queues
  *                          (about 10 900 cells; fl_reserve / fl_commit say so), the observation kernels its rail-cell index
  *                          (about 6 000 cells with 400 agents; the largest Round-2 map, 158 x 158 / 41 cities, has 2 710)
- *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (one 32-lane team per tree; the solution uses 31)
+ *   FL_MAX_CUTILS_NODES    flatland_cutils max_nodes (a tree's nodes are the lanes of its team: 32 lanes up to 32 nodes -- the solution
+ *                          uses 31 --, a whole wavefront up to 64; beyond 32 the fused entry points run the two builders as two launches)
  *   FL_MAX_PRED_DEPTH      predictor depth of either builder (the solution uses 500 / 30)
  *   FL_MAX_TREE_DEPTH      max_depth of the upstream TreeObsForRailEnv (85 rows at depth 3, 341 at depth 4; depth 4 on grids whose cells
  *                          have at most two transitions per direction -- every Flatland rail cell type --, the builders then run as
@@ -71,7 +72,7 @@ enum {
 #define FL_MAX_AGENTS 1024
 #define FL_MAX_SPEED_COUNT 63
 #define FL_MAX_RAIL_CELLS 16383
-#define FL_MAX_CUTILS_NODES 32
+#define FL_MAX_CUTILS_NODES 64
 #define FL_MAX_PRED_DEPTH 500
 #define FL_MAX_TREE_DEPTH 4
 

@@ -203,16 +203,17 @@ def sp_follow_actions(env, rng, p_stop=0.03):
 
 
 def run_episode(name, test_id, level, stream, seed=1, max_steps=None, obs_every=1,
-                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False, dims=None, speed_ratios=None):
+                malfunction_interval=None, pytree=None, pytree_every=25, dm_raw=False, dims=None, speed_ratios=None, max_nodes=31):
     """stream in {"uniform", "sparse", "spfollow", "fwd"}.  speed_ratios: {speed: probability} instead of the CSV row's."""
     row = csv_row(test_id, level)
     if speed_ratios is not None:
         row["speed_ratios"] = dict(speed_ratios)
-    env, mp = make_env(row, malfunction_interval, dims=dims)
+    env, mp = make_env(row, malfunction_interval, dims=dims, obs=None if max_nodes == 31 else TreeCutils(max_nodes, 500))
     obs0, _ = env.reset()
     A = env.get_num_agents()
     out = static_arrays(env, mp)
     out.update(dm_unique(env))
+    out["max_nodes"] = np.int32(max_nodes)
     if dm_raw:
         out["dm_f64"] = np.asarray(env.distance_map.get(), dtype=np.float64)
     out["stream"] = np.array(stream)
@@ -452,6 +453,11 @@ JOBS = {
     # (SpeedCounter.max_count = int(1 / speed) - 1 up to 49; speed_counter.py:41 takes any speed)
     "cfg2_depth4": lambda: run_episode("cfg2_depth4", "Test_2", "Level_3", "spfollow", seed=81, max_steps=260, obs_every=64,
                                        pytree=[(4, 30), (4, 10)], pytree_every=64),
+    # flatland_cutils trees of more than 32 nodes (treeobs.cpp:5-7, 223 take any max_nodes); named outside the cfg* pattern: the
+    # generic fixture tests build 31-node trees
+    "nodes50_cfg2": lambda: run_episode("nodes50_cfg2", "Test_2", "Level_6", "spfollow", seed=84, max_steps=300, obs_every=30, max_nodes=50),
+    "nodes64_cfg3": lambda: run_episode("nodes64_cfg3", "Test_4", "Level_2", "spfollow", seed=85, max_steps=240, obs_every=60, max_nodes=64,
+                                        malfunction_interval=200),
     "cfg2_slow_trains": lambda: run_episode("cfg2_slow_trains", "Test_2", "Level_4", "spfollow", seed=82, obs_every=16, max_steps=900,
                                             pytree=[(2, 30)], pytree_every=128,
                                             speed_ratios={1.0: 0.25, 1.0 / 20.0: 0.25, 1.0 / 33.0: 0.25, 1.0 / 50.0: 0.25}),

@@ -373,7 +373,7 @@ def test_fused_step_after_episode_end_raises_like_the_reference():
 
 
 def test_builder_sizes_beyond_the_limits_are_refused_with_a_message():
-    """max_depth 5, max_depth 4 on a grid with a three-way cell (DFS-slot node tables stop at depth 3), 33 cutils nodes, a speed below
+    """max_depth 5, max_depth 4 on a grid with a three-way cell (DFS-slot node tables stop at depth 3), 65 cutils nodes, a speed below
     1/64: FL_ERR_ARG with a message that names the limit, nothing launched"""
     from flatland_marl_amd.hip_backend import FlatlandHipError
     fx = util.load("cfg1_uniform")
@@ -383,7 +383,7 @@ def test_builder_sizes_beyond_the_limits_are_refused_with_a_message():
     assert env.obs_tree(4, 30).shape == (1, env.A, 341, 12)
     with pytest.raises(FlatlandHipError, match=r"max_depth must be in \[1,4\]"):
         env.obs_tree(5, 30)
-    env.max_nodes = 33
+    env.max_nodes = 65
     env._obs = None
     with pytest.raises(FlatlandHipError, match="max_nodes"):
         env.obs_cutils()
