@@ -10,8 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3", "cfg4_d2_distinct4", "cfg5_d3_distinct2")   # the last two: distinct generated maps
-TAG = "r04"
+WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3", "cfg2_d2_distinct10", "cfg3_d3_distinct10", "cfg4_d2_distinct4", "cfg5_d3_distinct2")   # the last four: distinct generated maps
+TAG = "r05"
 
 
 def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():

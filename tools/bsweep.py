@@ -56,7 +56,7 @@ def main():
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.out:
-        open(os.path.join(ROOT, a.out), "w").write(txt + "\n")
+        open(a.out if os.path.isabs(a.out) else os.path.join(ROOT, a.out), "w").write(txt + "\n")
 
 
 if __name__ == "__main__":

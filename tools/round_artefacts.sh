@@ -6,7 +6,11 @@ set -uo pipefail
 tag=$1
 out=gpurun_out/prof_$tag
 mkdir -p $out
-python tools/profile_workloads.py $tag cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild cfg4:2:distinct4 cfg5:3:rebuild:distinct2 > $out/profile_workloads.log 2>&1 || tail -5 $out/profile_workloads.log
+# (PART=traces: only this step; PART=rest: everything after it -- two GPU-box calls when one would not fit the call's time limit)
+if [ "${PART:-all}" != "rest" ]; then
+python tools/profile_workloads.py $tag cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild cfg2:2:distinct10 cfg3:3:distinct10 cfg4:2:distinct4 cfg5:3:rebuild:distinct2 > $out/profile_workloads.log 2>&1 || tail -5 $out/profile_workloads.log
+fi
+[ "${PART:-all}" = "traces" ] && exit 0
 echo "[artefacts] traces + traffic done"
 A="--no-extra-workloads --steps 100"
 python tools/pmc_pass.py $out/sq1.json "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" $A > /dev/null 2>&1 || echo "sq pass 1 failed"
@@ -26,8 +30,9 @@ PY
 echo "[artefacts] SQ counters done"
 if [ -f build_ab/libfl_timing.so ]; then
   : > $out/${tag}_phase_clocks.txt
-  for w in "cfg2 2" "cfg3 3" "cfg4 2" "cfg5 3"; do
-    WARM=$([ "$w" = "cfg5 3" ] && echo 60 || echo 200) python tools/obs_phase_clocks.py build_ab/libfl_timing.so $w 2>&1 | grep -v amdgpu.ids >> $out/${tag}_phase_clocks.txt
+  # (the clocks are taken in the bench's regime: de-phased replicas, see tools/obs_phase_clocks.py)
+  for w in "cfg2 2" "cfg3 3" "cfg4 2" "cfg5 3" "cfg4 2 4" "cfg5 3 2"; do
+    python tools/obs_phase_clocks.py build_ab/libfl_timing.so $w 2>&1 | grep -v amdgpu.ids >> $out/${tag}_phase_clocks.txt
     echo >> $out/${tag}_phase_clocks.txt
   done
 fi
@@ -35,3 +40,9 @@ echo "[artefacts] phase clocks done"
 python bench.py > $out/${tag}_bench_default.json 2> $out/bench_default.err || tail -3 $out/bench_default.err
 python -c "
 import json,sys; d=json.load(open('$out/${tag}_bench_default.json')); print('headline %.2f M' % (d['value']/1e6), d['roofline'], {k: round(v['value']/1e6,1) for k,v in d.get('workloads',{}).items()})"
+# round 5: throughput against the number of envs at the cfg2 shape (one / two workgroups a CU, fixed classes and runtime carving), the
+# latency of the drop-in plug-in, the soak of the non-BASELINE shapes
+python tools/bsweep.py --bs 256,384,512,768,1024,2048 --modes one_a_cu,two_a_cu,default,nofix,nofix_two_a_cu --out $out/${tag}_cfg2_bsweep.json > $out/bsweep.log 2>&1 || tail -3 $out/bsweep.log
+python tools/plugin_latency.py --out $out/${tag}_plugin_latency.json > $out/plugin.log 2>&1 || tail -3 $out/plugin.log
+python tools/soak_round2.py 320 1 $out/${tag}_soak_round2.txt > $out/soak.log 2>&1 || tail -3 $out/soak.log
+echo "[artefacts] sweep, plug-in latency, soak done"

@@ -81,7 +81,7 @@ def main():
     txt = "\n".join(lines)
     print(txt)
     if out:
-        open(os.path.join(ROOT, out), "w").write(txt + "\n")
+        open(out if os.path.isabs(out) else os.path.join(ROOT, out), "w").write(txt + "\n")
     mb.close()
 
 
