@@ -5,7 +5,7 @@ set -euo pipefail
 mkdir -p gpurun_out
 tag=$1; shift
 for wl in ${WLS:-cfg2 cfg3 cfg4 cfg5}; do
-  case $wl in cfg2) depth=2; steps=600; extra="";; cfg3) depth=3; steps=100; extra="";; cfg4) depth=2; steps=100; extra="";; cfg5) depth=3; steps=60; extra="--dm-rebuild";; esac
+  case $wl in cfg2) depth=2; steps=600; extra="";; cfg3) depth=3; steps=100; extra="";; cfg4) depth=2; steps=100; extra="";; cfg5) depth=3; steps=60; extra="--dm-rebuild";; *) echo "unknown workload $wl (cfg2 cfg3 cfg4 cfg5)"; continue;; esac
   for rep in 1 2; do
     n=0
     for setting in "$@"; do
