@@ -230,7 +230,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)b * A * P.n_tree_nodes * 12);
             const int n2 = A * P.n_tree_nodes * 6;
             const double2 ninf = make_double2(-INFINITY, -INFINITY);
-            for (int k = tid; k < n2; k += nt) o2[k] = ninf;
+            for (int k = tid; k < n2; k += nt) out_store_d2(reinterpret_cast<double *>(o2 + k), -INFINITY, -INFINITY);
             prefilled = true;
         }
         for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
@@ -385,8 +385,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 a_dead[i] = 1;
                 d.pk[g] |= PK_DEADLOCK_BIT;
             }
-            P.attr[(size_t)g * FL_CUTILS_ATTR + 41] = (float)a_dead[i];
-            if (P.props) P.props[(size_t)g * 3 + 1] = (double)a_dead[i];
+            out_store(&P.attr[(size_t)g * FL_CUTILS_ATTR + 41], (float)a_dead[i]);
+            if (P.props) out_store(&P.props[(size_t)g * 3 + 1], (double)a_dead[i]);
         }
     };
     // Rest of phase 1, per agent: valid actions, props, attribute row (everything but the deadlock flag).  A team of 32
@@ -449,10 +449,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             } else va |= 1u << ACT_NOTHING;
         } else if (state == ST_READY) va = (1u << ACT_FORWARD) | (1u << ACT_STOP);
         else va = 1u << ACT_NOTHING;
-        if (gl < 5) P.valid[(size_t)g * 5 + gl] = (va >> gl) & 1;
+        if (gl < 5) out_store(&P.valid[(size_t)g * 5 + gl], (uint8_t)((va >> gl) & 1));
         if (P.props && gl == 5) {
-            P.props[(size_t)g * 3 + 0] = (double)dist_target;
-            P.props[(size_t)g * 3 + 2] = (double)(state == ST_READY);
+            out_store(&P.props[(size_t)g * 3 + 0], (double)dist_target);
+            out_store(&P.props[(size_t)g * 3 + 2], (double)(state == ST_READY));
         }
         // AgentAttrParser::get_features (feature_parser.cpp:3-98): elements 0 .. 69 are 0 / 1 -- bit j of (m_lo, m_hi)
         const int road_type = raw.road_type;
@@ -477,13 +477,13 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                               f_before < f_dist ? f_before : f_dist, (float)max_count / 10, (float)a_speed[i] / 1.0f, (float)scount / 10,
                               (float)malf01 / 10, isinf(init_dist) ? 8.0f : init_dist / max_dist_target};
         float *o = P.attr + (size_t)g * FL_CUTILS_ATTR;
-        o[gl] = (float)((m_lo >> gl) & 1ull);
-        if (gl + 32 != 41) o[gl + 32] = (float)((m_lo >> (gl + 32)) & 1ull);  // element 41: the deadlock flag (phase 1a)
+        out_store(&o[gl], (float)((m_lo >> gl) & 1ull));
+        if (gl + 32 != 41) out_store(&o[gl + 32], (float)((m_lo >> (gl + 32)) & 1ull));  // element 41: the deadlock flag (phase 1a)
         if (gl + 64 < FL_CUTILS_ATTR) {
             float v = (float)((m_hi >> gl) & 1u);
 #pragma unroll
             for (int k = 0; k < 13; k++) v = gl == 6 + k ? fv[k] : v;
-            o[gl + 64] = v;
+            out_store(&o[gl + 64], v);
         }
     };
     // all agents of the env, one team of 32 lanes each
@@ -531,7 +531,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const int k0 = (j - n_up_jobs - n_p1_jobs) * PF_CHUNK + lane;
 #pragma unroll
                 for (int q = 0; q < 16; q++)
-                    if (k0 + q * 64 < pf_n2) o2[k0 + q * 64] = ninf;
+                    if (k0 + q * 64 < pf_n2) out_store_d2(reinterpret_cast<double *>(o2 + k0 + q * 64), -INFINITY, -INFINITY);
                 stored = true;
             }
         }

@@ -71,6 +71,42 @@ struct ObsCtx {
     int dbg_base;
 };
 
+// The observation tensors are written once and never read back by the kernel: their stores carry the non-temporal hint (round 5;
+// -DOBS_NO_NT_STORES: plain stores), so that a gigabyte of rows streaming through the L2 does not push out the lines the launch keeps
+// coming back to -- the shared static tables, the prediction items, the work lists' tails, the next step's state.  Same box: cfg3
+// 121.7 -> 132.3 M (k_obs 0.659 -> 0.609 ms, and k_step 18.8 -> 16.9 us: its state is still in the L2), cfg5 79.8 -> 82.0 M, cfg4
+// 128.6 -> 129.9 M, cfg2 111.6 -> 113.0 M.
+#ifndef OBS_NO_NT_STORES
+#define OBS_NT_STORES 1
+#endif
+typedef float obs_f4_t __attribute__((ext_vector_type(4)));
+typedef double obs_d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void out_store_f4(float *p, float a, float b, float c, float d) {
+#ifdef OBS_NT_STORES
+    const obs_f4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<obs_f4_t *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ void out_store_d2(double *p, double a, double b) {
+#ifdef OBS_NT_STORES
+    const obs_d2_t v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<obs_d2_t *>(p));
+#else
+    *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ void out_store(T *p, T v) {   // one element of an output tensor
+#ifdef OBS_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Time bucket of the per-key masks (64 bits a key): equal buckets of 1 << tshift steps and one catch-all for everything later.
 // (Round 4, measured and dropped: a piecewise map -- 2-step buckets to t = 64, 8-step to 192, 16-step to 448 -- instead of the
 // catch-all: 1 to 3 % slower on all four workloads, the longer bucket arithmetic of every classified cell costs more than the

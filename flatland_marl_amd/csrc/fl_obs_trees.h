@@ -51,10 +51,10 @@ __device__ __forceinline__ void scale_and_store(const double *f, float max_dist,
     v[9] = f[9] != -1 ? (float)f[9] / (float)n_agents : -1.0f;
     v[10] = f[10] != -1 ? (float)f[10] : -1.0f;
     v[11] = f[11] != -1 ? (float)f[11] / (float)n_agents : -1.0f;
-    float4 *d4 = reinterpret_cast<float4 *>(dst);  // rows are 48 B, 16-B aligned
-    d4[0] = make_float4(v[0], v[1], v[2], v[3]);
-    d4[1] = make_float4(v[4], v[5], v[6], v[7]);
-    d4[2] = make_float4(v[8], v[9], v[10], v[11]);
+    // rows are 48 B, 16-B aligned
+    out_store_f4(dst, v[0], v[1], v[2], v[3]);
+    out_store_f4(dst + 4, v[4], v[5], v[6], v[7]);
+    out_store_f4(dst + 8, v[8], v[9], v[10], v[11]);
 }
 
 __device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P,
                         if (n % TEAM == tl) {
                             const int row = w * 32 + __ffs((int)m) - 1;
 #pragma unroll
-                            for (int q = 0; q < 6; q++) o2[row * 6 + q] = ninf;
+                            for (int q = 0; q < 6; q++) out_store_d2(reinterpret_cast<double *>(o2 + row * 6 + q), -INFINITY, -INFINITY);
                         }
             }
             if (tl == 0) *mk = make_uint4(m0, m1, m2, 1u);
@@ -200,7 +200,7 @@ __device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P,
         root[10] = X.a_speed[i];
         double2 *row = reinterpret_cast<double2 *>(out);
 #pragma unroll
-        for (int q = 0; q < 6; q++) row[q] = make_double2(root[2 * q], root[2 * q + 1]);
+        for (int q = 0; q < 6; q++) out_store_d2(reinterpret_cast<double *>(row + q), root[2 * q], root[2 * q + 1]);
     }
     for (int k = tl; k < ns; k += TEAM) {
         if (nt_start((uint32_t)nt_r(scr, STRIDE, N_SE, k)) < 0) continue;
@@ -208,7 +208,7 @@ __device__ __forceinline__ void upstream_rows(const ObsCtx &X, const ObsArgs &P,
         node_row<false>(X, i, scr, STRIDE, k, f);
         double2 *row = reinterpret_cast<double2 *>(out + (size_t)nt_row((uint32_t)nt_r(scr, STRIDE, N_UF, k)) * 12);  // rows are 96 B, 16-B aligned
 #pragma unroll
-        for (int q = 0; q < 6; q++) row[q] = make_double2(f[2 * q], f[2 * q + 1]);
+        for (int q = 0; q < 6; q++) out_store_d2(reinterpret_cast<double *>(row + q), f[2 * q], f[2 * q + 1]);
     }
 }
 
@@ -347,7 +347,7 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
             int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
             if (idx < node_base) {
                 const uint32_t ph = (uint32_t)nt_r(scr, CAP, N_PH, idx);
-                adj[0] = (int)(ph & 0xFFu) - 2; adj[1] = idx; adj[2] = (int)((ph >> 8) & 3u) - 1;
+                out_store(&adj[0], (int32_t)((int)(ph & 0xFFu) - 2)); out_store(&adj[1], (int32_t)idx); out_store(&adj[2], (int32_t)((int)((ph >> 8) & 3u) - 1));
                 if (nt_start((uint32_t)nt_r(scr, CAP, N_SE, idx)) < 0) {
                     const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
                     scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
@@ -360,7 +360,7 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
             } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
                 const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
                 scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                adj[0] = adj[1] = adj[2] = -2;
+                out_store(&adj[0], (int32_t)-2); out_store(&adj[1], (int32_t)-2); out_store(&adj[2], (int32_t)-2);
             }
         }
     }
@@ -387,8 +387,8 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
         if (have) {
             int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
             if (gl < N) {
-                NO[gl] = gl < node_base ? h : -2;
-                if (gl >= 1) EO[gl - 1] = (gl >= node_base || parent < 0) ? -2 : hp;
+                out_store(&NO[gl], (int32_t)(gl < node_base ? h : -2));
+                if (gl >= 1) out_store(&EO[gl - 1], (int32_t)((gl >= node_base || parent < 0) ? -2 : hp));
             }
         }
     }
