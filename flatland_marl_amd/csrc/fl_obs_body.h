@@ -230,7 +230,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             double2 *o2 = reinterpret_cast<double2 *>(P.tree_out + (size_t)b * A * P.n_tree_nodes * 12);
             const int n2 = A * P.n_tree_nodes * 6;
             const double2 ninf = make_double2(-INFINITY, -INFINITY);
-            for (int k = tid; k < n2; k += nt) out_store_d2(reinterpret_cast<double *>(o2 + k), -INFINITY, -INFINITY);
+            for (int k = tid; k < n2; k += nt) fill_store_d2(reinterpret_cast<double *>(o2 + k), -INFINITY, -INFINITY);
             prefilled = true;
         }
         for (int i = tid; i < A; i += nt) { slot_agent[i] = -1; slot_ready[i] = 0; }
@@ -531,7 +531,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 const int k0 = (j - n_up_jobs - n_p1_jobs) * PF_CHUNK + lane;
 #pragma unroll
                 for (int q = 0; q < 16; q++)
-                    if (k0 + q * 64 < pf_n2) out_store_d2(reinterpret_cast<double *>(o2 + k0 + q * 64), -INFINITY, -INFINITY);
+                    if (k0 + q * 64 < pf_n2) fill_store_d2(reinterpret_cast<double *>(o2 + k0 + q * 64), -INFINITY, -INFINITY);
                 stored = true;
             }
         }

@@ -76,13 +76,23 @@ struct ObsCtx {
 // coming back to -- the shared static tables, the prediction items, the work lists' tails, the next step's state.  Same box: cfg3
 // 121.7 -> 132.3 M (k_obs 0.659 -> 0.609 ms, and k_step 18.8 -> 16.9 us: its state is still in the L2), cfg5 79.8 -> 82.0 M, cfg4
 // 128.6 -> 129.9 M, cfg2 111.6 -> 113.0 M.
-#ifndef OBS_NO_NT_STORES
-#define OBS_NT_STORES 1
+// OBS_NT_LEVEL: 0 plain stores; 1 the -inf pre-fill of the upstream slabs only (whole lines, lane after lane); 2 also the 16-byte
+// pieces of the rows (forest, tree); 3 also the 4-byte elements (attribute rows, adjacency, orders, masks, properties).
+#ifndef OBS_NT_LEVEL
+#define OBS_NT_LEVEL 3
 #endif
 typedef float obs_f4_t __attribute__((ext_vector_type(4)));
 typedef double obs_d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fill_store_d2(double *p, double a, double b) {   // the pre-fill: consecutive lanes, whole lines
+#if OBS_NT_LEVEL >= 1
+    const obs_d2_t v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<obs_d2_t *>(p));
+#else
+    *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+#endif
+}
 __device__ __forceinline__ void out_store_f4(float *p, float a, float b, float c, float d) {
-#ifdef OBS_NT_STORES
+#if OBS_NT_LEVEL >= 2
     const obs_f4_t v = {a, b, c, d};
     __builtin_nontemporal_store(v, reinterpret_cast<obs_f4_t *>(p));
 #else
@@ -90,7 +100,7 @@ __device__ __forceinline__ void out_store_f4(float *p, float a, float b, float c
 #endif
 }
 __device__ __forceinline__ void out_store_d2(double *p, double a, double b) {
-#ifdef OBS_NT_STORES
+#if OBS_NT_LEVEL >= 2
     const obs_d2_t v = {a, b};
     __builtin_nontemporal_store(v, reinterpret_cast<obs_d2_t *>(p));
 #else
@@ -100,7 +110,7 @@ __device__ __forceinline__ void out_store_d2(double *p, double a, double b) {
 
 template <typename T>
 __device__ __forceinline__ void out_store(T *p, T v) {   // one element of an output tensor
-#ifdef OBS_NT_STORES
+#if OBS_NT_LEVEL >= 3
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
