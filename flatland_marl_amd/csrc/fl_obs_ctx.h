@@ -74,12 +74,17 @@ struct ObsCtx {
 // The observation tensors are written once and never read back by the kernel: their stores carry the non-temporal hint (round 5;
 // -DOBS_NO_NT_STORES: plain stores), so that a gigabyte of rows streaming through the L2 does not push out the lines the launch keeps
 // coming back to -- the shared static tables, the prediction items, the work lists' tails, the next step's state.  Same box: cfg3
-// 121.7 -> 132.3 M (k_obs 0.659 -> 0.609 ms, and k_step 18.8 -> 16.9 us: its state is still in the L2), cfg5 79.8 -> 82.0 M, cfg4
-// 128.6 -> 129.9 M, cfg2 111.6 -> 113.0 M.
+// 120.0 -> 132.1 M (k_obs 0.671 -> 0.612 ms, and k_step 18.8 -> 16.9 us: its state is still in the L2), cfg5 79.0 -> 81.4 M, cfg4
+// 128.0 -> 129.4 M, cfg2 110.9 -> 112.2 M.
 // OBS_NT_LEVEL: 0 plain stores; 1 the -inf pre-fill of the upstream slabs only (whole lines, lane after lane); 2 also the 16-byte
 // pieces of the rows (forest, tree); 3 also the 4-byte elements (attribute rows, adjacency, orders, masks, properties).
+// Measured per level on one box (profiles/r05_nt_store_levels.txt; M agent-steps/s | WRITE_SIZE | FETCH_SIZE MB per launch):
+//   cfg3: 120.0 | 907 | 17.3 -> 127.8 | 904 | 15.8 -> 132.1 | 991 | 11.3 -> 132.1 | 1018 | 10.7;   cfg5: 79.0 | 1558 | 401 -> 79.4 -> 81.4 | 1642 | 358 -> 80.8 | 1673 | 346
+//   cfg4: 128.0 | 237 | 33.9 -> 129.1 -> 129.4 | 276 | 25.0 -> 129.6 | 287 | 22.2;                   cfg2: 110.9 | 23.8 -> 110.9 -> 112.2 | 27.3 -> 112.7 | 28.2
+// A non-temporal store of part of a line leaves the L2 on its own (counted as a 32-byte write) instead of waiting for the rest of the
+// line: level 2 is where the time is, level 3 buys 0.5 % at cfg2 for 3 - 4 % more bytes written -- level 2 is the default.
 #ifndef OBS_NT_LEVEL
-#define OBS_NT_LEVEL 3
+#define OBS_NT_LEVEL 2
 #endif
 typedef float obs_f4_t __attribute__((ext_vector_type(4)));
 typedef double obs_d2_t __attribute__((ext_vector_type(2)));
