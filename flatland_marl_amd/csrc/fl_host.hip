@@ -568,16 +568,8 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
         set_err("fl_step_obs: null output buffer");
         return FL_ERR_ARG;
     }
-    // ONE launch where a kernel for it exists (envs of launch class 1: fl_obs_g1.hip, the step at the head of the observation kernel's
-    // workgroup); else two launches back to back on the handle's stream.
-    if (tree_max_depth > 0 && tree_max_depth <= 3 && max_nodes <= 32) {
-        const FlStepArgs sa = {actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags};
-        bool step_done = false;
-        const int rc1 = fl_launch_step_obs(h->obs, h->d, sa, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
-                                           valid_actions_dev, props_dev, tree_max_depth, tree_pred_depth, tree_out_dev, h->stream, &step_done);
-        if (rc1 != FL_OK) { set_err("fl_step_obs: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc1; }
-        if (step_done) { HIPCHK(hipGetLastError()); return FL_OK; }
-    }
+    // Two launches back to back on the handle's stream.  A single fused launch was measured and is slower: the step wants
+    // one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
     fl_launch_step(h->d, actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags, h->stream);
     HIPCHK(hipGetLastError());
     if (tree_max_depth > 3 || (tree_max_depth > 0 && max_nodes > 32)) return fl_obs_cutils_tree(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
@@ -986,15 +978,6 @@ extern "C" int fl_debug_last_obs_class(fl_batch *h, int *out3) {
     if (!h || !out3) return FL_ERR_ARG;
     out3[0] = h->obs.last_fix; out3[1] = h->obs.last_split; out3[2] = h->obs.last_fit;
     return FL_OK;
-}
-
-// diagnostic (not part of the public header): 1 when fl_step_obs with these builder sizes is ONE launch on this batch (launch class 1 with
-// the step at the head of the workgroup, fl_obs_g1.hip), 0 when it is the step's launch followed by the observation launch
-extern "C" int fl_debug_step_obs_is_one_launch(fl_batch *h, int max_nodes, int pred_depth, int max_depth, int tree_pred) {
-    if (!h || !h->committed || max_nodes != 31 || max_depth < 1 || max_depth > 3 || getenv("FL_NO_STEP_FUSION")) return 0;
-    int out[11];
-    if (fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out, h->obs.n_cu > 0 && h->d.B >= OBS_WIDE_ENVS_PER_CU * h->obs.n_cu) != FL_OK) return 0;
-    return out[10] == 1 && !h->obs.keep_rows;
 }
 
 // diagnostic (not part of the public header), no GPU needed: the same for a batch of the given sizes -- agents, rail-cell and

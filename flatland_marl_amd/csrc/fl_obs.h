@@ -42,18 +42,6 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
 int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
-// RailEnv.step() INCLUDING the observations it returns as ONE launch (round 5), where a kernel for it exists: envs of fixed launch
-// class 1 (at most 32 agents / 256 rail cells, the solution's builder sizes, at most one env per CU) -- the step runs at the head of the
-// observation kernel's workgroup, in the LDS its node tables take later.  step: what fl_launch_step takes.  fl_launch_obs_both's `step`
-// argument: non-null = the caller has NOT launched the step; *step_done says whether this launch included it (else the caller launches
-// the step first and calls again with step = null).
-struct FlStepArgs {
-    const uint8_t *actions; uint32_t seed, stream_base; int synth_kind;
-    int32_t *rewards; uint8_t *dones, *done_all; int flags;
-};
-int fl_launch_step_obs(FlObsScratch &o, const FlDev &d, const FlStepArgs &step, int max_nodes, int pred_depth, float *attr, float *forest,
-                       int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                       int max_depth, int tree_pred, double *tree_out, hipStream_t s, bool *step_done);
 // more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
 FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s);
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11], int wide = 0);  // diagnostic (wide: several envs per CU)

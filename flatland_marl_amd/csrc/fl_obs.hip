@@ -385,24 +385,9 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     return fl_obs_launch_m0(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }
 
-static int obs_launch_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
-                           int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                           int max_depth, int tree_pred, double *tree_out, hipStream_t s, const FlStepArgs *step, bool *step_done);
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s) {
-    return obs_launch_both(o, d, max_nodes, pred_depth, attr, forest, adjacency, node_order, edge_order, valid, props, max_depth, tree_pred, tree_out, s, nullptr, nullptr);
-}
-int fl_launch_step_obs(FlObsScratch &o, const FlDev &d, const FlStepArgs &step, int max_nodes, int pred_depth, float *attr, float *forest,
-                       int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                       int max_depth, int tree_pred, double *tree_out, hipStream_t s, bool *step_done) {
-    return obs_launch_both(o, d, max_nodes, pred_depth, attr, forest, adjacency, node_order, edge_order, valid, props, max_depth, tree_pred, tree_out, s, &step, step_done);
-}
-// step != null: the caller has not launched the step.  A launch class with the step at its head (class 1) takes it along (*step_done =
-// true); any other configuration launches NOTHING and reports *step_done = false -- the caller launches the step and calls again.
-static int obs_launch_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
-                           int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                           int max_depth, int tree_pred, double *tree_out, hipStream_t s, const FlStepArgs *step, bool *step_done) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > OBS_CAP_C) return FL_ERR_ARG;   // (the fused kernels: 32-lane teams)
     if (max_depth > 3 || tree_pred > pred_depth || tree_pred < 0) return FL_ERR_ARG;  // the upstream path must be a prefix
     ObsArgs P = {};
@@ -413,11 +398,6 @@ static int obs_launch_both(FlObsScratch &o, const FlDev &d, int max_nodes, int p
     P.wide = o.n_cu > 0 && d.B >= OBS_WIDE_ENVS_PER_CU * o.n_cu;
     P.keep_mode = o.keep_rows;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    static const bool no_step_fusion = getenv("FL_NO_STEP_FUSION") != nullptr;   // diagnostic: the step always as a launch of its own
-    if (step) {
-        *step_done = P.fix == 1 && !no_step_fusion;
-        if (!*step_done) return FL_OK;     // (nothing launched, nothing recorded: the caller launches the step and comes back)
-    }
     // FL_OBS_KEEP_TREE_ROWS: the row masks of the previous launch describe this very buffer at this depth -> no pre-fill of the slab
     P.keep_rows = o.keep_rows && o.rows_out == tree_out && o.rows_depth == max_depth;
     o.rows_out = tree_out; o.rows_depth = max_depth;
@@ -438,7 +418,6 @@ static int obs_launch_both(FlObsScratch &o, const FlDev &d, int max_nodes, int p
         default: return FL_ERR_ARG;
         }
     }
-    if (step) return fl_obs_launch_g1(d, u, P, *step, s);   // class 1 with the step at its head
     switch (P.fix) {   // a fixed launch class: its own kernel (MODE and VAR are the class's)
     case 1: return fl_obs_launch_f1(d, u, P, s);
     case 2: return fl_obs_launch_f2(d, u, P, s);

@@ -311,9 +311,6 @@ int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hi
 int fl_obs_launch_f3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f5(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
-// class 1 with RailEnv.step() at the head of the workgroup (fl_obs_g1.hip)
-struct FlStepArgs;
-int fl_obs_launch_g1(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, const FlStepArgs &step, hipStream_t s);
 // the same classes for a batch with larger maps among its envs (P.split): per env the class's body or the runtime-carving one
 int fl_obs_launch_s2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

@@ -463,15 +463,6 @@ class BatchedRailEnv:
         _chk(lib().fl_positions_map(self.h, b, _p(out)))
         return out
 
-    def step_obs_is_one_launch(self, tree_depth=2, tree_pred=30):
-        """diagnostic: step_obs() with these builder sizes is ONE kernel launch on this batch (envs of launch class 1: the step runs at
-        the head of the observation kernel's workgroup) rather than the step's launch followed by the observation launch"""
-        L = lib()
-        if not hasattr(L, "fl_debug_step_obs_is_one_launch"):
-            return False
-        L.fl_debug_step_obs_is_one_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-        return bool(L.fl_debug_step_obs_is_one_launch(self.h, self.max_nodes, self.pred_depth, int(tree_depth), int(tree_pred)))
-
     def last_obs_class(self):
         """diagnostic: (fixed launch class, split, envs on the class's body) of the last obs_both / step_obs launch -- class 0 = the
         runtime-carving kernel; split 1 = the class served only the envs that fit it, the others ran the runtime-carving body"""

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha only; nothing touches the GPU at import)
 
 NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_obs<3": "k_obs<cutils+tree>", "k_obs<4": "k_obs<cutils+tree>",
-         "k_obs<5": "k_obs<cutils+tree>", "k_obs_split<": "k_obs<cutils+tree>", "k_obs_step<": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
+         "k_obs<5": "k_obs<cutils+tree>", "k_obs_split<": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
          "k_distance_map": "k_distance_map", "k_hop8": "k_hop8", "k_nexthop": "k_nexthop", "k_segments": "k_segments"}
 tag = sys.argv[1]
 specs = sys.argv[2:] or ["cfg2:2", "cfg3:3", "cfg4:2", "cfg5:3:rebuild"]
