@@ -18,7 +18,7 @@ int fl_obs_alloc(FlObsScratch &o, const FlDev &d, hipStream_t s, std::vector<voi
     void *p = nullptr;
     if (hipMalloc(&p, BA * o.pred_cap * 2) != hipSuccess) return FL_ERR_HIP;
     o.path = (uint16_t *)p; allocs.push_back(p);
-    if (hipMalloc(&p, (size_t)d.B * o.items_cap * 4) != hipSuccess) return FL_ERR_HIP;
+    if (hipMalloc(&p, (size_t)d.B * o.items_cap * 4 + 64) != hipSuccess) return FL_ERR_HIP;   // (+ 64: conflict_flags reads up to seven words behind a list)
     o.cell_items = (uint32_t *)p; allocs.push_back(p);
     if (hipMalloc(&p, (size_t)d.B * 64 * 8) != hipSuccess) return FL_ERR_HIP;
     o.dbg = (long long *)p; allocs.push_back(p);

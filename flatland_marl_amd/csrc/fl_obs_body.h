@@ -282,7 +282,6 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     X.Tn = my_pred_depth >= 0 ? my_pred_depth + 1 : 0;
     // without the masks nearly every cell on somebody's route would be a conflict candidate: those are handled in place
     X.tmask = (p_use_tmask && X.Tn > 0) ? tmask : nullptr;
-    X.wl_hbm = WL_HBM;
     X.wl_occ = WL_HBM ? S.wl + (size_t)b * OBS_WL_HBM_ENTRIES : reinterpret_cast<uint2 *>(wl_lds);
     X.wl_occ_cap = X.tmask ? wl_entries / p_wl_occ_div : wl_entries;  // a share of the entries
     X.wl_cf = X.wl_occ + X.wl_occ_cap; X.wl_cf_cap = wl_entries - X.wl_occ_cap;

@@ -42,7 +42,6 @@ struct ObsCtx {
     // pass B work lists (LDS): cells with an occupant / cells whose key has a prediction near the queried time
     uint2 *wl_occ, *wl_cf;
     int wl_occ_cap, wl_cf_cap;
-    bool wl_hbm;                  // the lists live in HBM scratch: their flag words are merged with L2 atomics, read them past the L1
     // LDS HEAD of HBM work lists (round 5): entries [0, wl_head_*_n) of a list live in LDS, the others in HBM scratch at the same
     // index -- the entries a round pushes first never leave the CU (cfg4: the 16 KB an LDS copy of the items held without use)
     uint2 *wl_head_occ, *wl_head_cf;
@@ -182,13 +181,15 @@ __device__ __forceinline__ ListRange list_range(const ObsCtx &X, bool cu, int r,
     } else if (X.bk_rel) {
         // bucket-major items: the key's items of the one or two time buckets the three queried times fall in -- two pieces
         const int b1 = min(max(pt - 1, 0) >> X.bk_shift, X.bk_nb - 1), b2 = min(min(pt + 1, X.Tn - 1) >> X.bk_shift, X.bk_nb - 1);
-        const uint16_t *r1 = X.bk_rel + b1 * X.bk_k1 + key;
-        const int s1 = (int)r1[0], e1 = (int)r1[1];
+        // (start, end) of a key are neighbouring 16-bit words: ONE 2-byte-aligned dword load each (HBM scratch; see conflict_flags)
+        struct __attribute__((packed, aligned(2))) Pair16 { uint32_t v; };
+        const uint32_t w1 = reinterpret_cast<const Pair16 *>(X.bk_rel + b1 * X.bk_k1 + key)->v;
+        const int s1 = (int)(w1 & 0xFFFFu), e1 = (int)(w1 >> 16);
         R.lo = X.bk_base[b1] + s1;
         R.n1 = R.n = e1 - s1;
         if (b2 != b1) {
-            const uint16_t *r2 = X.bk_rel + b2 * X.bk_k1 + key;
-            const int s2 = (int)r2[0], e2 = (int)r2[1];
+            const uint32_t w2 = reinterpret_cast<const Pair16 *>(X.bk_rel + b2 * X.bk_k1 + key)->v;
+            const int s2 = (int)(w2 & 0xFFFFu), e2 = (int)(w2 >> 16);
             R.lo2 = X.bk_base[b2] + s2;
             R.n += e2 - s2;
         }

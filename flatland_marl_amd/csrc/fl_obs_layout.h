@@ -16,6 +16,9 @@
 #ifndef CF_CHUNK_HBM
 #define CF_CHUNK_HBM 8
 #endif
+#ifndef CF_FIRST_HBM
+#define CF_FIRST_HBM 8              // items the lane of a conflict entry scans itself before the list is split in chunks (HBM items; 16: cfg4 -2.5 %, 24: -5 %)
+#endif
 #ifndef OBS_GLB_BATCH
 #define OBS_GLB_BATCH 8              // items per round trip when the prediction items live in HBM scratch
 #endif
@@ -25,7 +28,6 @@
 #ifndef OBS_TSHIFT
 #define OBS_TSHIFT 1                 // time-bucket width of the per-key masks for long horizons: 1 << OBS_TSHIFT steps
 #endif
-#define CF_MORE 0x800000u            // work-list entry of a further chunk (see wg_pass_b)
 #ifndef CF_DIRECT
 #define CF_DIRECT 32                 // when no list of the env is longer, every conflict entry is scanned by its lane alone, in one pass
 #endif

@@ -79,10 +79,34 @@ __device__ __forceinline__ uint32_t conflict_flags(const ObsCtx &X, bool CUTILS,
     // masks) are fetched in bigger batches: their round trips are what the scan costs
     // (one call site for the two LDS copies: the lanes of a wavefront work on entries of both builders, two sites would run
     // one after the other)
+    // Items in HBM scratch: the eight items of a chunk are consecutive words of the index (a list in two pieces: unless the chunk
+    // straddles them), so a lane fetches them with TWO 16-byte loads (4-byte aligned: global_load_dwordx4 takes that) instead of
+    // eight gathers -- every lane of a wavefront is in another list, i.e. another cache line, and the texture addresser takes a
+    // gather of 64 lines at one line a cycle whatever its width.  (Words behind the end of a list are read and masked: the
+    // scratch is padded, fl_obs.hip.)
+    auto scan_glb = [&](const uint32_t *items) __attribute__((always_inline)) {
+        typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+        for (int e0 = v0; e0 < v1; e0 += 8) {
+            uint32_t itv[8];
+            const int p0 = list_index<TWO>(R, e0);
+            if (!TWO || e0 >= R.n1 || R.n1 - e0 >= min(8, v1 - e0)) {
+                const u4a a = *reinterpret_cast<const u4a *>(items + p0), c = *reinterpret_cast<const u4a *>(items + p0 + 4);
+                itv[0] = a.x; itv[1] = a.y; itv[2] = a.z; itv[3] = a.w; itv[4] = c.x; itv[5] = c.y; itv[6] = c.z; itv[7] = c.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) itv[q] = items[list_index<TWO>(R, min(e0 + q, v1 - 1))];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t tl = IT_TLO(itv[q]), th = IT_THI(itv[q], tlast);
+                if (e0 + q < v1 && th >= t1 && tl <= t2) test_item(itv[q]);
+            }
+        }
+    };
+    static_assert(CF_CHUNK_HBM == 8 && OBS_GLB_BATCH == 8, "scan_glb fetches eight items a round trip");
     if (ITL) scan(second ? X.u_items : X.items_lds, std::integral_constant<int, 8>());
     else if (second) scan(X.u_items, std::integral_constant<int, 8>());      // (the second index is always LDS-resident)
-    else if (X.tmask) scan(X.items_glb, std::integral_constant<int, CF_CHUNK_HBM>());  // chunked work-list entries: the whole chunk in flight at once
-    else scan(X.items_glb, std::integral_constant<int, OBS_GLB_BATCH>());
+    else scan_glb(X.items_glb);  // chunked work-list entries: the whole chunk in flight at once
     return flags;
 }
 // the other-agent test takes the first time (pt, pt - 1, pt + 1) at which somebody else is predicted on the cell
@@ -102,12 +126,15 @@ __device__ __forceinline__ void wl_occ_put(const ObsCtx &X, int i, uint2 e) { if
 __device__ __forceinline__ uint2 wl_cf_get(const ObsCtx &X, int i) { return i < X.wl_head_cf_n ? X.wl_head_cf[i] : X.wl_cf[i]; }
 __device__ __forceinline__ void wl_cf_put(const ObsCtx &X, int i, uint2 e) { if (i < X.wl_head_cf_n) X.wl_head_cf[i] = e; else X.wl_cf[i] = e; }
 __device__ __forceinline__ void wl_cf_set_y(const ObsCtx &X, int i, uint32_t y) { if (i < X.wl_head_cf_n) X.wl_head_cf[i].y = y; else X.wl_cf[i].y = y; }
-__device__ __forceinline__ void wl_cf_or_y(const ObsCtx &X, int i, uint32_t bits) { if (i < X.wl_head_cf_n) atomicOr(&X.wl_head_cf[i].y, bits); else atomicOr(&X.wl_cf[i].y, bits); }
-// flag word of a conflict work-list entry (other lanes OR their bits into it): HBM lists merge them with L2 atomics, read them past the L1
-__device__ __forceinline__ uint32_t wl_cf_flags(const ObsCtx &X, int i) {
-    if (i < X.wl_head_cf_n) return X.wl_head_cf[i].y;
-    if (X.wl_hbm) return __hip_atomic_load(&X.wl_cf[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return X.wl_cf[i].y;
+// a further chunk of entry i's key is scanned: OR its flag bits into the entry's word and count the chunk down (bits 9 .. 14); returns
+// the word as it was before the count-down (the OR and the count-down go to one address in program order)
+__device__ __forceinline__ uint32_t wl_cf_done(const ObsCtx &X, int i, uint32_t bits) {
+    if (i < X.wl_head_cf_n) {
+        if (bits) atomicOr(&X.wl_head_cf[i].y, bits);
+        return atomicSub(&X.wl_head_cf[i].y, 1u << 9);
+    }
+    if (bits) atomicOr(&X.wl_cf[i].y, bits);
+    return atomicSub(&X.wl_cf[i].y, 1u << 9);
 }
 
 // append e to the conflict work list; one LDS atomic per wavefront.  false = the list is full and the caller handles the event itself
@@ -151,6 +178,12 @@ __device__ __forceinline__ void wl_reserve2_finish(unsigned long long old, unsig
     if ((k2) >= 0) atomicMax((unsigned long long *)&(X).dbg[(X).dbg_base + ((k2) < 0 ? 0 : (k2))], (unsigned long long)((1ll << 40) - now_)); } } while (0)
 #else
 #define WAVE_MARK(X, k, k2) do {} while (0)
+#endif
+#ifdef FL_OBS_TIMING
+// sums over the wavefronts (and rounds of trees) of the time since the start of the work-list step, slot 51 + k (k = 5: slot 48) of the env
+#define WL_ACC(X, k) do { if ((X).dbg && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&(X).dbg[(k) == 5 ? 48 : 51 + (k)], (unsigned long long)((long long)wall_clock64() - wl_t0_)); } while (0)
+#else
+#define WL_ACC(X, k) do {} while (0)
 #endif
 #ifdef FL_OBS_TIMING
 // accumulates the time since the previous stamp of this stage in slot k (summed over the rounds of trees)
@@ -471,6 +504,9 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     __syncthreads();
     TREE_STAMP(X, 11);
     WAVE_MARK(X, 18, -1);
+#ifdef FL_OBS_TIMING
+    const long long wl_t0_ = (long long)wall_clock64();
+#endif
     // step 2: one list entry per lane
     const int n_occ = min(X.wl_cnt[0], X.wl_occ_cap), n_cf = min(X.wl_cnt[1], X.wl_cf_cap);
 #ifdef FL_OBS_TIMING
@@ -484,6 +520,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         occ_event(X, pb_cu<PB>(X, team), sc, cap, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
     WAVE_MARK(X, 12, -1);
+    WL_ACC(X, 0);
     if (*X.long_lists == 0) {  // every list is short: one pass, every lane scans the list of its entry
         for (int e = tid; e < n_cf; e += nt) {
             const uint2 w = wl_cf_get(X, e);
@@ -511,35 +548,44 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             }
         }
         WAVE_MARK(X, 13, 17);
+        WL_ACC(X, 1);
         late();
+        WL_ACC(X, 2);
         __syncthreads();
+        WL_ACC(X, 5);
         return;
     }
     constexpr int CF_CHUNK = ITL ? CF_CHUNK_LDS : CF_CHUNK_HBM;
+    // ... and the lane of the first entry takes CF_FIRST items itself (more than one chunk's worth measured slower: the wavefront waits
+    // for its longest scan)
+    constexpr int CF_FIRST = ITL ? CF_CHUNK_LDS : CF_FIRST_HBM;
     // One entry per CF_CHUNK items of a key's list, so that no lane scans a long list alone.  Every lane scans the FIRST chunk of
     // its entry right away (with lists grouped by time bucket that is the whole list of most queries: no second look at the entry,
     // its offsets and its flag word -- which are HBM round trips on large maps); a longer list pushes an entry per further chunk,
     // and those are scanned after a barrier, one per lane on densely packed wavefronts.
-    // First entry: tot | chunks << 9 | flags << 15 (OR-ed together below) | node << 24; the others: chunk | index of the
-    // first entry << 6 (17 bits) | CF_MORE.
-    bool any_multi = false;
+    // First entry: tot | further chunks still to come << 9 | flags so far << 15 | node << 24; the others: chunk | index of the first
+    // entry << 6 (17 bits) | tot << 23.  Whoever scans a further chunk ORs its flags into the first entry's word and counts it down
+    // with ONE returning atomic each (same address, program order); the lane that takes the count to zero has all the flags in the
+    // value it got back and files the result -- no pass over all entries afterwards (round 5: that pass and its barrier were 8.7 us
+    // of cfg3's 54 us work-list step and 90 of cfg5's 390).
     for (int e0 = 0; e0 < n_cf; e0 += nt) {
         const int e = e0 + tid;
-        int nch = 0, cell = 0, handle = 0, tot = 0, pt = 0;
+        int nch = 0, cell = 0, handle = 0, tot = 0, pt = 0, team = 0, np = 0;
         ListRange R = {0, 0, 0, 0};
         bool cu = PB == 1;
         uint2 w = make_uint2(0u, 0u);
+        uint32_t fl = 0;
         if (e < n_cf) {
             w = wl_cf_get(X, e);
             cell = (int)((w.x & 0xFFFFFFu) >> 2);
-            const int team = (int)(w.x >> 24);
+            team = (int)(w.x >> 24);
             handle = pb_handle<PB>(X, team_meta, team);
             tot = (int)(w.y & 511u);
             cu = pb_cu<PB>(X, team);
             pt = pt_of<PB>(X, cu, handle, tot);
             R = list_range<PB>(X, cu, cell, pt);
-            nch = max(min((R.n + CF_CHUNK - 1) / CF_CHUNK, 63), 1);  // an absurdly long list: the last chunk takes the rest
-            const uint32_t f = R.n > 0 ? conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, nch == 1 ? R.n : CF_CHUNK) : 0u;
+            nch = 1 + min(max(R.n - CF_FIRST + CF_CHUNK - 1, 0) / CF_CHUNK, 62);  // an absurdly long list: the last chunk takes the rest
+            const uint32_t f = R.n > 0 ? conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, min(R.n, CF_FIRST)) : 0u;
 #ifdef FL_OBS_COUNTS  // with FL_OBS_TIMING: statistics of the conflict entries (they slow the step down; first chunks only)
             if (X.dbg) {
                 atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 27], (unsigned long long)R.n);
@@ -549,58 +595,53 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 if (!(f & 7u) && (f & 64u)) atomicAdd((unsigned long long *)&X.dbg[X.dbg_base + 31], 1ull);
             }
 #endif
-            if (nch == 1) {
-                if (conflict_hit(f)) {
+            fl = f & 63u;
+        }
+        for (int j = 1; __any(j < nch); j++) {
+            const bool want = j < nch;
+            if (!wl_push_cf(X, want, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | ((uint32_t)tot << 23)))) {
+                // list full: this chunk is scanned here
+                fl |= conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, CF_FIRST + (j - 1) * CF_CHUNK, j == 62 ? R.n : min(R.n, CF_FIRST + j * CF_CHUNK)) & 63u;
+            } else if (want) np++;
+        }
+        if (e < n_cf) {
+            if (np == 0) {  // nothing left to others
+                if (conflict_hit(fl)) {
                     constexpr int cap = PB == 2 ? 32 : CAP;
                     int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                     atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
                 }
             } else {
-                wl_cf_set_y(X, e, w.y | ((uint32_t)nch << 9) | ((f & 63u) << 15));
-                any_multi = true;
-            }
-        }
-        for (int j = 1; __any(j < nch); j++) {
-            if (!wl_push_cf(X, j < nch, make_uint2(w.x, (uint32_t)j | ((uint32_t)e << 6) | CF_MORE))) {
-                // list full: this chunk is scanned here
-                const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, j * CF_CHUNK, j == 62 ? R.n : min(R.n, (j + 1) * CF_CHUNK));
-                if (f & 63u) wl_cf_or_y(X, e, (f & 63u) << 15);
+                wl_cf_set_y(X, e, w.y | ((uint32_t)np << 9) | (fl << 15));
             }
         }
     }
-    if (__any(any_multi) && lane == 0) X.wl_cnt[2] = 1;
     WAVE_MARK(X, 13, 17);
+    WL_ACC(X, 1);
     late();
+    WL_ACC(X, 2);
     __syncthreads();
     WAVE_MARK(X, 14, -1);
-    if (X.wl_cnt[2] == 0) return;   // (workgroup-uniform) every list fitted one chunk
-    const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);
+    WL_ACC(X, 3);
+    const int n_cf2 = min(X.wl_cnt[1], X.wl_cf_cap);   // (workgroup-uniform)
     for (int e = n_cf + tid; e < n_cf2; e += nt) {  // the further chunks
         const uint2 w = wl_cf_get(X, e);
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u);
-        const uint32_t fy = wl_cf_flags(X, first);
-        const int tot = (int)(fy & 511u);
+        const int first = (int)((w.y >> 6) & 0x1FFFFu), chunk = (int)(w.y & 63u), tot = (int)(w.y >> 23);
         const int handle = pb_handle<PB>(X, team_meta, team);
         const bool cu = pb_cu<PB>(X, team);
         const int pt = pt_of<PB>(X, cu, handle, tot);
         const ListRange R = list_range<PB>(X, cu, cell, pt);
-        const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, chunk * CF_CHUNK, chunk == 62 ? R.n : min(R.n, (chunk + 1) * CF_CHUNK));
-        if (f & 63u) wl_cf_or_y(X, first, (f & 63u) << 15);
-    }
-    __syncthreads();
-    {  // keys with more than one chunk: the first entry has collected all flags
-        for (int e = tid; e < n_cf; e += nt) {
-            uint2 w = wl_cf_get(X, e);
-            w.y = wl_cf_flags(X, e);
-            if (((w.y >> 9) & 63u) <= 1u) continue;
-            if (conflict_hit((w.y >> 15) & 63u)) {
-                constexpr int cap = PB == 2 ? 32 : CAP;
-                int *sc = team_table<PB, CAP>(X, scr0, team_words, (int)(w.x >> 24));
-                atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), (int)(w.y & 511u));
-            }
+        const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, CF_FIRST + (chunk - 1) * CF_CHUNK, chunk == 62 ? R.n : min(R.n, CF_FIRST + chunk * CF_CHUNK));
+        const uint32_t old = wl_cf_done(X, first, (f & 63u) << 15);
+        if (((old >> 9) & 63u) == 1u && conflict_hit((old >> 15) & 63u)) {  // the last chunk of its key
+            constexpr int cap = PB == 2 ? 32 : CAP;
+            int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
+            atomicMin(&nt_w(sc, cap, N_PC, (int)(old >> 24)), (int)(old & 511u));
         }
-        __syncthreads();
     }
+    WL_ACC(X, 4);
+    WL_ACC(X, 5);
+    __syncthreads();
 }
 

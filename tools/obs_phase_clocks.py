@@ -105,6 +105,10 @@ def report():
     if (env.A <= 31 and c[:, :, 50].max() == 0) or os.environ.get("WL_MARKS"):  # marks of the LAST round of trees (of the last stage) only
         print("work-list step, since its start: occupants done %.1f, conflict scan done: earliest wavefront %.1f, latest %.1f" %
               (rel(12, 18), rel_min(17, 18), rel(13, 18)))
+    if c[:, :, 51].max() > 0:   # mean wavefront, summed over the rounds of trees (and both stages)
+        nw = float(os.environ.get("NWAVES", "16"))
+        print("work-list step (mean wavefront, sum over rounds): occupants %.1f, first chunks of the conflict entries %.1f, late jobs %.1f, barrier %.1f, further chunks %.1f, end %.1f" %
+              tuple((c[:, :, 48 if k == 5 else 51 + k] / 100.0 / nw).mean() for k in range(6)))
     if c[:, :, 27].max() > 0:  # a -DFL_OBS_COUNTS build
       print("conflict entries (cutils | upstream): items in their lists %.0f | %.0f, queried beyond the fine buckets %.0f | %.0f, somebody else there %.0f | %.0f, conflicts %.0f | %.0f, only the walking agent itself there %.0f | %.0f" %
             (c[:, :, 27].mean(), c[:, :, 59].mean(), c[:, :, 28].mean(), c[:, :, 60].mean(), c[:, :, 29].mean(), c[:, :, 61].mean(), c[:, :, 30].mean(), c[:, :, 62].mean(), c[:, :, 31].mean(), c[:, :, 63].mean()))
