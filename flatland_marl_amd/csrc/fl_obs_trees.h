@@ -33,13 +33,10 @@ __device__ __forceinline__ void node_row(const ObsCtx &X, int handle, const int 
     f[11] = (double)(rm & 0xFFFFu);
 }
 
-// children of a node (treeobs.cpp:583-608 / observations.py:464-489): child k (k = 0 left, 1 forward, 2 right, 3 back)
-// -> start state or -1 (null cell); tabulated with the segment (fl_dmap.hip k_segments)
-__device__ __forceinline__ int child_state(const NodeDesc &nd, int k) {
-    if (!(nd.flags & (ND_SWITCH | ND_DEAD_END))) return -1;
-    const uint32_t c = ((k < 2 ? nd.kids01 : nd.kids23) >> (16 * (k & 1))) & 0xFFFFu;
-    return c == FL_R_NONE ? -1 : c == FL_R_PHANTOM ? -2 : (int)c;
-}
+// children of a node (treeobs.cpp:583-608 / observations.py:464-489): child k (k = 0 left, 1 forward, 2 right, 3 back) of a walk
+// that ends at a switch or a dead end starts at the state the segment table has for it (fl_dmap.hip k_segments: kids01 / kids23,
+// u16 each; FL_R_NONE = null cell, FL_R_PHANTOM = a cell without rail, see there); any other walk has no children.  Pass A hands
+// the packed words to the children's lanes, which decode their own.
 
 // scale_node (treeobs.cpp:111-152), float32 arithmetic
 __device__ __forceinline__ void scale_and_store(const double *f, float max_dist, int n_agents, float *dst) {
@@ -57,10 +54,6 @@ __device__ __forceinline__ void scale_and_store(const double *f, float max_dist,
     out_store_f4(dst + 8, v[8], v[9], v[10], v[11]);
 }
 
-__device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
-    for (int i = 0; i < k; i++) m &= m - 1;
-    return __ffsll((long long)m) - 1;
-}
 
 // ---- upstream dense tree (observations.py:196-254, 464-494).  Output: DFS pre-order rows (node, L, F, R, B); a row that is
 // not a real node is -inf.  The env's whole slab is pre-filled with -inf in phase 0 (obs_body), the builder writes the real rows.
@@ -104,37 +97,38 @@ __device__ __forceinline__ void upstream_pass_a(const ObsCtx &X, const ObsArgs &
     const int tgt_r = X.a_target[ia];
     int width = FAN;
     for (int level = 1; level <= D; level++) {
-        int ch[4] = {-1, -1, -1, -1};
-        int ch_tot = 0;
+        // what a node hands to its children: their start states as the segment table has them (u16 each, FL_R_NONE = null cell), the
+        // tot_dist they start at and its own DFS row -- three words
+        uint32_t k01 = 0xFFFFFFFFu, k23 = 0xFFFFFFFFu, ch_tot = 0;
         if (have && tl < width && c_index >= 0 && c_state != -1) {
             const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
             nt_store_desc(scr, STRIDE, COMPACT ? width - 2 + tl : c_index, nd, c_index, err);
-            ch_tot = nd.tot0 + nd.nvis;
-#pragma unroll
-            for (int k = 0; k < 4; k++) ch[k] = child_state(nd, k);
+            ch_tot = (uint32_t)(nd.tot0 + nd.nvis);
+            if (nd.flags & (ND_SWITCH | ND_DEAD_END)) { k01 = nd.kids01; k23 = nd.kids23; }
         } else if (tl < width) {
             c_index = -1;  // missing node: its whole subtree stays -inf
         }
         if (level == D) break;
         // children of lane p go to lanes FAN * p .. FAN * p + FAN - 1 of the next level (all lanes take part in the shuffles)
         const int src = tl / FAN, which = tl % FAN;
-        const int p_index = __shfl(c_index, src, TEAM);
-        const int s0 = __shfl(ch[0], src, TEAM), s1 = __shfl(ch[1], src, TEAM), s2 = __shfl(ch[2], src, TEAM), s3 = __shfl(ch[3], src, TEAM);
-        const int s_tot = __shfl(ch_tot, src, TEAM);
+        const uint32_t s01 = (uint32_t)__shfl((int)k01, src, TEAM), s23 = (uint32_t)__shfl((int)k23, src, TEAM);
+        const uint32_t s_ti = (uint32_t)__shfl((int)((ch_tot & 0xFFFFu) | ((uint32_t)(c_index + 1) << 16)), src, TEAM);
+        const int p_index = (int)(s_ti >> 16) - 1, s_tot = (int)(s_ti & 0xFFFFu);
         width *= FAN;
         c_index = -1;
         c_state = -1;
         if (tl < width && p_index >= 0) {
-            int kk = which, st = which == 0 ? s0 : which == 1 ? s1 : which == 2 ? s2 : s3;
+            int kk = which;
             if (COMPACT) {  // the which-th child that exists
-                const uint32_t m4 = (uint32_t)(s0 != -1) | ((uint32_t)(s1 != -1) << 1) | ((uint32_t)(s2 != -1) << 2) | ((uint32_t)(s3 != -1) << 3);
+                const uint32_t m4 = (uint32_t)((s01 & 0xFFFFu) != FL_R_NONE) | ((uint32_t)((s01 >> 16) != FL_R_NONE) << 1) |
+                                    ((uint32_t)((s23 & 0xFFFFu) != FL_R_NONE) << 2) | ((uint32_t)((s23 >> 16) != FL_R_NONE) << 3);
                 if (which == 0 && __popc(m4) > 2 && err) atomicCAS(err, 0, FL_ERR_CAPACITY);
                 const uint32_t m = which == 1 ? (m4 & (m4 - 1)) : m4;
                 kk = m ? __ffs((int)m) - 1 : -1;
-                st = kk == 0 ? s0 : kk == 1 ? s1 : kk == 2 ? s2 : kk == 3 ? s3 : -1;
             }
             if (kk >= 0) {
-                c_state = st;
+                const uint32_t c = ((kk < 2 ? s01 : s23) >> (16 * (kk & 1))) & 0xFFFFu;
+                c_state = c == FL_R_NONE ? -1 : c == FL_R_PHANTOM ? -2 : (int)c;
                 c_tot = s_tot;
                 c_index = p_index + 1 + kk * sz[level + 1];
             }
@@ -283,34 +277,53 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         const int m = active ? min(n_cur, N - node_base) : 0;
         const bool mine = gl < m;
         const int idx_node = node_base + gl;
-        int ch0 = -1, ch1 = -1, ch2 = -1, ch_tot = 0;
+        // what an explored node hands to its three children: their start states as the segment table has them (u16 each, FL_R_NONE =
+        // null cell) and the tot_dist they start at -- two words
+        uint32_t k01 = 0xFFFFFFFFu, k2t = 0xFFFFu;
         bool explored = false;
         if (mine && c_state != -1) {
             const NodeDesc nd = node_topology(X, dm_t, tgt_r, c_state, c_tot);
             explored = true;
-            ch_tot = nd.tot0 + nd.nvis;  // children start one step beyond the end of this walk
-            ch0 = child_state(nd, 0); ch1 = child_state(nd, 1); ch2 = child_state(nd, 2);
+            const bool kids = (nd.flags & (ND_SWITCH | ND_DEAD_END)) != 0;
+            k01 = kids ? nd.kids01 : 0xFFFFFFFFu;
+            k2t = (kids ? (nd.kids23 & 0xFFFFu) : 0xFFFFu) | ((uint32_t)(nd.tot0 + nd.nvis) << 16);  // children start one step beyond the end of this walk
             nt_store_desc(scr, CAP, idx_node, nd, 0, &d.err[b]);
         }
-        const unsigned long long exp_mask = TC == 64 ? __ballot(explored) : ((__ballot(explored) >> (grp * 32)) & 0xFFFFFFFFull);
-        const int n_next = 3 * __popcll(exp_mask);
+        // explored lanes of the team, and how many of them below this lane (teams of 32: the mask is the team's half of the ballot)
+        int n_next, my_rank;
+        if (TC == 64) {
+            const unsigned long long em = __ballot(explored);
+            n_next = 3 * __popcll(em);
+            my_rank = __popcll(em & ((1ull << gl) - 1ull));
+        } else {
+            const unsigned long long bal = __ballot(explored);
+            const uint32_t em = grp ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            n_next = 3 * __popc(em);
+            my_rank = __popc(em & ((1u << gl) - 1u));
+        }
         if (mine) {  // first child's node index (children are numbered consecutively) << 2 | action + 1
-            const int fc = explored ? node_base + m + 3 * __popcll(exp_mask & ((1ull << gl) - 1ull)) : 0;
+            const int fc = explored ? node_base + m + 3 * my_rank : 0;
             nt_w(scr, CAP, N_PH, idx_node) = (c_parent + 2) | (((fc << 2) | (c_act + 1)) << 8);
         }
-        // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane
+        // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane.  Which lane that is:
+        // every explored lane PUSHES its number to the lane of its rank (ds_permute; the others push to the team's last lane, whose
+        // rank no explored lane has: at most TC - 1 nodes are explored), lane j reads it from lane j / 3 -- two cross-lane moves
+        // instead of a loop over the set bits of the mask (pass A is bound by instruction issue: a few nodes a level on 32 lanes).
         const int src_rank = gl / 3, which = gl - 3 * src_rank;
-        const int src = (gl < n_next) ? kth_set_bit((uint64_t)exp_mask, src_rank) : 0;
-        const int s_c0 = __shfl(ch0, src, TC), s_c1 = __shfl(ch1, src, TC), s_c2 = __shfl(ch2, src, TC);
-        const int s_tot = __shfl(ch_tot, src, TC);
+        const int tbase = (int)__lane_id() - gl;
+        const int pushed = __builtin_amdgcn_ds_permute((tbase + (explored ? my_rank : TC - 1)) << 2, gl);
+        const int src_of_rank = __shfl(pushed, src_rank, TC);
+        const int src = (gl < n_next) ? src_of_rank : 0;
+        const uint32_t s_k01 = (uint32_t)__shfl((int)k01, src, TC), s_k2t = (uint32_t)__shfl((int)k2t, src, TC);
         if (active) {
             const int parent_base = node_base;
             node_base += m;
             n_cur = n_next;
             if (gl < n_next) {
-                c_state = which == 0 ? s_c0 : (which == 1 ? s_c1 : s_c2);
+                const uint32_t c = which == 0 ? (s_k01 & 0xFFFFu) : (which == 1 ? (s_k01 >> 16) : (s_k2t & 0xFFFFu));
+                c_state = c == FL_R_NONE ? -1 : c == FL_R_PHANTOM ? -2 : (int)c;
                 c_parent = parent_base + src;
-                c_tot = s_tot;
+                c_tot = (int)(s_k2t >> 16);
                 c_act = which - 1;
             }
         }
