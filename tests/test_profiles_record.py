@@ -53,3 +53,16 @@ def test_default_bench_line_of_record_keeps_the_contract():
     assert c["cores"] == c["physical_cores"] <= c["threads"]      # one worker per PHYSICAL core is the stated figure
     # whole-job throughput and time per step belong together: B * A agent-steps per step
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 256 * 20) < 1.0
+
+
+def test_sq_counters_of_record_are_this_tree_s_and_consistent():
+    """the SQ counters the bench line's `roofline.valu_issue` quotes: taken on the tree's kernel sources, and the two independent
+    counters of the vector instructions agree on 4 cycles a wave64 instruction (ACTIVE_INST_VALU is in quad-cycles)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    sq = json.load(open(os.path.join(P, f"{TAG}_sq_counters_cfg2.json")))
+    assert sq["kernel_source_sha"] == bench.kernel_source_sha() and sq["tag"] == TAG
+    c = sq[[k for k in sq if k.startswith("void k_obs")][0]]
+    assert abs(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"] - 4.0) < 0.1
+    frac = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    assert 0.3 < frac < 1.0, frac

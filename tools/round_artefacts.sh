@@ -25,6 +25,10 @@ for k in (1, 2, 3):
     if os.path.exists(p):
         for kern, d in json.load(open(p)).items():
             acc.setdefault(kern, {}).update(d)
+sys.path.insert(0, os.getcwd())
+import bench
+acc["kernel_source_sha"] = bench.kernel_source_sha()   # (the bench line quotes the VALU issue fraction only for these sources)
+acc["tag"] = tag
 json.dump(acc, open(os.path.join(out, "%s_sq_counters_cfg2.json" % tag), "w"), indent=1, sort_keys=True)
 PY
 echo "[artefacts] SQ counters done"
