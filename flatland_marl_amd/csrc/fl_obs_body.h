@@ -576,6 +576,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
             if (bk) for (int k = tid; k < (bk_lds ? K * bk_w / 2 : ((K + 1) * bk_nb + 1) / 2); k += nt) bkc[k] = 0u;
         }
         if (dual) for (int k = tid; k <= K; k += nt) { csr2[k] = 0; if (p_use_tmask) tmaskb[k] = 0ull; if (X.tmask_m2) tmaskb_m2[k] = 0ull; }
+        if (STAGE != 2 && tid < 64) { team_meta[64 + tid] = 1; team_meta[192 + tid] = 1; }   // (trees the hoisted pass A below does not build: the root alone)
         __syncthreads();
         const int pred_depth = my_pred_depth;
         if (STAGE != 2) {
@@ -704,19 +705,27 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         if (wsel >= 0 && lane == 0) atomicMax((unsigned long long *)&X.dbg[21], (unsigned long long)wall_clock64());
 #endif
         {
-            const int grp = lane >> 5, gl = lane & 31, team_id = wave * 2 + grp;
 #ifdef FL_OBS_TIMING
             const long long t_pa0 = (long long)wall_clock64();
 #endif
-            if (CUTILS && (!bk || bk_lds) && P.max_nodes <= OBS_CAP_C) {  // pass A of the team's first tree (not while the node tables hold the bucket counters; 32-lane teams)
-                int node_base, levels;
-                const bool have = team_id < A;
-                cutils_pass_a(X, d, P, b, team_id, have, grp, gl,
-                              merged ? merged_table_c(wave_scr, min(team_id, ROUND - 1)) : wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (N_WORDS_C * OBS_CAP_C),
-                              a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
-                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 1] : d.spk[b * A + (have ? team_id : 0)],
-                              a_raw ? a_raw[(have ? team_id : 0) * 8 + 2] : d.malf[b * A + (have ? team_id : 0)], node_base, levels);
-                if (gl == 0) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
+            if (CUTILS && (!bk || bk_lds) && P.max_nodes <= OBS_CAP_C) {  // pass A of the first round's trees (not while the node tables hold the bucket counters)
+                // teams of 16 lanes, four trees a wavefront, where no cell has more than two transitions a direction (cutils_pass_a); else 32 lanes
+                const int n_first = min(A, merged ? ROUND : (nt >> 6) * 2);   // trees of the first round
+                auto hoisted = [&](auto team_tag) __attribute__((always_inline)) {
+                    constexpr int TEAM = decltype(team_tag)::value;
+                    const int grp = lane / TEAM, gl = lane % TEAM, team_id = wave * (64 / TEAM) + grp;
+                    if (__builtin_amdgcn_readfirstlane(wave * (64 / TEAM)) >= n_first) return;   // (no tree on this wavefront)
+                    int node_base, levels;
+                    const bool have = team_id < n_first;
+                    cutils_pass_a<OBS_CAP_C, TEAM>(X, d, P, b, team_id, have, grp, gl,
+                                  merged ? merged_table_c(wave_scr, min(team_id, ROUND - 1)) : wave_scr + min(team_id, min((nt >> 6) * 2, A)) * (N_WORDS_C * OBS_CAP_C),
+                                  a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, (float)T,
+                                  a_raw ? a_raw[(have ? team_id : 0) * 8 + 1] : d.spk[b * A + (have ? team_id : 0)],
+                                  a_raw ? a_raw[(have ? team_id : 0) * 8 + 2] : d.malf[b * A + (have ? team_id : 0)], node_base, levels);
+                    if (gl == 0 && have) { team_meta[64 + team_id] = node_base; team_meta[192 + team_id] = levels; }
+                };
+                if (p_compact_t) hoisted(std::integral_constant<int, 16>());
+                else hoisted(std::integral_constant<int, 32>());
             }
 #ifdef FL_OBS_TIMING
             if (lane == 0) {

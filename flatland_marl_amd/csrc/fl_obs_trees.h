@@ -239,9 +239,13 @@ __device__ __forceinline__ void tree_upstream(const ObsCtx &X, const FlDev &d, c
 // Pass A of one flatland_cutils tree (treeobs.cpp:154-256): root row, node topology level by level (BFS), one team of 32
 // lanes per agent, two teams per wavefront.  Only wave-level synchronisation, so a wavefront can run it whenever the
 // rail bitmap and the agent snapshot are in LDS (the workgroup overlaps it with the path walk of phase 2).
-// TC = lanes of the team = slots of its node table: 32 (two trees a wavefront; max_nodes <= 32, the solution's 31) or 64 (one tree a
-// wavefront; max_nodes up to 64, the stand-alone flatland_cutils launch only)
-template <int TC = OBS_CAP_C>
+// TC = slots of the node table: 32 (max_nodes <= 32, the solution's 31) or 64 (max_nodes up to 64, the stand-alone flatland_cutils launch
+// only).  TEAM = lanes of the team: TC (two trees / one tree a wavefront), or 16 for 32-slot tables on maps whose cells have at most two
+// transitions a direction (FlDev::max_branch, every Flatland rail cell type) -- FOUR trees a wavefront: an explored node has then at most
+// two real children of three, so a level of size s needs s - 2 nodes before it and the 31 nodes of a tree leave no level more than 12
+// (3, 6, 12, then at most 9); pass A is bound by instruction issue, half the wavefronts issue half the instructions.  grp / gl: the team
+// inside the wavefront and the lane inside the team.
+template <int TC = OBS_CAP_C, int TEAM = TC>
 __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int grp,
                                               int gl, int *scr, const uint16_t *a_vpos, const int *a_pos,
                                               const uint8_t *a_dir, const uint8_t *a_state, const double *a_speed,
@@ -257,9 +261,12 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
     uint32_t orientation = dir;
     if (__popc(rbits) == 1) orientation = first_dir(rbits);
     float *F = P.forest + (size_t)g * N * 12;
-    nt_clear_desc(scr, CAP, gl);
-    // N_PH: parent + 2 | (first child's node index << 2 | action + 1) << 8; the root: no parent, first child = node 1
-    nt_w(scr, CAP, N_PH, gl) = gl == 0 ? (((1 << 2) | 1) << 8) : 0;
+#pragma unroll
+    for (int k = gl; k < CAP; k += TEAM) {
+        nt_clear_desc(scr, CAP, k);
+        // N_PH: parent + 2 | (first child's node index << 2 | action + 1) << 8; the root: no parent, first child = node 1
+        nt_w(scr, CAP, N_PH, k) = k == 0 ? (((1 << 2) | 1) << 8) : 0;
+    }
     // level 1: three cells from the root (treeobs.cpp:205-222)
     int c_state = -1, c_parent = 0, c_tot = 1, c_act = 0;
     if (gl < 3) {
@@ -275,6 +282,7 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         const bool active = have && node_base < N && n_cur > 0;
         if (!__any(active)) break;  // wave-uniform: both teams take part in the shuffles below
         const int m = active ? min(n_cur, N - node_base) : 0;
+        if (TEAM < TC && m > TEAM) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);   // (cannot happen with at most two transitions a direction)
         const bool mine = gl < m;
         const int idx_node = node_base + gl;
         // what an explored node hands to its three children: their start states as the segment table has them (u16 each, FL_R_NONE =
@@ -291,13 +299,13 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         }
         // explored lanes of the team, and how many of them below this lane (teams of 32: the mask is the team's half of the ballot)
         int n_next, my_rank;
-        if (TC == 64) {
+        if (TEAM == 64) {
             const unsigned long long em = __ballot(explored);
             n_next = 3 * __popcll(em);
             my_rank = __popcll(em & ((1ull << gl) - 1ull));
         } else {
             const unsigned long long bal = __ballot(explored);
-            const uint32_t em = grp ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            const uint32_t em = TEAM == 32 ? (grp ? (uint32_t)(bal >> 32) : (uint32_t)bal) : ((uint32_t)(bal >> (grp * TEAM)) & ((1u << (TEAM & 31)) - 1u));
             n_next = 3 * __popc(em);
             my_rank = __popc(em & ((1u << gl) - 1u));
         }
@@ -307,14 +315,14 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
         }
         // hand the children to the next level's lanes: lane j takes child j % 3 of the (j / 3)-th explored lane.  Which lane that is:
         // every explored lane PUSHES its number to the lane of its rank (ds_permute; the others push to the team's last lane, whose
-        // rank no explored lane has: at most TC - 1 nodes are explored), lane j reads it from lane j / 3 -- two cross-lane moves
+        // rank no explored lane has: fewer nodes than lanes are explored), lane j reads it from lane j / 3 -- two cross-lane moves
         // instead of a loop over the set bits of the mask (pass A is bound by instruction issue: a few nodes a level on 32 lanes).
         const int src_rank = gl / 3, which = gl - 3 * src_rank;
         const int tbase = (int)__lane_id() - gl;
-        const int pushed = __builtin_amdgcn_ds_permute((tbase + (explored ? my_rank : TC - 1)) << 2, gl);
-        const int src_of_rank = __shfl(pushed, src_rank, TC);
+        const int pushed = __builtin_amdgcn_ds_permute((tbase + (explored ? my_rank : TEAM - 1)) << 2, gl);
+        const int src_of_rank = __shfl(pushed, src_rank, TEAM);
         const int src = (gl < n_next) ? src_of_rank : 0;
-        const uint32_t s_k01 = (uint32_t)__shfl((int)k01, src, TC), s_k2t = (uint32_t)__shfl((int)k2t, src, TC);
+        const uint32_t s_k01 = (uint32_t)__shfl((int)k01, src, TEAM), s_k2t = (uint32_t)__shfl((int)k2t, src, TEAM);
         if (active) {
             const int parent_base = node_base;
             node_base += m;
