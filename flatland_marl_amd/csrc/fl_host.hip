@@ -968,8 +968,11 @@ extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
 // second index, items in LDS, one pass B for both builders, compact upstream trees of the fused observation launch on this batch
 extern "C" int fl_debug_obs_config(fl_batch *h, int pred_depth, int max_depth, int tree_pred, int *out11) {
     NEED_COMMIT(h);
-    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11, h->obs.n_cu > 0 && h->d.B >= OBS_WIDE_ENVS_PER_CU * h->obs.n_cu);
+    return fl_obs_config_of_fused(h->d, pred_depth, max_depth, tree_pred, out11, obs_batch_is_wide(h->d.B, h->obs.n_cu));
 }
+
+// diagnostic (not part of the public header), no GPU needed: does the launcher take a batch of B small envs on n_cu CUs as two workgroups a CU
+extern "C" int fl_debug_batch_is_wide(int B, int n_cu) { return obs_batch_is_wide(B, n_cu) ? 1 : 0; }
 
 // diagnostic (not part of the public header): what the last fused observation launch (fl_obs_cutils_tree / fl_step_obs with a tree)
 // of this handle ran -- out[0] fixed launch class (0 = the runtime-carving kernel), out[1] 1 = the class's split kernel (the class's

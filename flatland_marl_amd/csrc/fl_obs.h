@@ -7,9 +7,15 @@
 #define FL_OBS_MAX_NODES 64  /* a tree's nodes are the lanes of one team: 32 lanes (two trees a wavefront) up to 32 nodes, a whole wavefront up to 64 */
 #define FL_OBS_MAX_PRED 500
 
-#ifndef OBS_WIDE_ENVS_PER_CU
-#define OBS_WIDE_ENVS_PER_CU 4   // a batch of at least this many envs per CU is "wide": small envs then run two workgroups a CU (class 5; same-box sweep: +3 % at 4 envs per CU, +7 % at 8, -10 % at 3, even at 2)
-#endif
+// A batch is "wide" when small envs (at most 32 agents) are better off as TWO 512-thread workgroups a CU (class 5) than as one 1 024-thread
+// workgroup (class 1): a co-resident pair takes 1.6 x what one 1 024-thread workgroup takes alone (same-box sweep at the cfg2 shape,
+// profiles/r05_cfg2_bsweep.json: 65 against 40 us), so the launch is ceil(B / 2 CUs) pairs against ceil(B / CUs) single workgroups --
+// two a CU from 257 envs on except at three and five envs a CU (round 5, first: from four envs a CU on; 384 envs +4 %, 512 +2.6 %)
+static inline bool obs_batch_is_wide(int B, int n_cu) {
+    if (n_cu <= 0) return false;
+    const long long pairs = (B + 2LL * n_cu - 1) / (2LL * n_cu), singles = (B + (long long)n_cu - 1) / n_cu;
+    return 8 * pairs < 5 * singles;
+}
 
 struct FlObsScratch {
     int pred_cap;      // waypoints kept per agent (pred_depth + 2)

@@ -395,7 +395,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * OBS_CAP_C;
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
-    P.wide = o.n_cu > 0 && d.B >= OBS_WIDE_ENVS_PER_CU * o.n_cu;
+    P.wide = obs_batch_is_wide(d.B, o.n_cu);
     P.keep_mode = o.keep_rows;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     // FL_OBS_KEEP_TREE_ROWS: the row masks of the previous launch describe this very buffer at this depth -> no pre-fill of the slab

@@ -98,3 +98,13 @@ def test_wide_batches_of_small_envs_run_two_workgroups_a_cu():
     assert got["fix"] == 0 and got["nt"] == 512 and got["lds"] <= 80 * 1024, got
     assert _config(20, 213, 5, 3, wide=True)["fix"] == 0          # depth 3: not the class's
     assert _config(80, 193, 10, 3, wide=True)["fix"] == 2         # envs of more than 32 agents: their own classes, one a CU
+
+
+def test_small_envs_go_two_workgroups_a_cu_when_that_ends_the_launch_sooner():
+    """obs_batch_is_wide (csrc/fl_obs.h): a co-resident pair of 512-thread workgroups takes 1.6 x one 1 024-thread workgroup, so class 5
+    is the choice when ceil(B / 2 CUs) pairs end before ceil(B / CUs) single workgroups (profiles/r05_cfg2_bsweep.json)"""
+    L = ctypes.CDLL(hb.LIB_PATH)
+    wide = {B: bool(L.fl_debug_batch_is_wide(B, 256)) for B in (1, 256, 257, 384, 512, 513, 640, 768, 769, 1024, 1280, 1536, 2048, 8192)}
+    assert wide == {1: False, 256: False, 257: True, 384: True, 512: True, 513: False, 640: False, 768: False, 769: True, 1024: True,
+                    1280: True, 1536: True, 2048: True, 8192: True}, wide
+    assert not L.fl_debug_batch_is_wide(1024, 0)
