@@ -31,6 +31,7 @@ acc["kernel_source_sha"] = bench.kernel_source_sha()   # (the bench line quotes 
 acc["tag"] = tag
 json.dump(acc, open(os.path.join(out, "%s_sq_counters_cfg2.json" % tag), "w"), indent=1, sort_keys=True)
 PY
+cp $out/${tag}_sq_counters_cfg2.json profiles/ 2>/dev/null   # (on the GPU box: the default bench line below quotes it as roofline.valu_issue)
 echo "[artefacts] SQ counters done"
 if [ -f build_ab/libfl_timing.so ]; then
   : > $out/${tag}_phase_clocks.txt
