@@ -568,8 +568,14 @@ int fl_step_obs(fl_batch *h, const uint8_t *actions_dev, uint32_t seed, uint32_t
         set_err("fl_step_obs: null output buffer");
         return FL_ERR_ARG;
     }
-    // Two launches back to back on the handle's stream.  A single fused launch was measured and is slower: the step wants
-    // one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
+    // every argument error is raised BEFORE anything is launched: a depth-4 tree needs compact node tables (fl_obs_tree's own check,
+    // which would otherwise fire after the envs have advanced a step and the cutils launch has set its sticky deadlock bits)
+    if (tree_max_depth > 3 && (h->d.max_branch > 2 || getenv("FL_OBS_NO_COMPACT") != nullptr)) {
+        set_err("fl_step_obs: max_depth 4 needs a grid on which no direction of a cell has more than two transitions (every Flatland rail cell type) and the compact node tables; this batch has %d (nothing was launched: the envs have not advanced)", h->d.max_branch);
+        return FL_ERR_ARG;
+    }
+    // TWO launches (k_step, then the observation kernel) back to back on the handle's stream behind this one call.  A single fused launch was
+    // measured and is slower: the step wants one lane per agent and few wavefronts, the builders 16 wavefronts, and the second launch's dispatch overlaps the first.
     fl_launch_step(h->d, actions_dev, seed, stream_base, kind, rewards_dev, dones_dev, done_all_dev, flags, h->stream);
     HIPCHK(hipGetLastError());
     if (tree_max_depth > 3 || (tree_max_depth > 0 && max_nodes > 32)) return fl_obs_cutils_tree(h, max_nodes, pred_depth, attr_dev, forest_dev, adjacency_dev, node_order_dev, edge_order_dev,
@@ -919,6 +925,10 @@ int fl_obs_cutils_tree(fl_batch *h, int max_nodes, int pred_depth, float *attr_d
     }
     if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev || !tree_out_dev) {
         set_err("fl_obs_cutils_tree: null output buffer");
+        return FL_ERR_ARG;
+    }
+    if (tree_max_depth > 3 && (h->d.max_branch > 2 || getenv("FL_OBS_NO_COMPACT") != nullptr)) {   // (before the cutils launch sets its sticky deadlock bits)
+        set_err("fl_obs_cutils_tree: max_depth 4 needs a grid on which no direction of a cell has more than two transitions (every Flatland rail cell type) and the compact node tables; this batch has %d", h->d.max_branch);
         return FL_ERR_ARG;
     }
     if (tree_max_depth > 3 || max_nodes > 32) {   // beyond the fused kernels' node tables: the two builders one after the other (same outputs)

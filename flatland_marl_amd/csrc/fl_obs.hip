@@ -116,6 +116,7 @@ template <int FIX>
 static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o, ObsLayout &L) {
     using F = ObsFixed<FIX>;
     if (F::opt.wl_head && obs_no_wl_head()) return false;
+    if (P.label) return false;   // (get_many(handles) with a strict subset: the stand-alone kernel's runtime body)
     if ((FIX == 1 || FIX == 5) && P.keep_mode) return false;   // (the small-env classes carry no row-mask code: FL_OBS_KEEP_TREE_ROWS runs the runtime carving there)
     const size_t nh_bytes = F::opt.nh ? (((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15) : 0;
     if (!(d.A <= F::dims.A && d.Rcap <= F::dims.Rcap && d.rkey == nullptr && obs_same_options(o, F::opt) && P.merged == F::shape.merged &&
@@ -136,6 +137,14 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;   // diagnostic: the runtime carving for every batch
     P.fix = 0; P.split = 0;
     if (no_fix || !allowed) return;
+    if (P.tw_t == 0) {   // the flatland_cutils builder alone: classes 6 .. 10 (the counterparts of 1 .. 5)
+        if (obs_fits_fixed<6>(d, P, o, L)) P.fix = 6;
+        else if (obs_fits_fixed<7>(d, P, o, L)) P.fix = 7;
+        else if (obs_fits_fixed<8>(d, P, o, L)) P.fix = 8;
+        else if (obs_fits_fixed<9>(d, P, o, L)) P.fix = 9;
+        else if (obs_fits_fixed<10>(d, P, o, L)) P.fix = 10;
+        return;
+    }
     if (obs_fits_fixed<1>(d, P, o, L)) P.fix = 1;
     else if (obs_fits_fixed<2>(d, P, o, L)) P.fix = 2;
     else if (obs_fits_fixed<3>(d, P, o, L)) P.fix = 3;
@@ -170,6 +179,9 @@ static int obs_take_split_class(const FlDev &d, ObsArgs &P, const int *h_R) {
     if (no_fix || no_split || !g_fix_allowed || P.fix != 0) return 0;
     int n = 0, k = 0;
     unsigned total = 0;
+    if (P.tw_t == 0) {   // the flatland_cutils builder alone: the large-map class has a split kernel (the levels of cfg5's row differ by 13 % in rail cells)
+        if ((n = obs_split_fits<9>(d, P, h_R)) > 0) { k = 9; total = ObsFixed<9>::L.total; }
+    } else
     if ((n = obs_split_fits<2>(d, P, h_R)) > 0) { k = 2; total = ObsFixed<2>::L.total; }
     else if ((n = obs_split_fits<3>(d, P, h_R)) > 0) { k = 3; total = ObsFixed<3>::L.total; }
     else if ((n = obs_split_fits<4>(d, P, h_R)) > 0) { k = 4; total = ObsFixed<4>::L.total; }
@@ -206,6 +218,10 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     const bool nh_fit = (size_t)d.Ucap * d.Rcap * 2 <= 24 * 1024;  // beyond that the next-hop tables stay in HBM / L2
     const bool dual_ok = P.tw_c != 0 && P.tw_t != 0 && P.tree_pred >= 0 &&
                          (long long)d.A * (P.pred_depth + 2) < 65536 && (long long)d.A * (P.tree_pred + 2) < 32768;
+    // the flatland_cutils builder ALONE on the one-pass kernels (MODE 6 / 7 / 8: no second index, no upstream tables): 32-slot trees,
+    // every agent listed (get_many(handles) with a strict subset stays on the stand-alone kernel)
+    const bool up = P.tw_t != 0;
+    const bool merge_ok = up ? dual_ok : (P.cutils_alone && P.tw_c == N_WORDS_C * OBS_CAP_C && P.label == nullptr && (long long)d.A * (P.pred_depth + 2) < 65536);
     static const int opts[5][3] = {{1, 1, 1}, {1, 0, 1}, {1, 0, 0}, {0, 0, 1}, {0, 0, 0}};  // masks, second index, items
     // Order of preference, from same-box A/B runs (tools/obs_sweep.py): the most wavefronts; the full work-list space; the LDS
     // copy of the items, the time masks and the second index; the successor table; the next-hop tables; own scan scratch.
@@ -230,11 +246,11 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     const bool r16 = (r16_small || (d.A > 32 && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0))) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
     const int merged_nt = r16 ? 512 : OBS_NT;
     const size_t merged_limit = r16 ? std::min(lds_limit, (size_t)80 * 1024) : lds_limit;
-    if (!no_merge && dual_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
-        ok(force.tmask, 1) && ok(force.dual, 1) && ok(force.snext, 1) &&
-        (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP) {
+    if (!no_merge && merge_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
+        ok(force.tmask, 1) && ok(force.dual, up ? 1 : 0) && ok(force.snext, 1) &&
+        (!up || (size_t)d.A * (P.tree_pred + 2) <= OBS_ITEMS2_CAP)) {
         P.merged = r16 ? 3 : d.A <= 32 ? 1 : 2;
-        o.nt = merged_nt; o.tmask = 1; o.dual = 1; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
+        o.nt = merged_nt; o.tmask = 1; o.dual = up ? 1 : 0; o.snext = 1; o.partial = 1; o.tab = 0; o.bk_room = 0;
         // Order of preference, from same-box sweeps (tools/gpu_env_sweep.sh).  One round (at most 32 agents, cfg2): 24 KB of LDS work
         // lists, the items in LDS, plain lists (the extra counting pass of the bucketed lists costs more than their short scans
         // save: 57.9 against 51.8 us).  Rounds of 32 agents: a round of 64 trees meets thousands of occupied cells, and a work
@@ -260,7 +276,7 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
         // what a configuration of this branch sets in P (and the fixed launch class that has exactly these options, if the batch fits one)
         auto accept = [&](const ObsOptions &oo, ObsLayout L) {
             g_last_options = oo;
-            P.use_tmask = 1; P.dual_index = 1;
+            P.use_tmask = 1; P.dual_index = up ? 1 : 0;
             P.bk = oo.fb ? 2 : 0; P.bk_nb = OBS_FB_NB; P.bk_shift = OBS_FB_SHIFT;
             P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
             // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
@@ -379,10 +395,32 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * (max_nodes > OBS_CAP_C ? 64 : OBS_CAP_C);   // (more than 32 nodes: 64-slot tables, one tree a wavefront)
+    // The builder alone -- what the reference's solution launches (solution/eval_env.py:15-17) -- runs on the one-pass kernels' machinery
+    // (MODE 6 / 7 / 8 = MODE 3 / 4 / 5 without the upstream builder; classes 6 .. 10) wherever those apply: 16-lane pass A teams need grids
+    // whose cells have at most two transitions a direction (every Flatland rail cell type).  FL_OBS_NO_CUTILS_MERGE: the stand-alone kernel.
+    static const bool no_compact = getenv("FL_OBS_NO_COMPACT") != nullptr, no_alone = getenv("FL_OBS_NO_CUTILS_MERGE") != nullptr;
+    P.compact_t = d.max_branch <= 2 && !no_compact;
+    P.cutils_alone = !no_alone;
+    P.wide = obs_batch_is_wide(d.B, o.n_cu);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
+    if (!P.merged && !P.fix) P.compact_t = 0;    // (the stand-alone kernel's own pass A: teams of 32 lanes)
+    const int n_split = P.label ? 0 : obs_take_split_class(d, P, o.h_R);
+    o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
     obs_verbose(P);
-    return fl_obs_launch_m0(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
+    FlObsScratch u = o;
+    if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
+    else u = fl_obs_env_order(o, d, s);
+    if (P.split) return P.fix == 9 ? fl_obs_launch_s9(d, u, P, s) : FL_ERR_ARG;
+    switch (P.fix) {
+    case 6: return fl_obs_launch_f6(d, u, P, s);
+    case 7: return fl_obs_launch_f7(d, u, P, s);
+    case 8: return fl_obs_launch_f8(d, u, P, s);
+    case 9: return fl_obs_launch_f9(d, u, P, s);
+    case 10: return fl_obs_launch_f10(d, u, P, s);
+    default: break;
+    }
+    return P.merged == 1 ? fl_obs_launch_m6(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m7(obs_var(P), d, u, P, s) :
+           P.merged == 3 ? fl_obs_launch_m8(obs_var(P), d, u, P, s) : fl_obs_launch_m0(obs_var(P), d, u, P, s);
 }
 
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
@@ -459,7 +497,11 @@ int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tr
     P.pred_depth = pred_depth;
     P.max_nodes = 31;   // (the solution's tree size; the fixed launch classes are for exactly that)
     P.tw_c = N_WORDS_C * OBS_CAP_C;
-    obs_tree_args(d, P, max_depth, tree_pred, nullptr);
+    if (max_depth > 0) obs_tree_args(d, P, max_depth, tree_pred, nullptr);
+    else {   // max_depth 0: the flatland_cutils builder alone (fl_launch_obs_cutils)
+        P.compact_t = d.max_branch <= 2 && getenv("FL_OBS_NO_COMPACT") == nullptr;
+        P.cutils_alone = getenv("FL_OBS_NO_CUTILS_MERGE") == nullptr;
+    }
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     if (getenv("FL_OBS_VERBOSE")) {   // diagnostic: the carving of the LDS, array by array (enum L_* of fl_obs_layout.h)
         const ObsOptions &q = g_last_options;

@@ -39,7 +39,9 @@
 // index would be vector arithmetic -- 29 spilled vector registers in the rounds kernel)
 __device__ __forceinline__ int obs_env_of_workgroup(const FlObsScratch &S) { return __builtin_amdgcn_readfirstlane(S.order ? S.order[blockIdx.x] : (int)blockIdx.x); }
 
-template <bool CUTILS, int VAR, int STAGE, int MERGED = 0, int FIX = 0>
+// UP = false (one-pass kernels only, MODE 6 / 7 / 8): the flatland_cutils builder ALONE on the one-pass machinery -- no second index, no
+// upstream tables / jobs / rows; what the reference's solution launches (solution/eval_env.py:15-17: TreeCutils(31, 500) and nothing else).
+template <bool CUTILS, int VAR, int STAGE, int MERGED = 0, int FIX = 0, bool UP = true>
 __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P_launch) {
     // A fixed launch class also fixes the builders' parameters (BASELINE's: 31 nodes, predictor depths 500 / 30): the launcher only
     // takes the class for exactly these, the kernel has them as constants (a local copy the compiler takes apart; no memory).
@@ -71,7 +73,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // measured in the static code only: two spilled VECTOR registers in k_obs<4,2,0> -- not done)
     const int p_bk = FIX != 0 ? obs_fixed_bk<FIX != 0 ? FIX : 1>() : P.bk;
     const int p_bk_nb = FIX != 0 ? (MERGED != 0 ? OBS_FB_NB : OBS_BK_NB) : P.bk_nb, p_bk_shift = FIX != 0 ? (MERGED != 0 ? OBS_FB_SHIFT : OBS_BK_SHIFT) : P.bk_shift;
-    const bool p_use_tmask = FIX != 0 ? FixT::opt.tmask != 0 : P.use_tmask != 0, p_dual_index = FIX != 0 ? FixT::opt.dual != 0 : P.dual_index != 0;
+    const bool p_use_tmask = FIX != 0 ? FixT::opt.tmask != 0 : P.use_tmask != 0, p_dual_index = UP && (FIX != 0 ? FixT::opt.dual != 0 : P.dual_index != 0);
     const bool p_compact_t = FIX != 0 ? true : P.compact_t != 0;   // (every class's shape has the compact upstream tables)
     const int p_wl_occ_div = FIX != 0 ? obs_fixed_wl_occ_div<FIX != 0 ? FIX : 1>() : P.wl_occ_div;
 #define LDS_AT(T, which) reinterpret_cast<T *>(lds + L_OFF(which))
@@ -221,8 +223,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         // (a slice of the pre-fill in every round of the first stage's trees instead measured slower at cfg5, 1.73 against 1.65 ms:
         // the next global load of a wavefront waits for its stores)
         // (FL_OBS_KEEP_TREE_ROWS: the buffer still holds the previous launch's rows -- no pre-fill, upstream_rows sets the stale ones)
-        bg_prefill = CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6) && !P.keep_rows;
-        if ((!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill && !P.keep_rows) {
+        bg_prefill = UP && CUTILS && STAGE == 1 && P.tree_out != nullptr && P.pred_depth >= 0 && nw_walk0 < (nt >> 6) && !P.keep_rows;
+        if (UP && (!CUTILS || STAGE == 1) && P.tree_out && !bg_prefill && !P.keep_rows) {
             // the upstream trees of the env: every row that is not a real node is -inf (observations.py:247, 489); the builders
             // only write the real rows later.  Coalesced 16-byte stores beside the staging.  The wait below (before the barrier
             // that ends this phase) lets them reach the L2 ahead of any later store of this workgroup to the same rows -- same CU,
@@ -257,7 +259,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
                 if (on) atomicMax(&slot_agent[slot], i);
                 else atomicAdd(&slot_ready[slot], 1);
             }
-            if (!CUTILS || STAGE == 1) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
+            if (UP && (!CUTILS || STAGE == 1)) atomicOr(&cell_target[a_target[i] >> 5], 1u << (a_target[i] & 31));
         }
     } else {
         // second stage: only the predictor's times-per-cell differ (int(np.reciprocal(speed)), predictions.py:139)
@@ -503,7 +505,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     // wavefronts finish at very different times (late_jobs) -- this phase then ends with the last pass A.
     const int n_p1_all = (do_p1 && p1_beside_walk && X.Tn > 0) ? (A + 1) / 2 : 0;
     const bool late_p1 = merged && n_p1_all > 0;
-    const int n_up_jobs = merged ? (min(A, ROUND) + 3) / 4 : 0, n_p1_jobs = late_p1 ? 0 : n_p1_all;
+    const int n_up_jobs = (merged && UP) ? (min(A, ROUND) + 3) / 4 : 0, n_p1_jobs = late_p1 ? 0 : n_p1_all;
     // ... and, last, the -inf pre-fill of the env's upstream rows (see phase 0) in chunks of 16 KB: pure stores that drain beside
     // the latency-bound rest of the phase (no builder writes a row before the trees phase)
     constexpr int PF_CHUNK = 64 * 16;  // double2 per job
@@ -556,7 +558,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (X.Tn > 0) {
         // fused launch: stage 1 builds the upstream predictor's index too (same paths, one pass over the waypoints); stage 2
         // then starts at its trees.  misc[4] tells stage 2 that the second index is complete.
-        const bool dual = CUTILS && STAGE == 1 && p_dual_index && P.tree_pred >= 0;
+        const bool dual = UP && CUTILS && STAGE == 1 && p_dual_index && P.tree_pred >= 0;
         const bool reuse = STAGE == 2 && p_dual_index && misc[4] != 0;
         const int Tn2 = P.tree_pred + 1, tshift2 = Tn2 <= 64 ? 0 : P.tshift;  // the same bucket width stage 2 queries with
         // large maps: bucketed lists (OBS_BK_NB).  Their per-(key, bucket) counters -- u16, two per word -- live in the node
@@ -915,7 +917,7 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         const bool fit = items_lds != nullptr && misc[2] <= L_FIELD(items_cap);
         const bool dual_fill = dual && misc[3] <= L_FIELD(items2_cap);
         if (dual && tid == 0) misc[4] = dual_fill ? 1 : 0;
-        if (merged && !dual_fill) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);  // (cannot happen: the LDS copy holds the exact bound)
+        if (merged && UP && !dual_fill) atomicCAS(&d.err[b], 0, FL_ERR_CAPACITY);  // (cannot happen: the LDS copy holds the exact bound)
         if (fit && !reuse) { csr_items = items_lds; X.items_lds = items_lds; }
         // fill: bumping csr[key] turns it from the start into the END offset of key's list (start = csr[key - 1]);
         // one wavefront per agent, one lane per waypoint
@@ -1124,8 +1126,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     const int nwaves = nt >> 6;
     const bool items_in_lds = X.items_lds != nullptr;
     if (merged) {
-        if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
-        else trees_merged<false, MERGED >= 2, ROUND>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5) ? nullptr : S.rowmask);
+        if (items_in_lds) trees_merged<true, MERGED >= 2, ROUND, UP>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5 || !UP) ? nullptr : S.rowmask);
+        else trees_merged<false, MERGED >= 2, ROUND, UP>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5 || !UP) ? nullptr : S.rowmask);
     } else if (CUTILS && STAGE == 0 && FIX == 0 && P.max_nodes > OBS_CAP_C) {
         // more than 32 nodes a tree (the stand-alone flatland_cutils launch only): a team of 64 lanes, one tree a wavefront
         if (items_in_lds) trees_cutils<true, 64>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
@@ -1159,23 +1161,26 @@ template <int MODE, int VAR, int FIX>
 __device__ __forceinline__ void obs_kernel_body(const FlDev &d, const FlObsScratch &S, const ObsArgs &P) {
     // what this env takes goes to S.cost: the next launch starts the longest envs first.  Env and start clock wait in two LDS words
     // (not in registers: the kernel sits at its register ceiling, and every scalar that lives through it costs spills)
-    if (MODE != 3 && S.order && threadIdx.x == 0) {
+    if (MODE != 3 && MODE != 6 && S.order && threadIdx.x == 0) {
         extern __shared__ __align__(16) unsigned char lds[];
         int *misc = reinterpret_cast<int *>(lds + (FIX != 0 ? ObsFixed<FIX != 0 ? FIX : 1>::L.off[L_MISC] : P.L.off[L_MISC]));
         misc[62] = obs_env_of_workgroup(S);
         misc[63] = (int)(uint32_t)wall_clock64();
     }
-    if (MODE == 0) obs_body<true, VAR, 0>(d, S, P);
+    if (MODE == 0) obs_body<true, VAR, 0, 0, FIX>(d, S, P);
     else if (MODE == 1) obs_body<false, VAR, 0>(d, S, P);
     else if (MODE == 3) obs_body<true, VAR, 1, 1, FIX>(d, S, P);
     else if (MODE == 4) obs_body<true, VAR, 1, 2, FIX>(d, S, P);
     else if (MODE == 5) obs_body<true, VAR, 1, 3, FIX>(d, S, P);
+    else if (MODE == 6) obs_body<true, VAR, 1, 1, FIX, false>(d, S, P);   // MODE 3 / 4 / 5 with the flatland_cutils builder alone
+    else if (MODE == 7) obs_body<true, VAR, 1, 2, FIX, false>(d, S, P);
+    else if (MODE == 8) obs_body<true, VAR, 1, 3, FIX, false>(d, S, P);
     else {
         obs_body<true, VAR, 1, 0, FIX>(d, S, P);
         __syncthreads();
         obs_body<false, VAR, 2, 0, FIX>(d, S, P);
     }
-    if (MODE != 3 && S.order && threadIdx.x == 0) {
+    if (MODE != 3 && MODE != 6 && S.order && threadIdx.x == 0) {
         extern __shared__ __align__(16) unsigned char lds[];
         const int *misc = reinterpret_cast<const int *>(lds + (FIX != 0 ? ObsFixed<FIX != 0 ? FIX : 1>::L.off[L_MISC] : P.L.off[L_MISC]));
         S.cost[misc[62]] = (uint32_t)wall_clock64() - (uint32_t)misc[63];
@@ -1189,7 +1194,7 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 // class's capacities bound what its carving holds per env (R, K <= dims.Rcap); the HBM strides are the batch's (d.Rcap) either way.
 template <int MODE, int VAR, int FIX>
 __global__ __launch_bounds__(OBS_NT) void k_obs_split(FlDev d, FlObsScratch S, ObsArgs P) {
-    const int b = MODE == 3 ? (int)blockIdx.x : obs_env_of_workgroup(S);
+    const int b = (MODE == 3 || MODE == 6) ? (int)blockIdx.x : obs_env_of_workgroup(S);
     if (d.R[b] <= ObsFixed<FIX>::dims.Rcap) obs_kernel_body<MODE, VAR, FIX>(d, S, P);
     else obs_kernel_body<MODE, VAR, 0>(d, S, P);
 }

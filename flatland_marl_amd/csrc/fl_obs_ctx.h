@@ -133,13 +133,14 @@ __device__ __forceinline__ uint32_t cw_slot(const ObsCtx &X, int r) { return X.c
 __device__ __forceinline__ uint32_t cw_load(const ObsCtx &X, int r) { return X.cellw[r]; }
 __device__ __forceinline__ int key_of(const ObsCtx &X, int r) { return X.rkey ? (int)X.rkey[r] : r; }
 // Pass B serves one builder (PB 0 = upstream, 1 = flatland_cutils) or both in one pass (PB 2): cu says which builder's
-// rules apply to a team
+// rules apply to a team.  PB 3 = the one-pass kernels' machinery (rounds of trees_merged, own-path filter, the fast classify loop)
+// with the flatland_cutils trees ALONE -- the launch the reference's solution makes (solution/eval_env.py:15-17 builds TreeCutils only).
 template <int PB>
-__device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 2 ? team < X.n_cu : PB == 1; }
+__device__ __forceinline__ bool pb_cu(const ObsCtx &X, int team) { return PB == 3 ? true : PB == 2 ? team < X.n_cu : PB == 1; }
 // the agent of a team: from the team table, or -- both builders in one pass -- from the numbering of trees_merged (no memory access)
 template <int PB>
 __device__ __forceinline__ int pb_handle(const ObsCtx &X, const int *team_meta, int team) {
-    return PB == 2 ? X.round_base + (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
+    return PB == 3 ? X.round_base + team : PB == 2 ? X.round_base + (team < X.n_cu ? team : team - X.n_cu) : team_meta[128 + team];
 }
 // predicted time at which the walking agent reaches a cell tot steps away (treeobs.cpp:378 / observations.py:329)
 template <int PB>

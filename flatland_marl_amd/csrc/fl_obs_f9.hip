@@ -1,0 +1,10 @@
+// fl_obs_f9.hip -- the observation kernel of FIXED launch class 9 (ObsFixed<9>, fl_obs_layout.h): the flatland_cutils builder alone with the
+// LDS carving compiled in (the counterpart of class 4).  One translation unit per class (they compile in parallel with the MODE units).
+#include "fl_obs_body.h"
+
+int fl_obs_launch_f9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
+    auto kern = k_obs<obs_fixed_mode<9>(), obs_fixed_var<9>(), 9>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return FL_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(d.B), dim3(P.L.nt), P.L.total, s, d, o, P);
+    return FL_OK;
+}

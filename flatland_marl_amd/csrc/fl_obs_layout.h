@@ -142,7 +142,7 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
         // trees_merged: 32 flatland_cutils + 32 compact upstream tables a round; else a slot per team + the dummy.  Large maps
         // borrow this space for the per-(key, time bucket) counters while the bucketed index is built (P.bk): room for those too
         // (a round = one flatland_cutils tree per 32 lanes: 32 agents on 1024 threads, 16 on 512)
-        unsigned long long scr = P.merged ? (unsigned long long)(o.nt / 32) * (N_WORDS_C * OBS_CAP_C + N_WORDS_T * OBS_CAP_T_COMPACT) * 4
+        unsigned long long scr = P.merged ? (unsigned long long)(o.nt / 32) * (N_WORDS_C * OBS_CAP_C + (P.tw_t != 0 ? N_WORDS_T * OBS_CAP_T_COMPACT : 0)) * 4
                                           : (unsigned long long)obs_scr_words(o.nt / 64, d.A, P.tw_c, P.tw_t, P.tpw_t) * 4;
         const unsigned long long bkc = (R + 1) * OBS_BK_NB * 2 + 4;
         if (o.bk_room && bkc > scr) scr = bkc;
@@ -192,6 +192,12 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 #define OBS_WL_HEAD_MAX (16 * 1024)   // LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
 #define OBS_WL_HEAD_MIN (4 * 1024)
 template <int FIX> struct ObsFixed;
+// options of the classes of the flatland_cutils builder alone: what obs_pick_config chooses at the classes' capacities (tests/test_obs_config.py)
+//                      nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap, wl_head
+#define OBS_FIX7_OPT  {OBS_NT, 36 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 0}
+#define OBS_FIX8_OPT  {OBS_NT, 36 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 0, OBS_ITEMS_LDS_CAP, 0}
+#define OBS_FIX9_OPT  {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0}
+#define OBS_FIX10_OPT {512, 16 * 1024, 0, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP, 0}
 template <> struct ObsFixed<1> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 2;   // the builders' parameters of the class (tree_pred: shape)
     static constexpr int agents = 0;   // agents per env, exactly (0 = any number up to dims.A)
@@ -244,13 +250,59 @@ template <> struct ObsFixed<5> {
     static constexpr ObsOptions opt = {512, 16 * 1024, 0, 0, 1, 1, 1, 1, 1, 0, 1, 0, 0, 2048};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
+// ---- classes 6 .. 10: the flatland_cutils builder ALONE (fl_obs_cutils / fl_step_obs without a tree -- the launch the reference's
+// solution makes: solution/eval_env.py:15-17, demo.py:39 build TreeCutils(31, 500) only), the counterparts of classes 1 .. 5 on the same
+// machinery without the second index and the upstream tables (shape.tw_t = 0; MODE 6 / 7 / 8 = MODE 3 / 4 / 5 with UP = false, class 9: MODE 0)
+template <> struct ObsFixed<6> {   // at most 32 agents / 256 rail cells, one round (cfg1, cfg2)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {256, 32, 0, 0};
+    static constexpr ObsShape shape = {1, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<7> {   // 80 agents, at most 232 rail cells, rounds of 32 agents, work lists in LDS (cfg3)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 80;
+    static constexpr ObsDims dims = {232, 80, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = OBS_FIX7_OPT;
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<8> {   // 80 agents, at most 680 rail cells, rounds of 32 agents (cfg4: every level of the Round-2 row)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 80;
+    static constexpr ObsDims dims = {OBS_FIX3_RCAP, 80, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = OBS_FIX8_OPT;
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<9> {   // 400 agents, at most 2688 rail cells: the stand-alone kernel (MODE 0, VAR 2) with its carving compiled in (cfg5)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 400;
+    static constexpr ObsDims dims = {2688, 400, 0, 0};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = OBS_FIX9_OPT;
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<10> {   // class 6's envs in rounds of 16 agents on 512 threads, two workgroups a CU (batches of several envs per CU)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {256, 32, 0, 0};
+    static constexpr ObsShape shape = {3, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = OBS_FIX10_OPT;
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
 // what obs_pick_config derives from a class's options for ObsArgs: ONE definition for the kernel (which has them as constants) and
 // for the host (obs_fits_fixed only takes the class when its own derivation for the batch gives the same values)
 template <int FIX> __host__ __device__ constexpr int obs_fixed_bk() { return ObsFixed<FIX>::shape.merged != 0 ? (ObsFixed<FIX>::opt.fb ? 2 : 0) : ObsFixed<FIX>::opt.bk_room; }
-template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (FIX == 2 || FIX == 3) ? 3 : OBS_WL_OCC_DIV; }
-template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return (FIX == 1 || FIX == 5) ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (FIX == 2 || FIX == 3 || FIX == 7 || FIX == 8) ? 3 : OBS_WL_OCC_DIV; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return (FIX == 1 || FIX == 5 || FIX == 6 || FIX == 10) ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
 // kernel of a class: MODE 3 (one round) / 4 (rounds of 32 agents) / 2 (two stages), VAR 1 (static tables in LDS) / 2 (work lists in HBM scratch) / 0
-template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() { return ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : ObsFixed<FIX>::shape.merged == 3 ? 5 : 2; }
+// (the flatland_cutils builder alone, shape.tw_t == 0: MODE 6 / 7 / 8 for the one-pass shapes, MODE 0 else)
+template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() {
+    return (ObsFixed<FIX>::shape.merged == 1 ? 3 : ObsFixed<FIX>::shape.merged == 2 ? 4 : ObsFixed<FIX>::shape.merged == 3 ? 5 : ObsFixed<FIX>::shape.tw_t == 0 ? -3 : 2) + (ObsFixed<FIX>::shape.tw_t == 0 ? 3 : 0);
+}
 template <int FIX> __host__ __device__ constexpr int obs_fixed_var() { return ObsFixed<FIX>::opt.tab ? 1 : ObsFixed<FIX>::opt.wl_bytes == 0 ? 2 : 0; }
 // The batch's own choice `a` (obs_pick_config's preference walk at the batch's sizes) is the class's kind of configuration: the same
 // structure, and of everything that is "whatever LDS the carving leaves" -- the next-hop tables, the agents' raw words, the
@@ -291,6 +343,7 @@ struct ObsArgs {
                        // kernels, which carry no code for it -- are not taken)
     int keep_rows;     // upstream tree: the output buffer still holds the previous launch's rows (FL_OBS_KEEP_TREE_ROWS and the same buffer and
                        // depth as that launch): no -inf pre-fill of the slab, only the rows that were real nodes then and are not now
+    int cutils_alone;  // host side: a launch of the flatland_cutils builder alone may take the one-pass kernels (MODE 6 / 7 / 8, classes 6 .. 10)
     int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
     int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
                        // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving
@@ -313,6 +366,16 @@ int fl_obs_launch_f2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hi
 int fl_obs_launch_f3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f4(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f5(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+// the flatland_cutils builder alone: MODE 6 / 7 / 8 (runtime carving) and its classes 6 .. 10, class 9's split kernel
+int fl_obs_launch_m6(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_m7(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_m8(int var, const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f6(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f7(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f8(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f10(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_s9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 // the same classes for a batch with larger maps among its envs (P.split): per env the class's body or the runtime-carving one
 int fl_obs_launch_s2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

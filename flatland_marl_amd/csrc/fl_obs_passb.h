@@ -266,6 +266,7 @@ __device__ __forceinline__ int team_prepare(bool have, int tl, int n_nodes, int 
 // The trees of a round: X.n_cu agents (32 on sixteen wavefronts; 16 on eight -- the 512-thread kernels, two workgroups a CU).
 template <int PB, int CAP>
 __device__ __forceinline__ int *team_table(const ObsCtx &X, int *scr0, int team_words, int team) {
+    if (PB == 3) return scr0 + team * (N_WORDS_C * 32);
     if (PB == 2) {
         const int u = team - X.n_cu;
         return u < 0 ? scr0 + team * (N_WORDS_C * 32) : scr0 + X.n_cu * (N_WORDS_C * 32) + (u >> 1) * (N_WORDS_T * 32) + (u & 1) * 16;
@@ -318,7 +319,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     int dbg_skip = 0;
 #endif
     if (pos < end) {
-        constexpr int cap = PB == 2 ? 32 : CAP;   // words between the fields of a node table
+        constexpr int cap = PB >= 2 ? 32 : CAP;   // words between the fields of a node table
         const int *vs = team_table<PB, CAP>(X, scr0, team_words, team);
         int nn = team_meta[64 + team];
         int handle = pb_handle<PB>(X, team_meta, team);
@@ -341,21 +342,19 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         bool cu;
         const unsigned long long *tmask_t = X.tmask, *tmask2_t = X.tmask_m2;
         int Tn_t = X.Tn, tshift_t = X.tshift;
-        const bool self_filter = PB == 2 && X.tmask_m2 != nullptr;
+        const bool self_filter = PB >= 2 && X.tmask_m2 != nullptr;
         const uint16_t *path_t = X.path;
         int lp_t = 0, tpc_t = 1;
         auto enter_team = [&]() __attribute__((always_inline)) {
             target = X.a_target[handle];
             cu = pb_cu<PB>(X, team);
             tq = (PB == 2 && !cu) ? X.a_tq2[handle] : X.a_tq[handle];
-            if (PB == 2) {
-                tmask_t = cu ? X.tmask : X.u_tmask; Tn_t = cu ? X.Tn : X.u_Tn; tshift_t = cu ? X.tshift : X.u_tshift;
-                if (self_filter) {
-                    tmask2_t = cu ? X.tmask_m2 : X.u_tmask_m2;
-                    path_t = X.path + (size_t)handle * X.pred_cap;
-                    lp_t = cu ? X.a_lp[handle] : X.a_lp2[handle];
-                    tpc_t = cu ? X.a_tpc[handle] : X.a_tpc2[handle];
-                }
+            if (PB == 2) { tmask_t = cu ? X.tmask : X.u_tmask; Tn_t = cu ? X.Tn : X.u_Tn; tshift_t = cu ? X.tshift : X.u_tshift; }
+            if (PB >= 2 && self_filter) {
+                tmask2_t = cu ? X.tmask_m2 : X.u_tmask_m2;
+                path_t = X.path + (size_t)handle * X.pred_cap;
+                lp_t = cu ? X.a_lp[handle] : X.a_lp2[handle];
+                tpc_t = cu ? X.a_tpc[handle] : X.a_tpc2[handle];
             }
         };
         enter_team();
@@ -396,7 +395,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
                 if (has_tmask) { tm = tmask_t[key]; if (FAST && self_filter) tm2 = tmask2_t[key]; }
                 else { c_hi = X.csr_end[key]; c_lo = key > 0 ? X.csr_end[key - 1] : 0; }
             }
-            if (PB != 1) ct = X.cell_target[cell >> 5];
+            if (PB != 1 && PB != 3) ct = X.cell_target[cell >> 5];
             if (left == 1 && nxt < nn) {  // the walk ends on this cell: descriptor of the team's next node with cells
                 n_se = (uint32_t)nt_r(vs, cap, N_SE, nxt); n_tv = (uint32_t)nt_r(vs, cap, N_TV, nxt);
                 n_inw = (uint32_t)nt_r(vs, cap, N_INCL, nxt);
@@ -490,7 +489,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
             if (!more) break;
         }
         };
-        if (PB == 2 || (X.tmask != nullptr && X.snext != nullptr && X.rkey == nullptr)) walk(std::true_type());  // PB 2: the launcher saw to it
+        if (PB >= 2 || (X.tmask != nullptr && X.snext != nullptr && X.rkey == nullptr)) walk(std::true_type());  // PB 2 / 3: the launcher saw to it
         else walk(std::false_type());
     }
 #ifdef FL_OBS_TIMING
@@ -515,7 +514,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
     for (int e = tid; e < n_occ; e += nt) {
         const uint2 w = wl_occ_get(X, e);
         const int cell = (int)((w.x & 0xFFFFFFu) >> 2), team = (int)(w.x >> 24);
-        constexpr int cap = PB == 2 ? 32 : CAP;
+        constexpr int cap = PB >= 2 ? 32 : CAP;
         int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
         occ_event(X, pb_cu<PB>(X, team), sc, cap, (int)(w.y >> 24), cw_slot(X, cell), w.x & 3u, (int)(w.y & 0xFFFFFFu));
     }
@@ -542,7 +541,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
 #else
             if (R.n > 0 && conflict_hit(conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, 0, R.n))) {
 #endif
-                constexpr int cap = PB == 2 ? 32 : CAP;
+                constexpr int cap = PB >= 2 ? 32 : CAP;
                 int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                 atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
             }
@@ -607,7 +606,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         if (e < n_cf) {
             if (np == 0) {  // nothing left to others
                 if (conflict_hit(fl)) {
-                    constexpr int cap = PB == 2 ? 32 : CAP;
+                    constexpr int cap = PB >= 2 ? 32 : CAP;
                     int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
                     atomicMin(&nt_w(sc, cap, N_PC, (int)(w.y >> 24)), tot);
                 }
@@ -635,7 +634,7 @@ __device__ __forceinline__ void wg_pass_b(const ObsCtx &X, int tid, int nt, int 
         const uint32_t f = conflict_flags<PB, ITL, TWO>(X, cu, handle, cell, w.x & 3u, pt, R, CF_FIRST + (chunk - 1) * CF_CHUNK, chunk == 62 ? R.n : min(R.n, CF_FIRST + chunk * CF_CHUNK));
         const uint32_t old = wl_cf_done(X, first, (f & 63u) << 15);
         if (((old >> 9) & 63u) == 1u && conflict_hit((old >> 15) & 63u)) {  // the last chunk of its key
-            constexpr int cap = PB == 2 ? 32 : CAP;
+            constexpr int cap = PB >= 2 ? 32 : CAP;
             int *sc = team_table<PB, CAP>(X, scr0, team_words, team);
             atomicMin(&nt_w(sc, cap, N_PC, (int)(old >> 24)), (int)(old & 511u));
         }

@@ -473,7 +473,8 @@ __device__ __forceinline__ int merged_upstream_of(int wave, int lane, int nwaves
 
 // MULTI = false: an env of at most 32 agents -- one round, whose pass A ran beside the path walk: no pass A code here.
 // ROUND = agents of a round = 2 * wavefronts of the workgroup: 32 (1024 threads) or 16 (512 threads, two workgroups a CU).
-template <bool ITL, bool MULTI, int ROUND, typename LATE>
+// UP = false: the flatland_cutils trees alone (pass B PB 3): no upstream tables, teams or rows.
+template <bool ITL, bool MULTI, int ROUND, bool UP, typename LATE>
 __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane, int nwaves,
                                              int *wave_scr, int *team_meta, const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
                                              const uint8_t *a_state, const double *a_speed, const uint16_t *a_tslot, float max_dist,
@@ -482,8 +483,8 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
     const int A = X.A;
     const int grp = lane >> 5, gl = lane & 31, ct = wave * 2 + grp;   // (ct covers 0 .. ROUND - 1)
     int *scr_c = merged_table_c(wave_scr, min(ct, ROUND - 1));
-    const int u = merged_upstream_of<ROUND>(wave, lane, nwaves), tl = lane & 15;
-    const bool wave_has_u = (nwaves - 1 - wave) * 4 < ROUND;  // wave-uniform
+    const int u = UP ? merged_upstream_of<ROUND>(wave, lane, nwaves) : -1, tl = lane & 15;
+    const bool wave_has_u = UP && (nwaves - 1 - wave) * 4 < ROUND;  // wave-uniform
     int *scr_u = merged_table_t<ROUND>(wave_scr, u < 0 ? 0 : u);
     const int ns = upstream_slots<true>(P);
     for (int base = 0; base < (MULTI ? A : 1); base += ROUND) {
@@ -511,7 +512,7 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
             const int id = ROUND + (u < 0 ? 0 : u);
             if (u >= 0 && tl == 0) { team_meta[id] = have_u ? cells : 0; team_meta[64 + id] = have_u ? ns : 1; team_meta[256 + id] = first; }
         }
-        wg_pass_b<2, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, 2 * ROUND, wave_scr, 0, team_meta, late);
+        wg_pass_b<UP ? 2 : 3, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, UP ? 2 * ROUND : ROUND, wave_scr, 0, team_meta, late);
         if (base == 0) late();  // (whatever the queue still holds)
         TREE_STAMP(X, 7);
         if (ct < ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);

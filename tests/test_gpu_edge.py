@@ -400,3 +400,16 @@ def test_builder_sizes_beyond_the_limits_are_refused_with_a_message():
     with pytest.raises(FlatlandHipError, match="more than two transitions"):
         e3.obs_tree(4, 30)
     assert e3.obs_tree(3, 30).shape[2] == 85
+    # the fused entry points raise the same error BEFORE anything runs: the envs have not advanced, no sticky deadlock bit was set
+    st0, el0 = e3.state()
+    aux0 = e3.state_aux()
+    with pytest.raises(FlatlandHipError, match="more than two transitions"):
+        e3.step_obs(seed=1, tree_depth=4, tree_pred=30)
+    with pytest.raises(FlatlandHipError, match="more than two transitions"):
+        e3.obs_both(4, 30)
+    st1, el1 = e3.state()
+    np.testing.assert_array_equal(st0, st1)
+    np.testing.assert_array_equal(el0, el1)
+    np.testing.assert_array_equal(aux0, e3.state_aux())
+    e3.step_obs(seed=1, tree_depth=3, tree_pred=30)          # a retry at depth 3 is the NEXT step, not the one after
+    assert e3.state()[1][0] == el0[0] + 1

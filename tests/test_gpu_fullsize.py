@@ -37,6 +37,9 @@ def _same(got, exp, msg):
     # four envs per CU at the north-star shape: class 5 -- 512-thread workgroups in rounds of 16 agents, two a CU (the solo runs of the
     # picks take class 1, the one-round kernel: two different kernels, the same bytes)
     ("cfg2", 1024, 90, (0, 257, 766, 1018, 1023), (3, 5, 1022), False, 0, 2, (5, 0)),
+    # THE HEADLINE LAUNCH: bench.py's cfg2 step is obs_both(2, 30) at exactly B = 256 on class 1 (k_obs<3,0,1>, one env per CU) --
+    # the launch the north-star number is quoted on, under the oracle
+    ("cfg2", 256, 120, (0, 37, 101, 200, 255), (3, 5, 254), False, 0, 2, (1, 0)),
 ])
 def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, rebuild, distinct, depth, klass):
     from flatland_marl_amd import synth, workload as wl
@@ -60,7 +63,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         if t == 0:      # which kernel builds the batch: the class, for every env (split 0) or for the envs that fit it (split 1)
             fix, split, n_fit = env.last_obs_class()
             rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
-            cap = {2: 232, 3: 680, 4: 2688, 5: 256}[klass[0]]
+            cap = {1: 256, 2: 232, 3: 680, 4: 2688, 5: 256}[klass[0]]
             assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
             if split:   # both bodies are under test: replicas on either side of the class's capacity among the picks / shadows
                 assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]

@@ -183,9 +183,9 @@ def test_bench_starts_its_own_ranks():
     assert d["dist_backend"] == "gloo" and d["device_per_rank"] == [0, 0]       # the rehearsal: both ranks on the one GPU
     A = d["config"]["agents"]
     assert d["agent_steps_per_rank"] == [8 * A * 12, 8 * A * 12] and d["agent_steps"] == 2 * 8 * A * 12
-    assert abs(d["value"] - 2 * 8 * A * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 1e-6 * d["value"]     # sum over ranks / max time
+    assert abs(d["value"] - 2 * 8 * A * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 2e-5 * d["value"]     # sum over ranks / max time (the line carries 6 significant digits)
     assert "cpu_baseline" not in d and d["scaling"] == "weak"
-    assert d["roofline"]["frac"] > 0 and "note" in d["roofline"]
+    assert d["roofline"]["frac"] > 0 and "roofline.note" in d["notes"] and len(lines[0]) < 8192
 
 
 def test_bench_two_ranks_over_rccl_on_two_gpus():
