@@ -874,6 +874,25 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
     return FL_OK;
 }
 
+int fl_obs_cutils_policy(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev, int64_t *adjacency_dev,
+                         int64_t *node_order_dev, int64_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev) {
+    NEED_COMMIT(h);
+    if (max_nodes < 4 || max_nodes > FL_OBS_MAX_NODES || pred_depth < 1 || pred_depth > FL_OBS_MAX_PRED) {
+        set_err("fl_obs_cutils_policy: max_nodes must be in [4,%d] and pred_depth in [1,%d]", FL_OBS_MAX_NODES, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (!attr_dev || !forest_dev || !adjacency_dev || !node_order_dev || !edge_order_dev || !valid_actions_dev) {
+        set_err("fl_obs_cutils_policy: null output buffer");
+        return FL_ERR_ARG;
+    }
+    int rc = fl_launch_obs_cutils(h->obs, h->d, max_nodes, pred_depth, attr_dev, forest_dev, reinterpret_cast<int32_t *>(adjacency_dev),
+                                  reinterpret_cast<int32_t *>(node_order_dev), reinterpret_cast<int32_t *>(edge_order_dev), valid_actions_dev, props_dev,
+                                  h->stream, nullptr, 1);
+    if (rc != FL_OK) { set_err("fl_obs_cutils_policy: no launch configuration: %d rail cells and %d agents per env do not fit the observation kernels' LDS (160 KiB a workgroup), or the sizes are out of range", h->d.Rcap, h->d.A); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 int fl_obs_cutils_handles(fl_batch *h, int max_nodes, int pred_depth, const int32_t *handles, int n_handles, float *attr_dev,
                           float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
                           uint8_t *valid_actions_dev, double *props_dev) {

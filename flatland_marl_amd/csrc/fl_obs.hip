@@ -286,6 +286,10 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             P.L = L;
         };
         for (int pk = 0; pk < n_prefs; pk++) {
+            // the builder alone has the room for 36 KB of LDS lists AND the items' copy on maps where both builders never had it -- but there
+            // (cfg4: 649 rail cells) every env has more items than the copy holds and the lists' entries are many: same box, runtime carving,
+            // 0.268 ms with the LDS lists against 0.261 with HBM lists behind a 16 KB LDS head.  Small maps (cfg3) keep the LDS lists.
+            if (!up && P.merged == 2 && prefs[pk].wl >= 36 * 1024 && d.Rcap > OBS_ALONE_LDS_LISTS_RCAP) continue;
             o.fb = prefs[pk].fb && P.pred_depth + 1 > 64; o.wl_bytes = prefs[pk].wl; o.items = prefs[pk].items;
             o.tab = force.tab == 1 && o.wl_bytes && nh_fit;   // diagnostic: the env's static tables in LDS too
             if ((o.fb && no_fb) || !ok(force.wl, o.wl_bytes) || !ok(force.items, o.items) || (o.items && d.A * 32 > OBS_ITEMS_LDS_CAP)) continue;
@@ -388,10 +392,11 @@ static void obs_tree_args(const FlDev &d, ObsArgs &P, int max_depth, int tree_pr
 }
 int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                          int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
-                         hipStream_t s, const int16_t *label_dev) {
+                         hipStream_t s, const int16_t *label_dev, int out64) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510 || max_nodes > FL_OBS_MAX_NODES) return FL_ERR_ARG;
     ObsArgs P = {};
     P.label = label_dev;
+    P.out64 = out64;
     P.max_nodes = max_nodes; P.pred_depth = pred_depth; P.attr = attr; P.forest = forest; P.adjacency = adjacency;
     P.node_order = node_order; P.edge_order = edge_order; P.valid = valid; P.props = props; P.dbg = o.dbg;
     P.tw_c = N_WORDS_C * (max_nodes > OBS_CAP_C ? 64 : OBS_CAP_C);   // (more than 32 nodes: 64-slot tables, one tree a wavefront)
@@ -403,8 +408,8 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     P.cutils_alone = !no_alone;
     P.wide = obs_batch_is_wide(d.B, o.n_cu);
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
-    if (!P.merged && !P.fix) P.compact_t = 0;    // (the stand-alone kernel's own pass A: teams of 32 lanes)
     const int n_split = P.label ? 0 : obs_take_split_class(d, P, o.h_R);
+    if (!P.merged && !P.fix) P.compact_t = 0;    // (the stand-alone kernel's own pass A: teams of 32 lanes)
     o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
     obs_verbose(P);
     FlObsScratch u = o;

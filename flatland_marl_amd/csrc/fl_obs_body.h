@@ -1130,11 +1130,11 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
         else trees_merged<false, MERGED >= 2, ROUND, UP>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, late_jobs, (FIX == 1 || FIX == 5 || !UP) ? nullptr : S.rowmask);
     } else if (CUTILS && STAGE == 0 && FIX == 0 && P.max_nodes > OBS_CAP_C) {
         // more than 32 nodes a tree (the stand-alone flatland_cutils launch only): a team of 64 lanes, one tree a wavefront
-        if (items_in_lds) trees_cutils<true, 64>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
-        else trees_cutils<false, 64>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
+        if (items_in_lds) trees_cutils<true, 64, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
+        else trees_cutils<false, 64, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, false);
     } else if (CUTILS) {
-        if (items_in_lds) trees_cutils<true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
-        else trees_cutils<false>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+        if (items_in_lds) trees_cutils<true, OBS_CAP_C, STAGE == 0>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
+        else trees_cutils<false, OBS_CAP_C, STAGE == 0>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, a_vpos, a_pos, a_dir, a_state, a_speed, a_tslot, max_dist, STAGE != 2 && X.Tn > 0 && X.bk_rel == nullptr);
     } else if (p_compact_t && STAGE == 0 && FIX == 0 && P.max_depth >= 4) {
         // depth 4 (341 rows): 30 compact slots, a team of 32 lanes, two trees a wavefront -- the stand-alone tree launch only
         if (items_in_lds) tree_upstream<32, 32, true, true>(X, d, P, b, wave, lane, nwaves, wave_scr, team_meta, nullptr);

@@ -191,11 +191,12 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 #define OBS_FIX3_WL_HEAD (10 * 1024)
 #define OBS_WL_HEAD_MAX (16 * 1024)   // LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
 #define OBS_WL_HEAD_MIN (4 * 1024)
+#define OBS_ALONE_LDS_LISTS_RCAP 320   // the flatland_cutils builder alone, rounds of 32 agents: LDS work lists up to this many rail cells, HBM lists with an LDS head beyond
 template <int FIX> struct ObsFixed;
 // options of the classes of the flatland_cutils builder alone: what obs_pick_config chooses at the classes' capacities (tests/test_obs_config.py)
 //                      nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap, wl_head
 #define OBS_FIX7_OPT  {OBS_NT, 36 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 0}
-#define OBS_FIX8_OPT  {OBS_NT, 36 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 0, OBS_ITEMS_LDS_CAP, 0}
+#define OBS_FIX8_OPT  {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, OBS_WL_HEAD_MAX}
 #define OBS_FIX9_OPT  {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0}
 #define OBS_FIX10_OPT {512, 16 * 1024, 0, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, OBS_ITEMS_LDS_CAP, 0}
 template <> struct ObsFixed<1> {
@@ -343,6 +344,8 @@ struct ObsArgs {
                        // kernels, which carry no code for it -- are not taken)
     int keep_rows;     // upstream tree: the output buffer still holds the previous launch's rows (FL_OBS_KEEP_TREE_ROWS and the same buffer and
                        // depth as that launch): no -inf pre-fill of the slab, only the rows that were real nodes then and are not now
+    int out64;         // launches of the flatland_cutils builder alone: adjacency / node_order / edge_order point to int64 buffers and are written as
+                       // the policy network takes them (fl_obs_cutils_policy; cutils_rows_orders)
     int cutils_alone;  // host side: a launch of the flatland_cutils builder alone may take the one-pass kernels (MODE 6 / 7 / 8, classes 6 .. 10)
     int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
     int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=

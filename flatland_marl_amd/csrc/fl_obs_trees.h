@@ -355,7 +355,10 @@ __device__ __forceinline__ void cutils_pass_a(const ObsCtx &X, const FlDev &d, c
 }
 
 // rows, adjacency and evaluation orders of one flatland_cutils tree from its node table (after pass B); lane gl of the team
-template <int TC = OBS_CAP_C>
+// I64 (the launches of the builder alone): when P.out64 is set the three index tensors are written as the POLICY takes them -- int64, the
+// adjacency's parent / child columns offset by tree * max_nodes with tree = b * A + agent, every negative entry (padding, action -1) -2 (plfActor.get_feature's casts +
+// Network.modify_adjacency, solution/plfActor.py:48-74, nn/net_tree.py:105-116) -- instead of int32 + a second kernel (fl_policy_pack).
+template <int TC = OBS_CAP_C, bool I64 = false>
 __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int i, bool have, int gl,
                                                    const int *scr, int node_base, int levels, float max_dist) {
     constexpr int CAP = TC;
@@ -363,12 +366,19 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
     const int g = b * A + (have ? i : 0);
     float *F = P.forest + (size_t)g * N * 12;
     int32_t *ADJ = P.adjacency + (size_t)g * (N - 1) * 3;
+    const bool w64 = I64 && P.out64 != 0;
+    long long *ADJ64 = reinterpret_cast<long long *>(P.adjacency) + (size_t)g * (N - 1) * 3;
+    const long long tree_off = (long long)g * N;
     if (have) {  // rows: lane gl writes node gl + 1
         for (int idx = gl + 1; idx < N; idx += TC) {
             int32_t *adj = ADJ + (size_t)(idx - 1) * 3;
+            long long *adj64 = ADJ64 + (size_t)(idx - 1) * 3;
             if (idx < node_base) {
                 const uint32_t ph = (uint32_t)nt_r(scr, CAP, N_PH, idx);
+                if (w64) { out_store(&adj64[0], tree_off + (long long)((int)(ph & 0xFFu) - 2)); out_store(&adj64[1], tree_off + (long long)idx); const int act = (int)((ph >> 8) & 3u) - 1; out_store(&adj64[2], act < 0 ? -2ll : (long long)act); }   // (adjacency[adjacency < 0] = -2 takes the action column too)
+                else {
                 out_store(&adj[0], (int32_t)((int)(ph & 0xFFu) - 2)); out_store(&adj[1], (int32_t)idx); out_store(&adj[2], (int32_t)((int)((ph >> 8) & 3u) - 1));
+                }
                 if (nt_start((uint32_t)nt_r(scr, CAP, N_SE, idx)) < 0) {
                     const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
                     scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
@@ -381,7 +391,8 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
             } else {  // padding rows when the queue ran dry (treeobs.cpp:268-276, 245-249)
                 const double nn[12] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, -1, -1, -1, -1, -1};
                 scale_and_store(nn, max_dist, A, F + (size_t)idx * 12);
-                out_store(&adj[0], (int32_t)-2); out_store(&adj[1], (int32_t)-2); out_store(&adj[2], (int32_t)-2);
+                if (w64) { out_store(&adj64[0], -2ll); out_store(&adj64[1], -2ll); out_store(&adj64[2], -2ll); }
+                else { out_store(&adj[0], (int32_t)-2); out_store(&adj[1], (int32_t)-2); out_store(&adj[2], (int32_t)-2); }
             }
         }
     }
@@ -407,7 +418,10 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
         const int hp = __shfl(h, parent < 0 ? 0 : parent, TC);
         if (have) {
             int32_t *NO = P.node_order + (size_t)g * N, *EO = P.edge_order + (size_t)g * (N - 1);
-            if (gl < N) {
+            if (gl < N && w64) {
+                out_store(reinterpret_cast<long long *>(P.node_order) + (size_t)g * N + gl, (long long)(gl < node_base ? h : -2));
+                if (gl >= 1) out_store(reinterpret_cast<long long *>(P.edge_order) + (size_t)g * (N - 1) + gl - 1, (long long)((gl >= node_base || parent < 0) ? -2 : hp));
+            } else if (gl < N) {
                 out_store(&NO[gl], (int32_t)(gl < node_base ? h : -2));
                 if (gl >= 1) out_store(&EO[gl - 1], (int32_t)((gl >= node_base || parent < 0) ? -2 : hp));
             }
@@ -416,7 +430,7 @@ __device__ __forceinline__ void cutils_rows_orders(const ObsCtx &X, const FlDev 
 }
 
 // flatland_cutils trees (treeobs.cpp:154-256): two agents per wavefront, a team of 32 lanes each
-template <bool ITL, int TC = OBS_CAP_C>
+template <bool ITL, int TC = OBS_CAP_C, bool I64 = false>
 __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, const ObsArgs &P, int b, int wave, int lane,
                                              int nwaves, int *wave_scr, int *team_meta,
                                              const uint16_t *a_vpos, const int *a_pos, const uint8_t *a_dir,
@@ -447,7 +461,7 @@ __device__ __forceinline__ void trees_cutils(const ObsCtx &X, const FlDev &d, co
         }
         wg_pass_b<1, CAP, ITL, NoLateWork, !ITL>(X, wave * 64 + lane, nwaves * 64, nwaves * TPW, wave_scr, TW, team_meta);   // (items in HBM: a query may be two pieces)
         TREE_STAMP(X, 7);
-        cutils_rows_orders<TC>(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
+        cutils_rows_orders<TC, I64>(X, d, P, b, i, have, gl, scr, node_base, levels, max_dist);
         team_sync();
         TREE_STAMP(X, 16);
     }
@@ -515,7 +529,7 @@ __device__ __forceinline__ void trees_merged(ObsCtx &X, const FlDev &d, const Ob
         wg_pass_b<UP ? 2 : 3, OBS_CAP_C, ITL, LATE, MULTI>(X, wave * 64 + lane, nwaves * 64, UP ? 2 * ROUND : ROUND, wave_scr, 0, team_meta, late);
         if (base == 0) late();  // (whatever the queue still holds)
         TREE_STAMP(X, 7);
-        if (ct < ROUND) cutils_rows_orders(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
+        if (ct < ROUND) cutils_rows_orders<OBS_CAP_C, !UP>(X, d, P, b, i_c, have_c, gl, scr_c, node_base, levels, max_dist);
         if (wave_has_u) upstream_rows<16, CT, true, 32>(X, P, b, i_u, have_u, tl, scr_u, rowmask);
         team_sync();
         TREE_STAMP(X, 16);

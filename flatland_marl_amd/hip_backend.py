@@ -26,7 +26,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_handles", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
+           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_policy", "fl_obs_cutils_handles", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
         L.fl_scores.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        if hasattr(L, "fl_obs_cutils_policy"):
+            L.fl_obs_cutils_policy.argtypes = [vp, i32, i32] + [vp] * 7
         if hasattr(L, "fl_obs_cutils_handles"):
             L.fl_obs_cutils_handles.argtypes = [vp, i32, i32, vp, i32] + [vp] * 7
         if hasattr(L, "fl_obs_set_mode"):             # (an older build loaded through bench.py --lib for a same-box A/B run has none)
@@ -386,6 +388,25 @@ class BatchedRailEnv:
                          t.empty((B, A, E), dtype=t.int64, device=self.device))
         adj, no, eo = self._pol
         policy_pack(o["adjacency"], o["node_order"], o["edge_order"], adj, no, eo)
+        return o["agent_attr"], o["forest"], adj, no, eo
+
+    def obs_policy(self):
+        """The consumer's call: the flatland_cutils observation with the index tensors as Network.forward takes them, ONE launch
+        (fl_obs_cutils_policy) -- (agents_attr f32[B,A,83], forest f32[B,A,N,12], adjacency i64[B,A,N-1,3] already modified,
+        node_order i64[B,A,N], edge_order i64[B,A,N-1]); valid_actions / props land in the obs_cutils() buffers.  Equal to
+        policy_inputs(obs_cutils()) element for element."""
+        t = self.torch
+        o = self._obs_buffers()
+        B, A, N = self.B, self.A, self.max_nodes
+        if not hasattr(self, "_pol64"):
+            self._pol64 = (t.empty((B, A, N - 1, 3), dtype=t.int64, device=self.device), t.empty((B, A, N), dtype=t.int64, device=self.device),
+                           t.empty((B, A, N - 1), dtype=t.int64, device=self.device))
+        adj, no, eo = self._pol64
+        L = lib()
+        if not hasattr(L, "fl_obs_cutils_policy"):
+            raise FlatlandHipError(1, "the loaded library has no fl_obs_cutils_policy (an older build loaded through --lib?)")
+        _chk(L.fl_obs_cutils_policy(self.h, self.max_nodes, self.pred_depth, o["agent_attr"].data_ptr(), o["forest"].data_ptr(), adj.data_ptr(),
+                                    no.data_ptr(), eo.data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
         return o["agent_attr"], o["forest"], adj, no, eo
 
     def obs_tree(self, max_depth=2, pred_depth=30):

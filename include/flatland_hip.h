@@ -187,6 +187,14 @@ int fl_obs_cutils(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, f
 int fl_obs_cutils_handles(fl_batch *h, int max_nodes, int pred_depth, const int32_t *handles, int n_handles, float *attr_dev,
                           float *forest_dev, int32_t *adjacency_dev, int32_t *node_order_dev, int32_t *edge_order_dev,
                           uint8_t *valid_actions_dev, double *props_dev);
+/* fl_obs_cutils with the three index tensors written as the POLICY NETWORK takes them, in the same launch (no fl_policy_pack pass):
+ * int64, the adjacency's parent / child columns offset by tree * max_nodes with tree = b * A + agent, every negative entry -2 (padding rows
+ * stay (-2, -2, -2); the action column's -1 becomes -2 too, as `adjacency[adjacency < 0] = -2` does) --
+ * plfActor.get_feature's casts (solution/plfActor.py:48-74) + Network.modify_adjacency (solution/nn/net_tree.py:105-116) for a batch
+ * flattened over (env, agent).  adjacency i64[B][A][max_nodes-1][3], node_order i64[B][A][max_nodes], edge_order i64[B][A][max_nodes-1];
+ * the other outputs as fl_obs_cutils'.  Equal to fl_obs_cutils + fl_policy_pack element for element (tests/test_gpu_fullsize.py). */
+int fl_obs_cutils_policy(fl_batch *h, int max_nodes, int pred_depth, float *attr_dev, float *forest_dev, int64_t *adjacency_dev,
+                         int64_t *node_order_dev, int64_t *edge_order_dev, uint8_t *valid_actions_dev, double *props_dev);
 /* upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)); pred_depth < 0: no predictor.
  * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);

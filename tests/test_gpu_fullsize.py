@@ -233,9 +233,133 @@ def test_other_launch_paths_give_the_same_bytes():
     assert _child(("FL_NO_SHARED_TABLES",), "paths", "own") == want       # one set of static tables per env instead of one per map
 
 
+# ---- the flatland_cutils builder ALONE (what the reference's solution launches: solution/eval_env.py:15-17 builds TreeCutils(31, 500) only):
+# fl_obs_cutils on the one-pass kernels without the upstream builder (MODE 6 / 7 / 8) and their fixed launch classes 6 .. 10
+CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2688, 10: 256}
+
+
+@pytest.mark.parametrize("workload,B,steps,picks,shadow,distinct,klass", [
+    ("cfg2", 256, 100, (0, 101, 255), (3, 5, 254), 0, (6, 0)),            # the bench's cfg2_cutils launch: k_obs<6,0,6>, one env per CU
+    ("cfg3", 1024, 48, (0, 766, 1023), (3, 1022), 10, (7, 0)),           # k_obs<7,0,7>
+    ("cfg4", 512, 40, (0, 256, 511), (3, 510), 4, (8, 0)),               # k_obs<7,0,8> with k_env_order
+    ("cfg5", 256, 32, (0, 85, 255), (3, 254), 0, (9, 0)),                # k_obs<0,2,9>: the stand-alone kernel with its carving compiled in
+    ("cfg5", 256, 32, (0, 85, 255), (3, 254), 2, (9, 1)),                # two levels of the row: k_obs_split<0,2,9>, both bodies
+    ("cfg2", 1024, 72, (0, 766, 1023), (3, 5, 1022), 0, (10, 0)),        # four envs a CU: k_obs<8,0,10>, two workgroups a CU
+])
+def test_cutils_alone_full_size_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, distinct, klass):
+    import torch
+    from flatland_marl_amd import synth, workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    from oracle import orc
+    envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
+    for b in range(B):
+        if b % 7 == 3:
+            envs[b] = dict(envs[b])
+            envs[b]["T"] = np.int32(17 + b % 11)
+    env = BatchedRailEnv(envs)
+    A = env.A
+    solo = {b: BatchedRailEnv([envs[b]]) for b in picks}
+    oracles = {b: orc.OracleEnv(envs[b]) for b in shadow}
+    tc = {b: 0 for b in shadow}
+    for t in range(steps):
+        rew, done, done_all = env.step_synth(seed, 0, 2 if t % 3 else 0, auto_reset=True)      # mostly shortest-path following: trains on the map
+        o = env.obs_cutils()
+        if t == 0:
+            fix, split, n_fit = env.last_obs_class()
+            rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
+            cap = CUTILS_ALONE_CAP[klass[0]]
+            assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
+            if split:
+                assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]
+        st, el = env.state()
+        check_obs = t % 6 == 0 or t == steps - 1
+        ob = {k: v.cpu().numpy() for k, v in o.items()} if check_obs else None
+        if check_obs:       # the consumer's tensors: fl_policy_pack behind the launch, and the same written BY the launch (fl_obs_cutils_policy)
+            _, _, adj, no, eo = env.policy_inputs(o)
+            a32 = o["adjacency"].to(torch.int64)
+            exp_adj = a32.clone()                       # Network.modify_adjacency (nn/net_tree.py:105-116) over the (env, agent)-flattened batch
+            exp_adj[exp_adj == -2] = -B * A * env.max_nodes
+            exp_adj[..., 0:2] += (torch.arange(B * A, device=a32.device) * env.max_nodes).view(B, A, 1, 1)
+            exp_adj[exp_adj < 0] = -2
+            assert torch.equal(adj, exp_adj) and torch.equal(no, o["node_order"].to(torch.int64)) and torch.equal(eo, o["edge_order"].to(torch.int64))
+            keep = {k: o[k].clone() for k in ("agent_attr", "forest", "valid_actions", "props")}
+            attr2, forest2, adj2, no2, eo2 = env.obs_policy()      # (idempotent on the state: the deadlock flags it sets were set by obs_cutils already)
+            assert torch.equal(adj2, adj) and torch.equal(no2, no) and torch.equal(eo2, eo), f"step {t}: fl_obs_cutils_policy != fl_obs_cutils + fl_policy_pack"
+            for k in keep:
+                assert torch.equal(o[k].view(torch.uint8), keep[k].view(torch.uint8)), (t, k)
+            assert env.last_obs_class()[:2] == klass
+        for b, s_env in solo.items():
+            s_rew, _, _ = s_env.step_synth(seed, b, 2 if t % 3 else 0, auto_reset=True)
+            s_o = s_env.obs_cutils()
+            _same(s_env.state()[0][0], st[b], f"replica {b} step {t} state")
+            if check_obs:
+                for key, _ in CUTILS:
+                    _same(s_o[key].cpu().numpy()[0], ob[key][b], f"replica {b} step {t} {key}")
+        for b, orc_env in oracles.items():
+            if t % 3:
+                dm = orc_env.distance_map()
+                s_o = orc_env.state()
+                acts = synth.spfollow_actions(seed, b, tc[b], s_o[:, 3], s_o[:, 0:2], s_o[:, 2], np.asarray(envs[b]["grid"]), *dm)
+            else:
+                acts = synth.uniform_actions(seed, b, tc[b], A)
+            r_o, d_o, da = orc_env.step(acts)
+            tc[b] += 1
+            _same(st[b], orc_env.state(), f"oracle replica {b} step {t} state")
+            exp = orc_env.obs_cutils(31, 500)
+            if check_obs:
+                for key, okey in CUTILS:
+                    _same(ob[key][b], exp[okey], f"oracle replica {b} step {t} {key}")
+            if da:
+                key, pos = orc_env.get_rng()
+                oracles[b] = orc.OracleEnv(envs[b])
+                oracles[b].set_rng(key, pos)
+                tc[b] = 0
+    env.check()
+    assert (env.state()[0][:, :, 0] >= 0).sum() > B      # trains are on the maps
+    for s_env in solo.values():
+        s_env.check()
+
+
+def _cutils_digest(workload, B, distinct, steps, want_class):
+    import hashlib
+    from flatland_marl_amd import workload as wl
+    from flatland_marl_amd.hip_backend import BatchedRailEnv
+    envs, seed = wl.make_envs(workload, B=B, distinct=distinct)
+    env = BatchedRailEnv(envs)
+    h = hashlib.sha256()
+    for t in range(steps):
+        env.step_synth(seed, 0, 2, auto_reset=True)
+        o = env.obs_cutils()
+        assert env.last_obs_class()[:2] == tuple(want_class), (workload, env.last_obs_class(), want_class)
+        h.update(env.state()[0].tobytes())
+        for k in sorted(o):
+            h.update(o[k].cpu().numpy().tobytes())
+    env.check()
+    return h.hexdigest()
+
+
+CUTILS_CASES = {"cfg2": dict(workload="cfg2", B=16, distinct=4, steps=80), "cfg3": dict(workload="cfg3", B=24, distinct=3, steps=60),
+                "cfg4": dict(workload="cfg4", B=12, distinct=4, steps=40), "cfg5": dict(workload="cfg5", B=4, distinct=2, steps=24)}
+CUTILS_CLASS_OF = {"cfg2": (6, 0), "cfg3": (7, 0), "cfg4": (8, 0), "cfg5": (9, 1)}
+
+
+def test_cutils_alone_other_launch_paths_give_the_same_bytes():
+    """fl_obs_cutils three ways (switches read once per process, hence children): the default (one-pass kernels + classes 6 .. 9), the
+    one-pass kernels with the runtime carving (FL_OBS_NO_FIX: MODE 6 / 7, MODE 0 at cfg5) and the stand-alone kernel every round before
+    this one ran (FL_OBS_NO_CUTILS_MERGE: k_obs<0,*>, 32-lane pass A teams, no own-path filter).  Same bytes."""
+    want = {k: _cutils_digest(want_class=CUTILS_CLASS_OF[k], **kw) for k, kw in CUTILS_CASES.items()}
+    assert _child(("FL_OBS_NO_FIX",), "cutils", "nofix") == want
+    assert _child(("FL_OBS_NO_CUTILS_MERGE",), "cutils", "alone") == want
+
+
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "paths":
+    if len(sys.argv) > 1 and sys.argv[1] == "cutils":
+        for k, kw in CUTILS_CASES.items():
+            # without the one-pass kernels only the large-map class (MODE 0 anyway) still applies
+            klass = (0, 0) if sys.argv[2] == "nofix" else (CUTILS_CLASS_OF[k] if k == "cfg5" else (0, 0))
+            print("DIGEST", k, _cutils_digest(want_class=klass, **kw))
+    elif len(sys.argv) > 1 and sys.argv[1] == "paths":
         for k, kw in CASES.items():
             # rounds of 16 agents apply to envs of more than 32 agents only: cfg2 keeps its class there
             klass = CLASS_OF[k] if sys.argv[2] == "own" else (0, 0) if sys.argv[2] == "0" or k == "cfg3" else CLASS_OF[k]
