@@ -123,7 +123,7 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
           P.tw_c == F::shape.tw_c && P.tw_t == F::shape.tw_t && P.tpw_t == F::shape.tpw_t)) return false;
     if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return false;
     // the class's kernel has the builders' parameters compiled in
-    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return false;
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || (F::max_depth != 0 && P.max_depth != F::max_depth)) return false;
     if (F::agents != 0 && d.A != F::agents) return false;
     // ... and what the launcher derives from the options (the kernel has the class's values: obs_fixed_* in fl_obs_layout.h)
     if (!P.compact_t || P.bk != obs_fixed_bk<FIX>() || P.wl_occ_div != obs_fixed_wl_occ_div<FIX>() || P.tshift != obs_fixed_tshift<FIX>(d.A)) return false;
@@ -133,8 +133,51 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
     L.total = (unsigned)total;
     return true;
 }
+// A BIN class (round 6): the batch fits the class's capacities, the call has the class's builder parameters (the depth is the call's) and the
+// batch's own choice has the class's STRUCTURE (one round / rounds of 32 agents / two stages) -- the class's options then replace the batch's
+// own: a compile-time carving with the options of the bin's largest shape instead of the runtime carving with options chosen for this one
+// (per shape of the Round-2 table: profiles/r06_round2_classes.txt).  FL_OBS_NO_BINS: exact classes only.
+template <int FIX> static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R);
+template <int FIX>
+static bool obs_fits_bin(const FlDev &d, ObsArgs &P, ObsLayout &L) {
+    using F = ObsFixed<FIX>;
+    if (F::opt.wl_head && obs_no_wl_head()) return false;
+    if (P.label || !P.compact_t || (d.rkey != nullptr) != (F::dims.rkey != 0) || d.A > F::dims.A || d.Rcap > F::dims.Rcap) return false;
+    if (P.merged != F::shape.merged || P.tw_c != F::shape.tw_c || P.tw_t != F::shape.tw_t || P.tpw_t != F::shape.tpw_t) return false;
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || (F::max_depth != 0 && P.max_depth != F::max_depth)) return false;
+    if (F::shape.tw_t != 0 && (P.max_depth < 1 || P.max_depth > 3)) return false;
+    if (FIX == 11 && P.keep_mode) return false;   // (class 1's code: no row masks)
+    if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return false;
+    if (F::shape.merged != 0 && (long long)d.A * (P.pred_depth + 2) >= 65536) return false;
+    const size_t nh_bytes = F::opt.nh ? (((size_t)d.Ucap * d.Rcap * 2 + 15) & ~(size_t)15) : 0;
+    const size_t total = F::opt.nh ? F::L.off[L_NH] + nh_bytes : F::L.total;
+    if (total > (size_t)160 * 1024) return false;
+    // what the launcher derives from the options: the class's values (its kernel has them compiled in)
+    P.use_tmask = F::opt.tmask; P.dual_index = F::opt.dual; P.bk = obs_fixed_bk<FIX>();
+    P.bk_nb = F::shape.merged != 0 ? OBS_FB_NB : OBS_BK_NB; P.bk_shift = F::shape.merged != 0 ? OBS_FB_SHIFT : OBS_BK_SHIFT;
+    P.wl_occ_div = obs_fixed_wl_occ_div<FIX>(); P.tshift = obs_fixed_tshift<FIX>(d.A);
+    L = F::L;
+    L.total = (unsigned)total;
+    return true;
+}
+// an exact class's SPLIT launch (its body for the envs that fit, the runtime carving for the few larger maps) goes before a bin class for the
+// whole batch when at least half the envs fit the exact class
+static bool g_fix_allowed;
+template <int FIX>
+static bool exact_split_covers_most(const FlDev &d, ObsArgs &P, const ObsLayout &L) {
+    static const bool no_split = getenv("FL_OBS_NO_SPLIT") != nullptr;
+    if (no_split || !P.h_R) return false;
+    const ObsLayout keep = P.L;
+    const bool keep_allowed = g_fix_allowed;
+    P.L = L;
+    const int n = obs_split_fits<FIX>(d, P, P.h_R);
+    P.L = keep;
+    g_fix_allowed = keep_allowed;
+    return 2 * n >= d.B;
+}
 static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o, ObsLayout &L, bool allowed) {
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;   // diagnostic: the runtime carving for every batch
+    static const bool no_bins = getenv("FL_OBS_NO_BINS") != nullptr;  // diagnostic: exact classes only (the launcher of rounds 4 and 5)
     P.fix = 0; P.split = 0;
     if (no_fix || !allowed) return;
     if (P.tw_t == 0) {   // the flatland_cutils builder alone: classes 6 .. 10 (the counterparts of 1 .. 5)
@@ -143,6 +186,13 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
         else if (obs_fits_fixed<8>(d, P, o, L)) P.fix = 8;
         else if (obs_fits_fixed<9>(d, P, o, L)) P.fix = 9;
         else if (obs_fits_fixed<10>(d, P, o, L)) P.fix = 10;
+        else if (no_bins || !P.cutils_alone) return;   // (FL_OBS_NO_CUTILS_MERGE: the stand-alone kernel as it ran before round 6)
+        else if (obs_fits_bin<17>(d, P, L)) P.fix = 17;
+        else if (obs_fits_bin<8>(d, P, L)) P.fix = 8;
+        else if (obs_fits_bin<18>(d, P, L)) P.fix = 18;
+        else if (obs_fits_bin<9>(d, P, L)) P.fix = 9;
+        else if (obs_fits_bin<19>(d, P, L)) P.fix = 19;
+        else if (obs_fits_bin<20>(d, P, L)) P.fix = 20;
         return;
     }
     if (obs_fits_fixed<1>(d, P, o, L)) P.fix = 1;
@@ -150,9 +200,18 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
     else if (obs_fits_fixed<3>(d, P, o, L)) P.fix = 3;
     else if (obs_fits_fixed<4>(d, P, o, L)) P.fix = 4;
     else if (obs_fits_fixed<5>(d, P, o, L)) P.fix = 5;
+    else if (no_bins) return;
+    else if (exact_split_covers_most<2>(d, P, L) || exact_split_covers_most<3>(d, P, L)) return;   // (obs_take_split_class takes it)
+    else if (obs_fits_bin<11>(d, P, L)) P.fix = 11;
+    else if (obs_fits_bin<12>(d, P, L)) P.fix = 12;
+    else if (obs_fits_bin<13>(d, P, L)) P.fix = 13;
+    else if (obs_fits_bin<15>(d, P, L)) P.fix = 15;
+    else if (obs_fits_bin<4>(d, P, L)) P.fix = 4;
+    else if (obs_fits_bin<14>(d, P, L)) P.fix = 14;
+    else if (obs_fits_bin<16>(d, P, L)) P.fix = 16;
 }
 
-static bool g_fix_allowed = false;  // the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
+// (defined above) g_fix_allowed: the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
 // A batch whose LARGEST map exceeds a class's rail cells still has the class's kind of envs in it (the levels of a Round-2 test differ
 // by a few per cent in rail cells; the classes are the BASELINE maps' own sizes): when everything but the rail-cell capacity matches
 // -- agents, builder parameters, and the runtime configuration just chosen for the batch runs the class's MODE and VAR -- the launch
@@ -165,7 +224,7 @@ static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R) {
     if (F::opt.wl_head && obs_no_wl_head()) return 0;
     if (!h_R || F::opt.nh) return 0;   // (class 1 keeps the next-hop tables, sized by the batch, behind its carving: not split)
     if ((F::agents != 0 ? d.A != F::agents : d.A > F::dims.A) || d.rkey != nullptr || !P.compact_t) return 0;
-    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || P.max_depth != F::max_depth) return 0;
+    if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || (F::max_depth != 0 && P.max_depth != F::max_depth)) return 0;
     if (P.merged != F::shape.merged || obs_var(P) != obs_fixed_var<FIX>() || P.L.nt != F::opt.nt) return 0;
     if (P.tw_c != F::shape.tw_c || P.tw_t != F::shape.tw_t || P.tpw_t != F::shape.tpw_t) return 0;
     if (F::opt.dual && (size_t)d.A * (P.tree_pred + 2) > (size_t)F::L.items2_cap) return 0;
@@ -176,7 +235,19 @@ static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R) {
 }
 static int obs_take_split_class(const FlDev &d, ObsArgs &P, const int *h_R) {
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr, no_split = getenv("FL_OBS_NO_SPLIT") != nullptr;   // diagnostic
-    if (no_fix || no_split || !g_fix_allowed || P.fix != 0) return 0;
+    if (no_fix || no_split || !g_fix_allowed) return 0;
+    if (P.fix == 14 || P.fix == 19) {
+        // the larger large-map bin (no LDS successor table) was taken because of the batch's largest map: the envs that fit the smaller class
+        // (with the table) run ITS body, the others the bin's -- one kernel, every env on a compile-time carving (split 2)
+        const int fix2 = P.fix;
+        P.fix = 0;
+        const int n2 = fix2 == 14 ? obs_split_fits<4>(d, P, h_R) : obs_split_fits<9>(d, P, h_R);
+        const unsigned t2 = fix2 == 14 ? ObsFixed<4>::L.total : ObsFixed<9>::L.total;
+        if (n2 > 0) { P.fix = fix2 == 14 ? 4 : 9; P.split = 2; if (t2 > P.L.total) P.L.total = t2; return n2; }
+        P.fix = fix2;
+        return 0;
+    }
+    if (P.fix != 0) return 0;
     int n = 0, k = 0;
     unsigned total = 0;
     if (P.tw_t == 0) {   // the flatland_cutils builder alone: the large-map class has a split kernel (the levels of cfg5's row differ by 13 % in rail cells)
@@ -415,8 +486,13 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     FlObsScratch u = o;
     if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
     else u = fl_obs_env_order(o, d, s);
+    if (P.split == 2) return P.fix == 9 ? fl_obs_launch_s9b(d, u, P, s) : FL_ERR_ARG;
     if (P.split) return P.fix == 9 ? fl_obs_launch_s9(d, u, P, s) : FL_ERR_ARG;
     switch (P.fix) {
+    case 17: return fl_obs_launch_f17(d, u, P, s);
+    case 18: return fl_obs_launch_f18(d, u, P, s);
+    case 19: return fl_obs_launch_f19(d, u, P, s);
+    case 20: return fl_obs_launch_f20(d, u, P, s);
     case 6: return fl_obs_launch_f6(d, u, P, s);
     case 7: return fl_obs_launch_f7(d, u, P, s);
     case 8: return fl_obs_launch_f8(d, u, P, s);
@@ -440,6 +516,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     obs_tree_args(d, P, max_depth, tree_pred, tree_out);
     P.wide = obs_batch_is_wide(d.B, o.n_cu);
     P.keep_mode = o.keep_rows;
+    P.h_R = o.h_R;
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;
     // FL_OBS_KEEP_TREE_ROWS: the row masks of the previous launch describe this very buffer at this depth -> no pre-fill of the slab
     P.keep_rows = o.keep_rows && o.rows_out == tree_out && o.rows_depth == max_depth;
@@ -453,6 +530,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     FlObsScratch u = o;
     if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
     else u = fl_obs_env_order(o, d, s);
+    if (P.split == 2) return P.fix == 4 ? fl_obs_launch_s4b(d, u, P, s) : FL_ERR_ARG;
     if (P.split) {   // the class for the envs that fit it, the runtime carving for the others: one kernel, the choice per workgroup
         switch (P.fix) {
         case 2: return fl_obs_launch_s2(d, u, P, s);
@@ -467,6 +545,12 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     case 3: return fl_obs_launch_f3(d, u, P, s);
     case 4: return fl_obs_launch_f4(d, u, P, s);
     case 5: return fl_obs_launch_f5(d, u, P, s);
+    case 11: return fl_obs_launch_f11(d, u, P, s);
+    case 12: return fl_obs_launch_f12(d, u, P, s);
+    case 13: return fl_obs_launch_f13(d, u, P, s);
+    case 14: return fl_obs_launch_f14(d, u, P, s);
+    case 15: return fl_obs_launch_f15(d, u, P, s);
+    case 16: return fl_obs_launch_f16(d, u, P, s);
     default: break;
     }
     return P.merged == 1 ? fl_obs_launch_m3(obs_var(P), d, u, P, s) : P.merged == 2 ? fl_obs_launch_m4(obs_var(P), d, u, P, s) :

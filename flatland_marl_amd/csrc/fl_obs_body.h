@@ -50,8 +50,10 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
     if (FIX != 0) {
         P_local.max_nodes = FixT::max_nodes; P_local.pred_depth = FixT::pred_depth; P_local.tree_pred = FixT::shape.tree_pred;
         P_local.tshift = obs_fixed_tshift<FIX != 0 ? FIX : 1>(d.A);
-        P_local.max_depth = FixT::max_depth;
-        P_local.n_tree_nodes = FixT::max_depth == 2 ? 21 : 85;   // (4^(depth + 1) - 1) / 3
+        if (FixT::max_depth != 0) {   // (0: the call's depth -- a class for a bin of shapes, or the flatland_cutils builder alone)
+            P_local.max_depth = FixT::max_depth;
+            P_local.n_tree_nodes = FixT::max_depth == 2 ? 21 : 85;   // (4^(depth + 1) - 1) / 3
+        }
     }
     const ObsArgs &P = P_local;
     constexpr bool TAB_LDS = (VAR & 1) != 0, WL_HBM = (VAR & 2) != 0;
@@ -1192,9 +1194,10 @@ __global__ __launch_bounds__(OBS_NT) void k_obs(FlDev d, FlObsScratch S, ObsArgs
 // A batch whose largest map exceeds a class's rail cells (P.split): the workgroup looks at ITS env -- the class's body (compile-time
 // carving) when the env fits the class, the runtime-carving body (P.L) otherwise; one launch, one order of the workgroups.  The
 // class's capacities bound what its carving holds per env (R, K <= dims.Rcap); the HBM strides are the batch's (d.Rcap) either way.
-template <int MODE, int VAR, int FIX>
+// FIX2 != 0 (P.split 2): the other envs run the larger bin class FIX2 (same MODE and VAR) instead of the runtime carving.
+template <int MODE, int VAR, int FIX, int FIX2 = 0>
 __global__ __launch_bounds__(OBS_NT) void k_obs_split(FlDev d, FlObsScratch S, ObsArgs P) {
     const int b = (MODE == 3 || MODE == 6) ? (int)blockIdx.x : obs_env_of_workgroup(S);
     if (d.R[b] <= ObsFixed<FIX>::dims.Rcap) obs_kernel_body<MODE, VAR, FIX>(d, S, P);
-    else obs_kernel_body<MODE, VAR, 0>(d, S, P);
+    else obs_kernel_body<MODE, VAR, FIX2>(d, S, P);
 }

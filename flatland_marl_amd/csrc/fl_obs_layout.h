@@ -193,6 +193,11 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 #define OBS_WL_HEAD_MIN (4 * 1024)
 #define OBS_ALONE_LDS_LISTS_RCAP 320   // the flatland_cutils builder alone, rounds of 32 agents: LDS work lists up to this many rail cells, HBM lists with an LDS head beyond
 template <int FIX> struct ObsFixed;
+// EXACT classes (1, 2, 3, 5, 6, 7, 10) are BASELINE configurations down to the number of agents and the upstream depth -- constants in their
+// kernels.  BIN classes (round 6) keep the compile-time carving but take the agents as an upper bound (dims.A, `agents` 0) and the depth from
+// the call (`max_depth` 0): same-box cost against the exact class 3 % at cfg3, 1.7 % at cfg4, nothing measurable at cfg5 and for the builder
+// alone (runtime carving: 7 - 8 %) -- so 4, 8, 9 are bins themselves and 2, 3, 7 have bin twins (12, 13, 17); 11 = class 1 at any depth;
+// 14 / 19 = the large-map classes without the LDS successor table: 432 agents / 3 072 rail cells (Test_14; the larger levels of cfg5's row).
 // options of the classes of the flatland_cutils builder alone: what obs_pick_config chooses at the classes' capacities (tests/test_obs_config.py)
 //                      nt, wl_bytes, tab, nh, tmask, dual, items, snext, partial, bk_room, own_filter, fb, raw, items_cap, wl_head
 #define OBS_FIX7_OPT  {OBS_NT, 36 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 0}
@@ -233,8 +238,8 @@ template <> struct ObsFixed<3> {
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<4> {
-    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 3;   // the builders' parameters of the class (tree_pred: shape)
-    static constexpr int agents = 400;   // agents per env, exactly (0 = any number up to dims.A)
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;   // (a bin: the call's depth, 1 .. 3)
+    static constexpr int agents = 0;   // agents per env, exactly (0 = any number up to dims.A)
     static constexpr ObsDims dims = {2688, 400, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
@@ -272,7 +277,7 @@ template <> struct ObsFixed<7> {   // 80 agents, at most 232 rail cells, rounds 
 };
 template <> struct ObsFixed<8> {   // 80 agents, at most 680 rail cells, rounds of 32 agents (cfg4: every level of the Round-2 row)
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
-    static constexpr int agents = 80;
+    static constexpr int agents = 0;
     static constexpr ObsDims dims = {OBS_FIX3_RCAP, 80, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
     static constexpr ObsOptions opt = OBS_FIX8_OPT;
@@ -280,7 +285,7 @@ template <> struct ObsFixed<8> {   // 80 agents, at most 680 rail cells, rounds 
 };
 template <> struct ObsFixed<9> {   // 400 agents, at most 2688 rail cells: the stand-alone kernel (MODE 0, VAR 2) with its carving compiled in (cfg5)
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
-    static constexpr int agents = 400;
+    static constexpr int agents = 0;
     static constexpr ObsDims dims = {2688, 400, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
     static constexpr ObsOptions opt = OBS_FIX9_OPT;
@@ -294,11 +299,69 @@ template <> struct ObsFixed<10> {   // class 6's envs in rounds of 16 agents on 
     static constexpr ObsOptions opt = OBS_FIX10_OPT;
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
+// ---- bin classes (see above): twins of exact classes with the agents as an upper bound and the call's depth, and the larger large-map classes
+template <> struct ObsFixed<11> : ObsFixed<1> { static constexpr int max_depth = 0; };
+template <> struct ObsFixed<12> : ObsFixed<2> { static constexpr int max_depth = 0, agents = 0; };
+template <> struct ObsFixed<13> : ObsFixed<3> { static constexpr int max_depth = 0, agents = 0; };
+template <> struct ObsFixed<17> : ObsFixed<7> { static constexpr int agents = 0; };
+#define OBS_FIXB_RCAP 3072
+#define OBS_FIXB_A 432
+template <> struct ObsFixed<14> {   // both builders, two stages, no LDS successor table: at most 432 agents / 3 072 rail cells, any depth
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {OBS_FIXB_RCAP, OBS_FIXB_A, 0, 0};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+// 15 / 18: rounds of 32 agents on maps beyond class 3's: at most 100 agents / 1 280 rail cells (Test_9, Test_10), HBM work lists
+template <> struct ObsFixed<15> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {1280, 100, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 4096, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<18> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {1280, 100, 0, 0};
+    static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 10 * 1024};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+// 16 / 20: maps TALLER than wide (the reference's prediction key col * W + row collides there, tool.h:391-398: compact keys in LDS, L_RKEY;
+// never the one-pass kernels) -- Test_3 (35 x 30), Test_6 (60 x 40), Test_9 (120 x 80): two stages, at most 100 agents / 1 280 rail cells
+template <> struct ObsFixed<16> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {1280, 100, 0, 1};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
+    static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<20> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {1280, 100, 0, 1};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = {OBS_NT, 24 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+template <> struct ObsFixed<19> {   // the flatland_cutils builder alone, the same capacities
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {OBS_FIXB_RCAP, OBS_FIXB_A, 0, 0};
+    static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
 // what obs_pick_config derives from a class's options for ObsArgs: ONE definition for the kernel (which has them as constants) and
 // for the host (obs_fits_fixed only takes the class when its own derivation for the batch gives the same values)
 template <int FIX> __host__ __device__ constexpr int obs_fixed_bk() { return ObsFixed<FIX>::shape.merged != 0 ? (ObsFixed<FIX>::opt.fb ? 2 : 0) : ObsFixed<FIX>::opt.bk_room; }
-template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (FIX == 2 || FIX == 3 || FIX == 7 || FIX == 8) ? 3 : OBS_WL_OCC_DIV; }
-template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return (FIX == 1 || FIX == 5 || FIX == 6 || FIX == 10) ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_wl_occ_div() { return (ObsFixed<FIX>::shape.merged != 0 && ObsFixed<FIX>::dims.A > 32) ? 3 : OBS_WL_OCC_DIV; }
+template <int FIX> __host__ __device__ constexpr int obs_fixed_tshift(int A) { return (ObsFixed<FIX>::shape.merged != 0 && ObsFixed<FIX>::dims.A <= 32) ? (A <= 31 ? 2 : OBS_TSHIFT) : OBS_TSHIFT; }
 // kernel of a class: MODE 3 (one round) / 4 (rounds of 32 agents) / 2 (two stages), VAR 1 (static tables in LDS) / 2 (work lists in HBM scratch) / 0
 // (the flatland_cutils builder alone, shape.tw_t == 0: MODE 6 / 7 / 8 for the one-pass shapes, MODE 0 else)
 template <int FIX> __host__ __device__ constexpr int obs_fixed_mode() {
@@ -348,7 +411,8 @@ struct ObsArgs {
                        // the policy network takes them (fl_obs_cutils_policy; cutils_rows_orders)
     int cutils_alone;  // host side: a launch of the flatland_cutils builder alone may take the one-pass kernels (MODE 6 / 7 / 8, classes 6 .. 10)
     int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
-    int split;         // fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
+    const int *h_R;    // host side: the envs' rail cells (FlObsScratch::h_R; null: unknown) -- an exact class's split launch goes before the bin classes
+    int split;         // (2: as 1, but the envs that do not fit run the larger bin class 14 / 19 -- every env on a compile-time carving.)  1: fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
                        // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving
                        // body with L below; 0: every env of the launch fits the class
     ObsLayout L;       // LDS carving of this launch (host-side obs_layout; the kernel only follows it -- or, fix != 0, has the same
@@ -379,6 +443,19 @@ int fl_obs_launch_f8(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hi
 int fl_obs_launch_f9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f10(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+// bin classes (round 6) and the large-map split kernels whose second body is the larger bin class (P.split 2) instead of the runtime carving
+int fl_obs_launch_f11(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f12(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f13(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f14(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f15(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f18(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f16(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f20(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f17(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f19(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_s4b(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_s9b(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 // the same classes for a batch with larger maps among its envs (P.split): per env the class's body or the runtime-carving one
 int fl_obs_launch_s2(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s3(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

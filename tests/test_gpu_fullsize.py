@@ -22,14 +22,15 @@ def _same(got, exp, msg):
 
 # fixed launch class of every case (fl_obs_layout.h ObsFixed<k>; BatchedRailEnv.last_obs_class): `klass` = (class, split) of the full
 # batch's launch -- split 1: the batch's largest map exceeds the class's rail cells, the class's body builds the envs that fit it and
-# the runtime-carving body of the same kernel the others (k_obs_split), so those cases cover BOTH bodies at shard size.
+# the runtime-carving body of the same kernel the others (k_obs_split), so those cases cover BOTH bodies at shard size; split 2 (round 6,
+# large maps): the others run the larger bin class's body (14 / 19: no LDS successor table) -- every env on a compile-time carving.
 @pytest.mark.parametrize("workload,B,steps,picks,shadow,rebuild,distinct,depth,klass", [
     # (replicas with b % 7 == 3 have short episodes: 3, 766, 1018 / 3, 255 restart inside the window)
     ("cfg3", 1024, 60, (0, 257, 766, 1018, 1023), (3, 1022), False, 10, 3, (2, 0)),
     # the per-GPU shard of cfg4 as the bench runs it: rounds of 32 agents, pass-B work lists in HBM scratch (per-env stride) AND
     # the longest-first workgroup order of k_env_order (more envs than CUs)
     ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 4, 2, (3, 0)),      # (class 3 holds every level of the row: 603 .. 677 rail cells)
-    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3, (4, 1)),
+    ("cfg5", 256, 40, (0, 85, 170, 255), (3, 254), True, 2, 3, (4, 2)),      # (split 2: class 4's body / bin class 14's for the 3 025-cell level)
     # the SINGLE-map shards of bench.py's EXTRA_WORKLOADS and of the profiles of record: every env fits its class -- k_obs<4,2,3>
     # with k_env_order and the per-env HBM work-list stride at B = 512, k_obs<2,2,4> with the masked rebuild at B = 256
     ("cfg4", 512, 40, (0, 129, 255, 256, 500, 511), (3, 510), False, 0, 2, (3, 0)),
@@ -209,12 +210,15 @@ def test_workgroup_order_and_the_split_of_a_launch_do_not_change_the_results_at_
     """The cfg4 shard on four levels of its Round-2 row plus a larger map (695 rail cells, beyond class 3's 680) in every seventh env:
     the default launch is the class's SPLIT kernel (class body / runtime-carving body per env) with the envs handed to the
     workgroups longest first by k_env_order (B > CUs).  FL_OBS_NO_ORDER (read once per process, hence the children) makes workgroup
-    k build env k; FL_OBS_NO_SPLIT runs every env on the runtime-carving kernel k_obs<4,2,0>; FL_OBS_NO_WL_HEAD keeps every
-    work-list entry in HBM scratch (no LDS head; the class then does not apply either).  Same bytes all four ways."""
+    k build env k; FL_OBS_NO_SPLIT / FL_OBS_NO_WL_HEAD (no LDS head of the HBM lists: class 3 does not apply) run every env on bin class 15,
+    with FL_OBS_NO_BINS on the runtime-carving kernel k_obs<4,2,0>.  Same bytes all five ways."""
     want = _cfg4_digest(want_class=(3, 1), big=True)
     assert _child(("FL_OBS_NO_ORDER",), "cfg4", "3", "1") == {"cfg4": want}
-    assert _child(("FL_OBS_NO_SPLIT",), "cfg4", "0", "0") == {"cfg4": want}
-    assert _child(("FL_OBS_NO_WL_HEAD",), "cfg4", "0", "0") == {"cfg4": want}
+    # round 6: without the split (or without LDS heads, which class 3 has) the whole batch takes BIN class 15 (rounds of 32 agents, at most
+    # 100 agents / 1 280 rail cells, HBM lists without a head) -- k_obs<4,2,15> at shard size; without the bins too: the runtime carving
+    assert _child(("FL_OBS_NO_SPLIT",), "cfg4", "15", "0") == {"cfg4": want}
+    assert _child(("FL_OBS_NO_WL_HEAD",), "cfg4", "15", "0") == {"cfg4": want}
+    assert _child(("FL_OBS_NO_SPLIT", "FL_OBS_NO_BINS"), "cfg4", "0", "0") == {"cfg4": want}
 
 
 CASES = {"cfg3": dict(steps=60, workload="cfg3", B=24, distinct=3, depth=3), "cfg2": dict(steps=80, workload="cfg2", B=16, distinct=4, depth=2)}
@@ -243,7 +247,7 @@ CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2688, 10: 256}
     ("cfg3", 1024, 48, (0, 766, 1023), (3, 1022), 10, (7, 0)),           # k_obs<7,0,7>
     ("cfg4", 512, 40, (0, 256, 511), (3, 510), 4, (8, 0)),               # k_obs<7,0,8> with k_env_order
     ("cfg5", 256, 32, (0, 85, 255), (3, 254), 0, (9, 0)),                # k_obs<0,2,9>: the stand-alone kernel with its carving compiled in
-    ("cfg5", 256, 32, (0, 85, 255), (3, 254), 2, (9, 1)),                # two levels of the row: k_obs_split<0,2,9>, both bodies
+    ("cfg5", 256, 32, (0, 85, 255), (3, 254), 2, (9, 2)),                # two levels of the row: k_obs_split<0,2,9,19>, both class bodies
     ("cfg2", 1024, 72, (0, 766, 1023), (3, 5, 1022), 0, (10, 0)),        # four envs a CU: k_obs<8,0,10>, two workgroups a CU
 ])
 def test_cutils_alone_full_size_replicas_equal_solo_runs_and_the_oracle(workload, B, steps, picks, shadow, distinct, klass):
@@ -340,7 +344,7 @@ def _cutils_digest(workload, B, distinct, steps, want_class):
 
 CUTILS_CASES = {"cfg2": dict(workload="cfg2", B=16, distinct=4, steps=80), "cfg3": dict(workload="cfg3", B=24, distinct=3, steps=60),
                 "cfg4": dict(workload="cfg4", B=12, distinct=4, steps=40), "cfg5": dict(workload="cfg5", B=4, distinct=2, steps=24)}
-CUTILS_CLASS_OF = {"cfg2": (6, 0), "cfg3": (7, 0), "cfg4": (8, 0), "cfg5": (9, 1)}
+CUTILS_CLASS_OF = {"cfg2": (6, 0), "cfg3": (7, 0), "cfg4": (8, 0), "cfg5": (9, 2)}
 
 
 def test_cutils_alone_other_launch_paths_give_the_same_bytes():
@@ -356,8 +360,9 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "cutils":
         for k, kw in CUTILS_CASES.items():
-            # without the one-pass kernels only the large-map class (MODE 0 anyway) still applies
-            klass = (0, 0) if sys.argv[2] == "nofix" else (CUTILS_CLASS_OF[k] if k == "cfg5" else (0, 0))
+            # without the one-pass kernels (and the bins, which go with them) only the large-map class (MODE 0 anyway) still applies: its body
+            # for the envs that fit, the runtime carving for the 3 025-cell level (split 1)
+            klass = (0, 0) if sys.argv[2] == "nofix" else ((9, 1) if k == "cfg5" else (0, 0))
             print("DIGEST", k, _cutils_digest(want_class=klass, **kw))
     elif len(sys.argv) > 1 and sys.argv[1] == "paths":
         for k, kw in CASES.items():

@@ -39,8 +39,14 @@ def _sizes(workload):
     ("cfg2", 2, dict(nt=1024, wl=24576, tmask=3, dual=1, items=4096, merged=1, compact=1, fix=1)),
     ("cfg3", 3, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=2)),
     ("cfg4", 2, dict(nt=1024, wl=0, tmask=3, dual=1, items=0, merged=2, compact=1, fix=3)),      # (round 5: no LDS copy of the items, an LDS head of the HBM lists)
-    ("cfg3", 2, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=0)),   # not BASELINE's depth: runtime carving
-    ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=0)),
+    ("cfg3", 2, dict(nt=1024, wl=36864, tmask=3, dual=1, items=4096, merged=2, compact=1, fix=12)),   # not BASELINE's depth: class 2's bin twin (round 6)
+    ("cfg5", 2, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=4)),            # (class 4 is a bin: any depth up to 3)
+    # the flatland_cutils builder alone (depth 0; round 6): the one-pass kernels without the upstream builder, classes 6 .. 9
+    ("cfg1", 0, dict(nt=1024, wl=24576, tmask=3, dual=0, items=4096, merged=1, compact=1, fix=6)),
+    ("cfg2", 0, dict(nt=1024, wl=24576, tmask=3, dual=0, items=4096, merged=1, compact=1, fix=6)),
+    ("cfg3", 0, dict(nt=1024, wl=36864, tmask=3, dual=0, items=6144, merged=2, compact=1, fix=7)),
+    ("cfg4", 0, dict(nt=1024, wl=0, tmask=3, dual=0, items=0, merged=2, compact=1, fix=8)),
+    ("cfg5", 0, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=9)),
     ("cfg5", 3, dict(nt=1024, wl=0, tmask=1, dual=0, items=0, merged=0, compact=1, fix=4)),   # round 2: 512 threads (85-slot tables)
 ])
 def test_observation_launch_configuration_of_the_bench_workloads(workload, depth, expect):
@@ -61,11 +67,13 @@ def test_grids_with_three_way_cells_take_the_dfs_slot_tables():
     assert got["merged"] == 0 and got["compact"] == 1, got
 
 
-@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 680, 24, 2), (4, 400, 2688, 53, 3)])
+@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 680, 24, 2), (4, 400, 2688, 53, 3),
+                                             (6, 32, 256, 8, 0), (7, 80, 232, 10, 0), (8, 80, 680, 24, 0), (9, 400, 2688, 53, 0)])
 def test_every_fixed_launch_class_is_the_choice_at_its_own_capacities(fix, A, R, U, depth):
     """ObsFixed<k>::opt is hand-written; this keeps it honest: at the class's capacities obs_pick_config's own preference walk
     lands on exactly those options (otherwise the class is never taken and `fix` stays 0), the carving fits 160 KiB, and one
-    more agent or rail cell falls back to the runtime carving with the same kernel code."""
+    more agent or rail cell goes to another class (a bin class, round 6) or to the runtime carving with the same kernel code.  depth 0 = the
+    flatland_cutils builder alone (classes 6 .. 9)."""
     got = _config(A, R, U, depth)
     assert got["fix"] == fix and got["lds"] <= 160 * 1024, got
     assert _config(A + 1, R, U, depth)["fix"] != fix and _config(A, R + 1, U, depth)["fix"] != fix
@@ -77,10 +85,10 @@ def test_fixed_launch_class_boundaries():
     other batch runs the runtime-layout kernel (same code, fix = 0)."""
     assert _config(32, 256, 8, 2)["fix"] == 1
     assert _config(32, 257, 8, 2)["fix"] == 0 and _config(32, 257, 8, 2)["merged"] == 1
-    assert _config(33, 200, 8, 2)["fix"] == 0
-    assert _config(20, 213, 5, 2, tall=1)["fix"] == 0
-    assert _config(20, 213, 5, 3)["fix"] == 0                 # depth 3 of the upstream tree: not the class's (BASELINE: depth 2)
-    assert _config(79, 200, 7, 3)["fix"] == 0                 # classes 2 - 4 are for exactly 80 / 80 / 400 agents
+    assert _config(33, 200, 8, 2)["fix"] == 12                # (rounds of 32 agents: class 2's bin twin)
+    assert _config(20, 213, 5, 2, tall=1)["fix"] == 16        # (colliding prediction keys: two stages -- the tall-map bin class)
+    assert _config(20, 213, 5, 3)["fix"] == 11                # depth 3 of the upstream tree: not class 1's (BASELINE: depth 2) -- its bin twin
+    assert _config(79, 200, 7, 3)["fix"] == 12                # classes 2 and 3 are for exactly 80 agents: 79 take the bin twin
     assert _config(20, 213, 5, 2, tree_pred=60)["fix"] == 0   # 20 * 62 items of the second index exceed the class's 1024
     got = _config(20, 213, 20, 2)
     assert got["fix"] == 1 and got["lds"] <= 160 * 1024      # the next-hop tables (last in the carving) at the batch's size
@@ -108,3 +116,21 @@ def test_small_envs_go_two_workgroups_a_cu_when_that_ends_the_launch_sooner():
     assert wide == {1: False, 256: False, 257: True, 384: True, 512: True, 513: False, 640: False, 768: False, 769: True, 1024: True,
                     1280: True, 1536: True, 2048: True, 8192: True}, wide
     assert not L.fl_debug_batch_is_wide(1024, 0)
+
+
+# (agents, rail cells of level 1, unique targets -- an upper estimate) of the fifteen tests of the Round-2 table
+# (solution/debug-environments/parameters_flatland_round_2_new.csv; profiles/r05_soak_round2.txt)
+ROUND2_SHAPES = {"Test_0": (7, 120, 4), "Test_1": (10, 99, 4), "Test_2": (20, 123, 6), "Test_3": (50, 183, 6), "Test_4": (80, 177, 10), "Test_5": (80, 239, 14),
+                 "Test_6": (80, 362, 18), "Test_7": (80, 422, 26), "Test_8": (80, 677, 34), "Test_9": (100, 1109, 42), "Test_10": (100, 1265, 50),
+                 "Test_11": (200, 1443, 58), "Test_12": (200, 2745, 66), "Test_13": (400, 3025, 74), "Test_14": (425, 2807, 82)}
+
+
+@pytest.mark.parametrize("test", sorted(ROUND2_SHAPES))
+def test_every_round2_shape_takes_a_launch_class_at_depth_2_and_3_and_alone(test):
+    """round 6: exact classes for the BASELINE configs, BIN classes (compile-time carving, agents an upper bound, the call's depth) for
+    every other shape of the table -- with both builders at depth 2 and 3 and for the flatland_cutils builder alone"""
+    A, R, U = ROUND2_SHAPES[test]
+    tall = int(test in ("Test_3", "Test_6", "Test_9"))      # maps taller than wide: compact prediction keys, two stages (bin classes 16 / 20)
+    for depth in (2, 3, 0):
+        got = _config(A, R, U, depth, tall=tall)
+        assert got["fix"] != 0 and got["lds"] <= 160 * 1024, (test, depth, got)

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
-# time and WRITE_SIZE / FETCH_SIZE of the observation kernel for builds with different OBS_NT_LEVEL (build_ab/libfl_nt<k>.so; "-" = tree)
+# time and WRITE_SIZE / FETCH_SIZE of the observation kernel for builds with different OBS_NT_LEVEL (ab_libs/libfl_nt<k>.so; "-" = tree)
 set -uo pipefail
 mkdir -p gpurun_out/nt
 for spec in "cfg2 2" "cfg3 3" "cfg4 2" "cfg5 3 --dm-rebuild"; do
   read wl depth extra <<< "$spec"
   steps=100; [ "$wl" = "cfg2" ] && steps=300; [ "$wl" = "cfg5" ] && steps=60
-  for lib in build_ab/libfl_nt0.so build_ab/libfl_nt1.so build_ab/libfl_nt2.so -; do
+  for lib in ab_libs/libfl_nt0.so ab_libs/libfl_nt1.so ab_libs/libfl_nt2.so -; do
     name=$(basename $lib .so); arg="--lib $PWD/$lib"; [ "$lib" = "-" ] && { name=tree; arg=""; }
     python bench.py --no-extra-workloads --no-cpu-baseline --workload $wl --tree-depth $depth --steps $steps --warmup 20 $extra $arg 2>/dev/null > gpurun_out/nt/b.json
     v=$(python -c "import json;d=json.load(open('gpurun_out/nt/b.json'));print('%.2f M obs %.4f ms' % (d['value']/1e6, list(d['kernel_ms'].values())[1]))")

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase clocks of the fused observation kernel, from a -DFL_OBS_TIMING build of the library.
 
-  mkdir -p build_ab; OUT=$PWD/build_ab/libfl_timing.so EXTRA_HIPCC_FLAGS=-DFL_OBS_TIMING FORCE=1 flatland_marl_amd/csrc/build.sh
-  python tools/obs_phase_clocks.py build_ab/libfl_timing.so [workload [tree depth]]        (on the GPU box)
+  mkdir -p build_ab; OUT=$PWD/ab_libs/libfl_timing.so EXTRA_HIPCC_FLAGS=-DFL_OBS_TIMING FORCE=1 flatland_marl_amd/csrc/build.sh
+  python tools/obs_phase_clocks.py ab_libs/libfl_timing.so [workload [tree depth]]        (on the GPU box)
 
 Prints the mean over envs / steps (us; wall_clock64 ticks at 100 MHz).  The phases of the trees are accumulated over the
 rounds of 32 (cutils) / 16-32 (upstream) trees.

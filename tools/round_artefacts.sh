@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # The profiles of record of a round, in one GPU-box call:  tools/round_artefacts.sh TAG   -> gpurun_out/prof_TAG/
 #   kernel traces + PMC traffic of the four workloads (tools/profile_workloads.py), SQ counters of the cfg2 launch (three passes of
-#   tools/pmc_pass.py), phase clocks (build_ab/libfl_timing.so = tools/build_variant.sh timing -DFL_OBS_TIMING), the default bench line
+#   tools/pmc_pass.py), phase clocks (ab_libs/libfl_timing.so = tools/build_variant.sh timing -DFL_OBS_TIMING), the default bench line
 set -uo pipefail
 tag=$1
 out=gpurun_out/prof_$tag
@@ -33,11 +33,13 @@ json.dump(acc, open(os.path.join(out, "%s_sq_counters_cfg2.json" % tag), "w"), i
 PY
 cp $out/${tag}_sq_counters_cfg2.json profiles/ 2>/dev/null   # (on the GPU box: the default bench line below quotes it as roofline.valu_issue)
 echo "[artefacts] SQ counters done"
-if [ -f build_ab/libfl_timing.so ]; then
+# (the timing variant is built HERE, on the box, when it did not travel: no toggling of .gpurunignore)
+[ -f ab_libs/libfl_timing.so ] || tools/build_variant.sh timing -DFL_OBS_TIMING > $out/build_timing.log 2>&1 || tail -3 $out/build_timing.log
+if [ -f ab_libs/libfl_timing.so ]; then
   : > $out/${tag}_phase_clocks.txt
   # (the clocks are taken in the bench's regime: de-phased replicas, see tools/obs_phase_clocks.py)
   for w in "cfg2 2" "cfg3 3" "cfg4 2" "cfg5 3" "cfg4 2 4" "cfg5 3 2"; do
-    python tools/obs_phase_clocks.py build_ab/libfl_timing.so $w 2>&1 | grep -v amdgpu.ids >> $out/${tag}_phase_clocks.txt
+    python tools/obs_phase_clocks.py ab_libs/libfl_timing.so $w 2>&1 | grep -v amdgpu.ids >> $out/${tag}_phase_clocks.txt
     echo >> $out/${tag}_phase_clocks.txt
   done
 fi

@@ -2,7 +2,7 @@
 
   git apply tools/step_timing.patch && tools/build_variant.sh steptiming -DFL_STEP_TIMING && git apply -R tools/step_timing.patch
   (the marks live in a patch so that the kernel sources of record -- bench.KERNEL_SOURCES -- stay as profiled)
-  python tools/step_phase_clocks.py build_ab/libfl_steptiming.so [workload]        (on the GPU box)
+  python tools/step_phase_clocks.py ab_libs/libfl_steptiming.so [workload]        (on the GPU box)
 
 Prints the mean over envs / steps of the time since the workgroup's first instruction (us; wall_clock64 ticks at 100 MHz),
 de-phased like bench.py.
