@@ -139,9 +139,12 @@ static bool obs_fits_fixed(const FlDev &d, const ObsArgs &P, const ObsOptions &o
 // (per shape of the Round-2 table: profiles/r06_round2_classes.txt).  FL_OBS_NO_BINS: exact classes only.
 template <int FIX> static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R);
 template <int FIX>
-static bool obs_fits_bin(const FlDev &d, ObsArgs &P, ObsLayout &L) {
+static bool obs_fits_bin(const FlDev &d, ObsArgs &P, const ObsOptions &own, ObsLayout &L) {
     using F = ObsFixed<FIX>;
     if (F::opt.wl_head && obs_no_wl_head()) return false;
+    // the large-map bins have no LDS successor table: not for a batch that affords one itself (Test_12: 200 agents on 2 745 rail cells --
+    // same box, its envs beyond class 4 on the runtime carving WITH the table 435 us, on class 14 without 442)
+    if (!F::opt.snext && F::dims.rkey == 0 && own.snext) return false;
     if (P.label || !P.compact_t || (d.rkey != nullptr) != (F::dims.rkey != 0) || d.A > F::dims.A || d.Rcap > F::dims.Rcap) return false;
     if (P.merged != F::shape.merged || P.tw_c != F::shape.tw_c || P.tw_t != F::shape.tw_t || P.tpw_t != F::shape.tpw_t) return false;
     if (P.max_nodes != F::max_nodes || P.pred_depth != F::pred_depth || P.tree_pred != F::shape.tree_pred || (F::max_depth != 0 && P.max_depth != F::max_depth)) return false;
@@ -187,12 +190,12 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
         else if (obs_fits_fixed<9>(d, P, o, L)) P.fix = 9;
         else if (obs_fits_fixed<10>(d, P, o, L)) P.fix = 10;
         else if (no_bins || !P.cutils_alone) return;   // (FL_OBS_NO_CUTILS_MERGE: the stand-alone kernel as it ran before round 6)
-        else if (obs_fits_bin<17>(d, P, L)) P.fix = 17;
-        else if (obs_fits_bin<8>(d, P, L)) P.fix = 8;
-        else if (obs_fits_bin<18>(d, P, L)) P.fix = 18;
-        else if (obs_fits_bin<9>(d, P, L)) P.fix = 9;
-        else if (obs_fits_bin<19>(d, P, L)) P.fix = 19;
-        else if (obs_fits_bin<20>(d, P, L)) P.fix = 20;
+        else if (obs_fits_bin<17>(d, P, o, L)) P.fix = 17;
+        else if (obs_fits_bin<8>(d, P, o, L)) P.fix = 8;
+        else if (obs_fits_bin<18>(d, P, o, L)) P.fix = 18;
+        else if (obs_fits_bin<9>(d, P, o, L)) P.fix = 9;
+        else if (obs_fits_bin<19>(d, P, o, L)) P.fix = 19;
+        else if (obs_fits_bin<20>(d, P, o, L)) P.fix = 20;
         return;
     }
     if (obs_fits_fixed<1>(d, P, o, L)) P.fix = 1;
@@ -202,13 +205,13 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
     else if (obs_fits_fixed<5>(d, P, o, L)) P.fix = 5;
     else if (no_bins) return;
     else if (exact_split_covers_most<2>(d, P, L) || exact_split_covers_most<3>(d, P, L)) return;   // (obs_take_split_class takes it)
-    else if (obs_fits_bin<11>(d, P, L)) P.fix = 11;
-    else if (obs_fits_bin<12>(d, P, L)) P.fix = 12;
-    else if (obs_fits_bin<13>(d, P, L)) P.fix = 13;
-    else if (obs_fits_bin<15>(d, P, L)) P.fix = 15;
-    else if (obs_fits_bin<4>(d, P, L)) P.fix = 4;
-    else if (obs_fits_bin<14>(d, P, L)) P.fix = 14;
-    else if (obs_fits_bin<16>(d, P, L)) P.fix = 16;
+    else if (obs_fits_bin<11>(d, P, o, L)) P.fix = 11;
+    else if (obs_fits_bin<12>(d, P, o, L)) P.fix = 12;
+    else if (obs_fits_bin<13>(d, P, o, L)) P.fix = 13;
+    else if (obs_fits_bin<15>(d, P, o, L)) P.fix = 15;
+    else if (obs_fits_bin<4>(d, P, o, L)) P.fix = 4;
+    else if (obs_fits_bin<14>(d, P, o, L)) P.fix = 14;
+    else if (obs_fits_bin<16>(d, P, o, L)) P.fix = 16;
 }
 
 // (defined above) g_fix_allowed: the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out

@@ -1,6 +1,7 @@
 // fl_obs_f10.hip -- the observation kernel of FIXED launch class 10 (ObsFixed<10>, fl_obs_layout.h): the flatland_cutils builder alone with the
 // LDS carving compiled in (the counterpart of class 5).  One translation unit per class (they compile in parallel with the MODE units).
 #include "fl_obs_body.h"
+static_assert(ObsFixed<10>::L.total <= 160 * 1024 || ObsFixed<10>::opt.nh, "the class's carving fits the LDS of a CU");
 
 int fl_obs_launch_f10(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     auto kern = k_obs<obs_fixed_mode<10>(), obs_fixed_var<10>(), 10>;

@@ -1,6 +1,7 @@
 // fl_obs_f15.hip -- the observation kernel of BIN launch class 15 (ObsFixed<15>, fl_obs_layout.h): compile-time LDS carving, the agents an
 // upper bound and the upstream depth the call's.  One translation unit per class (they compile in parallel with the MODE units).
 #include "fl_obs_body.h"
+static_assert(ObsFixed<15>::L.total <= 160 * 1024 || ObsFixed<15>::opt.nh, "the class's carving fits the LDS of a CU");
 
 int fl_obs_launch_f15(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     auto kern = k_obs<obs_fixed_mode<15>(), obs_fixed_var<15>(), 15>;

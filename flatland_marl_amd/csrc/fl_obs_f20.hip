@@ -1,6 +1,7 @@
 // fl_obs_f20.hip -- the observation kernel of BIN launch class 20 (ObsFixed<20>, fl_obs_layout.h): compile-time LDS carving, the agents an
 // upper bound and the upstream depth the call's.  One translation unit per class (they compile in parallel with the MODE units).
 #include "fl_obs_body.h"
+static_assert(ObsFixed<20>::L.total <= 160 * 1024 || ObsFixed<20>::opt.nh, "the class's carving fits the LDS of a CU");
 
 int fl_obs_launch_f20(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     auto kern = k_obs<obs_fixed_mode<20>(), obs_fixed_var<20>(), 20>;

@@ -2,6 +2,7 @@
 // compiled in -- class 1's envs (at most 32 agents / 256 rail cells) in rounds of 16 agents on 512 threads, two workgroups a CU, for
 // batches of several envs per CU.  One translation unit per class (they compile in parallel with the MODE units).
 #include "fl_obs_body.h"
+static_assert(ObsFixed<5>::L.total <= 160 * 1024 || ObsFixed<5>::opt.nh, "the class's carving fits the LDS of a CU");
 
 int fl_obs_launch_f5(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     static_assert(obs_fixed_mode<5>() == 5 && obs_fixed_var<5>() == 0 && ObsFixed<5>::L.total <= 80 * 1024, "class 5 is MODE 5, VAR 0, two workgroups a CU");

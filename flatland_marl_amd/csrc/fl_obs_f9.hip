@@ -1,6 +1,7 @@
 // fl_obs_f9.hip -- the observation kernel of FIXED launch class 9 (ObsFixed<9>, fl_obs_layout.h): the flatland_cutils builder alone with the
 // LDS carving compiled in (the counterpart of class 4).  One translation unit per class (they compile in parallel with the MODE units).
 #include "fl_obs_body.h"
+static_assert(ObsFixed<9>::L.total <= 160 * 1024 || ObsFixed<9>::opt.nh, "the class's carving fits the LDS of a CU");
 
 int fl_obs_launch_f9(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s) {
     auto kern = k_obs<obs_fixed_mode<9>(), obs_fixed_var<9>(), 9>;

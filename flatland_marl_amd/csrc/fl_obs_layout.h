@@ -188,6 +188,8 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 // the upstream tree's depth) and, for the larger ones, the exact number of agents -- all constants in its kernel.
 //   FIX 1: one round of trees for both builders (MODE 3): at most 32 agents, 256 rail cells, depth 2 -- cfg1, cfg2 (BASELINE configs[0..1])
 #define OBS_FIX3_RCAP 680
+#define OBS_FIX4_RCAP 2816   // classes 4 / 9 (round 6: bins): cfg5 (2 680 rail cells) and, with the LDS successor table still fitting, Test_12 (2 745) and
+#define OBS_FIX4_A 432       // the first level of Test_14 (2 807 cells, 425 agents)
 #define OBS_FIX3_WL_HEAD (10 * 1024)
 #define OBS_WL_HEAD_MAX (16 * 1024)   // LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
 #define OBS_WL_HEAD_MIN (4 * 1024)
@@ -217,7 +219,7 @@ template <> struct ObsFixed<1> {
 //   FIX 3: rounds of 32 agents, work lists in HBM scratch with an LDS head (MODE 4, VAR 2): 80 agents, at most 680 rail cells -- every
 //          level of the Round-2 row (Test_8: 603 .. 677) --, depth 2 -- cfg4 (configs[3]).  No LDS copy of the items: every cfg4 env has
 //          more items than the 4 096 entries that fitted (round 4: the copy was dead weight); its 16 KB are the larger maps and the head.
-//   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): 400 agents, at most 2688 rail cells, depth 3 -- cfg5 (configs[4])
+//   FIX 4: two stages, hundreds of agents (MODE 2, VAR 2): at most 432 agents / 2816 rail cells, any depth (a bin since round 6) -- cfg5 (configs[4]), Test_12, Test_14
 // The LDS of these three is full to the last few hundred bytes (that is how obs_pick_config chose their options), so the classes
 // are the BASELINE maps' own sizes rounded up to a multiple of 8 / 16 rail cells; tests/test_obs_config.py checks that each class
 // IS what obs_pick_config chooses at the class's capacities.
@@ -240,7 +242,7 @@ template <> struct ObsFixed<3> {
 template <> struct ObsFixed<4> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;   // (a bin: the call's depth, 1 .. 3)
     static constexpr int agents = 0;   // agents per env, exactly (0 = any number up to dims.A)
-    static constexpr ObsDims dims = {2688, 400, 0, 0};
+    static constexpr ObsDims dims = {OBS_FIX4_RCAP, OBS_FIX4_A, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
@@ -283,10 +285,10 @@ template <> struct ObsFixed<8> {   // 80 agents, at most 680 rail cells, rounds 
     static constexpr ObsOptions opt = OBS_FIX8_OPT;
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
-template <> struct ObsFixed<9> {   // 400 agents, at most 2688 rail cells: the stand-alone kernel (MODE 0, VAR 2) with its carving compiled in (cfg5)
+template <> struct ObsFixed<9> {   // at most 432 agents / 2816 rail cells: the stand-alone kernel (MODE 0, VAR 2) with its carving compiled in (cfg5)
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
     static constexpr int agents = 0;
-    static constexpr ObsDims dims = {2688, 400, 0, 0};
+    static constexpr ObsDims dims = {OBS_FIX4_RCAP, OBS_FIX4_A, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
     static constexpr ObsOptions opt = OBS_FIX9_OPT;
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
@@ -304,7 +306,7 @@ template <> struct ObsFixed<11> : ObsFixed<1> { static constexpr int max_depth =
 template <> struct ObsFixed<12> : ObsFixed<2> { static constexpr int max_depth = 0, agents = 0; };
 template <> struct ObsFixed<13> : ObsFixed<3> { static constexpr int max_depth = 0, agents = 0; };
 template <> struct ObsFixed<17> : ObsFixed<7> { static constexpr int agents = 0; };
-#define OBS_FIXB_RCAP 3072
+#define OBS_FIXB_RCAP 3200
 #define OBS_FIXB_A 432
 template <> struct ObsFixed<14> {   // both builders, two stages, no LDS successor table: at most 432 agents / 3 072 rail cells, any depth
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
@@ -314,21 +316,23 @@ template <> struct ObsFixed<14> {   // both builders, two stages, no LDS success
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
-// 15 / 18: rounds of 32 agents on maps beyond class 3's: at most 100 agents / 1 280 rail cells (Test_9, Test_10), HBM work lists
+// 15 / 18: rounds of 32 agents on maps beyond class 3's: at most 100 agents / 1 344 rail cells (Test_10: 1 265 / 1 319), HBM work lists with an
+// LDS head, no LDS copy of the items (a hundred paths across a 100 x 80 map are more items than any copy that fits)
+#define OBS_FIX15_RCAP 1344
 template <> struct ObsFixed<15> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
     static constexpr int agents = 0;
-    static constexpr ObsDims dims = {1280, 100, 0, 0};
+    static constexpr ObsDims dims = {OBS_FIX15_RCAP, 100, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
-    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 4096, 0};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 1, 0, 1, 1, 0, 0, 0, 0, 0, 8 * 1024};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 template <> struct ObsFixed<18> {
     static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
     static constexpr int agents = 0;
-    static constexpr ObsDims dims = {1280, 100, 0, 0};
+    static constexpr ObsDims dims = {OBS_FIX15_RCAP, 100, 0, 0};
     static constexpr ObsShape shape = {2, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
-    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 10 * 1024};
+    static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1, 1, OBS_ITEMS_LDS_CAP, 4 * 1024};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 // 16 / 20: maps TALLER than wide (the reference's prediction key col * W + row collides there, tool.h:391-398: compact keys in LDS, L_RKEY;

@@ -64,7 +64,7 @@ def test_full_size_batch_replicas_equal_solo_runs_and_the_oracle(workload, B, st
         if t == 0:      # which kernel builds the batch: the class, for every env (split 0) or for the envs that fit it (split 1)
             fix, split, n_fit = env.last_obs_class()
             rails = np.array([int((np.asarray(e["grid"]) != 0).sum()) for e in envs])
-            cap = {1: 256, 2: 232, 3: 680, 4: 2688, 5: 256}[klass[0]]
+            cap = {1: 256, 2: 232, 3: 680, 4: 2816, 5: 256}[klass[0]]
             assert (fix, split) == klass and n_fit == int((rails <= cap).sum()) and (split == 0) == (n_fit == B), (fix, split, n_fit)
             if split:   # both bodies are under test: replicas on either side of the class's capacity among the picks / shadows
                 assert {bool(rails[b] <= cap) for b in picks} == {True, False}, rails[list(picks)]
@@ -210,14 +210,14 @@ def test_workgroup_order_and_the_split_of_a_launch_do_not_change_the_results_at_
     """The cfg4 shard on four levels of its Round-2 row plus a larger map (695 rail cells, beyond class 3's 680) in every seventh env:
     the default launch is the class's SPLIT kernel (class body / runtime-carving body per env) with the envs handed to the
     workgroups longest first by k_env_order (B > CUs).  FL_OBS_NO_ORDER (read once per process, hence the children) makes workgroup
-    k build env k; FL_OBS_NO_SPLIT / FL_OBS_NO_WL_HEAD (no LDS head of the HBM lists: class 3 does not apply) run every env on bin class 15,
-    with FL_OBS_NO_BINS on the runtime-carving kernel k_obs<4,2,0>.  Same bytes all five ways."""
+    k build env k; FL_OBS_NO_SPLIT runs every env on bin class 15; FL_OBS_NO_WL_HEAD (no LDS head of the HBM lists: neither class applies) and
+    FL_OBS_NO_SPLIT + FL_OBS_NO_BINS on the runtime-carving kernel k_obs<4,2,0>.  Same bytes all five ways."""
     want = _cfg4_digest(want_class=(3, 1), big=True)
     assert _child(("FL_OBS_NO_ORDER",), "cfg4", "3", "1") == {"cfg4": want}
     # round 6: without the split (or without LDS heads, which class 3 has) the whole batch takes BIN class 15 (rounds of 32 agents, at most
-    # 100 agents / 1 280 rail cells, HBM lists without a head) -- k_obs<4,2,15> at shard size; without the bins too: the runtime carving
+    # 100 agents / 1 344 rail cells) -- k_obs<4,2,15> at shard size; without the bins too: the runtime carving
     assert _child(("FL_OBS_NO_SPLIT",), "cfg4", "15", "0") == {"cfg4": want}
-    assert _child(("FL_OBS_NO_WL_HEAD",), "cfg4", "15", "0") == {"cfg4": want}
+    assert _child(("FL_OBS_NO_WL_HEAD",), "cfg4", "0", "0") == {"cfg4": want}     # (classes 3 and 15 both have an LDS head: runtime carving)
     assert _child(("FL_OBS_NO_SPLIT", "FL_OBS_NO_BINS"), "cfg4", "0", "0") == {"cfg4": want}
 
 
@@ -239,7 +239,7 @@ def test_other_launch_paths_give_the_same_bytes():
 
 # ---- the flatland_cutils builder ALONE (what the reference's solution launches: solution/eval_env.py:15-17 builds TreeCutils(31, 500) only):
 # fl_obs_cutils on the one-pass kernels without the upstream builder (MODE 6 / 7 / 8) and their fixed launch classes 6 .. 10
-CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2688, 10: 256}
+CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2816, 10: 256}
 
 
 @pytest.mark.parametrize("workload,B,steps,picks,shadow,distinct,klass", [

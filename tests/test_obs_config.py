@@ -67,8 +67,8 @@ def test_grids_with_three_way_cells_take_the_dfs_slot_tables():
     assert got["merged"] == 0 and got["compact"] == 1, got
 
 
-@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 680, 24, 2), (4, 400, 2688, 53, 3),
-                                             (6, 32, 256, 8, 0), (7, 80, 232, 10, 0), (8, 80, 680, 24, 0), (9, 400, 2688, 53, 0)])
+@pytest.mark.parametrize("fix,A,R,U,depth", [(1, 32, 256, 8, 2), (2, 80, 232, 10, 3), (3, 80, 680, 24, 2), (4, 432, 2816, 53, 3),
+                                             (6, 32, 256, 8, 0), (7, 80, 232, 10, 0), (8, 80, 680, 24, 0), (9, 432, 2816, 53, 0)])
 def test_every_fixed_launch_class_is_the_choice_at_its_own_capacities(fix, A, R, U, depth):
     """ObsFixed<k>::opt is hand-written; this keeps it honest: at the class's capacities obs_pick_config's own preference walk
     lands on exactly those options (otherwise the class is never taken and `fix` stays 0), the carving fits 160 KiB, and one
