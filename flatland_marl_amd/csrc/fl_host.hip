@@ -985,6 +985,42 @@ int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev) {
     return FL_OK;
 }
 
+int fl_obs_tree_handles(fl_batch *h, int max_depth, int pred_depth, const int32_t *handles, int n_handles, double *out_dev) {
+    NEED_COMMIT(h);
+    const int A = h->A;
+    if (!handles || n_handles < 1 || n_handles > A) { set_err("fl_obs_tree_handles: 1 <= n_handles <= %d agents", A); return FL_ERR_ARG; }
+    // the reference's conflict test deletes position `handle` from the arrays of the listed handles' predictions and reads
+    // env.agents[position].state (observations.py:337-366): a listed handle >= len(handles) is an IndexError there; what remains are
+    // the permutations of 0 .. n-1
+    std::vector<int16_t> label(A, (int16_t)-1);
+    bool identity = n_handles == A;
+    for (int j = 0; j < n_handles; j++) {
+        const int a = handles[j];
+        if (a < 0 || a >= n_handles || label[a] >= 0) {
+            set_err("fl_obs_tree_handles: handles has to be a permutation of 0 .. %d (handle %d at position %d): the reference's get_many raises IndexError for a handle >= len(handles) "
+                    "(observations.py:337 deletes list position `handle`)", n_handles - 1, a, j);
+            return FL_ERR_ARG;
+        }
+        label[a] = (int16_t)j;
+        identity = identity && a == j;
+    }
+    if (identity || pred_depth < 0) return fl_obs_tree(h, max_depth, pred_depth, out_dev);   // (no predictor: no conflict test, the list does not matter)
+    if (max_depth < 1 || max_depth > FL_MAX_TREE_DEPTH || pred_depth > FL_OBS_MAX_PRED || !out_dev) {
+        set_err("fl_obs_tree_handles: max_depth must be in [1,%d], pred_depth <= %d", FL_MAX_TREE_DEPTH, FL_OBS_MAX_PRED);
+        return FL_ERR_ARG;
+    }
+    if (max_depth > 3 && h->d.max_branch > 2) {
+        set_err("fl_obs_tree_handles: max_depth 4 needs a grid on which no direction of a cell has more than two transitions; this batch has %d", h->d.max_branch);
+        return FL_ERR_ARG;
+    }
+    HIPCHK(hipMemcpyAsync(h->obs.label, label.data(), (size_t)A * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // (the staging vector is a local)
+    int rc = fl_launch_obs_tree(h->obs, h->d, max_depth, pred_depth, out_dev, h->stream, h->obs.label);
+    if (rc != FL_OK) { set_err("fl_obs_tree_handles: no launch configuration"); return rc; }
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
 // diagnostic (not part of the public header): copy the per-env phase clocks of a -DFL_OBS_TIMING build
 extern "C" int fl_debug_obs_clocks(fl_batch *h, long long *out /* [B][64] */) {
     NEED_COMMIT(h);

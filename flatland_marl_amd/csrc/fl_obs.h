@@ -47,7 +47,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
 int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_depth, float *attr, float *forest,
                        int32_t *adjacency, int32_t *node_order, int32_t *edge_order, uint8_t *valid, double *props,
                        int max_depth, int tree_pred, double *tree_out, hipStream_t s);
-int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s);
+int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s, const int16_t *label_dev = nullptr);
 // more envs than CUs: the order in which the workgroups take the envs (longest previous launch first); returns the scratch the launch uses
 FlObsScratch fl_obs_env_order(FlObsScratch &o, const FlDev &d, hipStream_t s);
 int fl_obs_config_of_fused(const FlDev &d, int pred_depth, int max_depth, int tree_pred, int out[11], int wide = 0);  // diagnostic (wide: several envs per CU)

@@ -560,7 +560,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
            P.merged == 3 ? fl_obs_launch_m5(obs_var(P), d, u, P, s) : fl_obs_launch_m2(obs_var(P), d, u, P, s);
 }
 
-int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s) {
+int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_depth, double *out, hipStream_t s, const int16_t *label_dev) {
     if (d.A > 1024 || pred_depth + 2 > o.pred_cap || pred_depth > 510) return FL_ERR_ARG;
     if (max_depth > FL_MAX_TREE_DEPTH) return FL_ERR_ARG;
     // depth 4: compact node tables only (level L of the tree has at most 2^L nodes when no direction of a cell has more than two
@@ -568,6 +568,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     if (max_depth > 3 && d.max_branch > 2) return FL_ERR_ARG;
     ObsArgs P = {};
     P.dbg = o.dbg;
+    P.label = label_dev;
     obs_tree_args(d, P, max_depth, pred_depth, out);
     if (max_depth > 3 && !P.compact_t) return FL_ERR_ARG;   // (FL_OBS_NO_COMPACT)
     if (!obs_pick_config(d, P)) return FL_ERR_ARG;

@@ -147,8 +147,8 @@ __device__ __forceinline__ void obs_body(const FlDev &d, const FlObsScratch &S, 
 #endif
     OBS_STAMP(0);
 
-    // get_many(handles) with a strict subset: the stand-alone flatland_cutils launch only
-    const int16_t *lab = (CUTILS && STAGE == 0 && MERGED == 0 && FIX == 0) ? P.label : nullptr;
+    // get_many(handles) with a strict subset: the stand-alone launches (flatland_cutils: treeobs.cpp:50-62; upstream: observations.py:72-83)
+    const int16_t *lab = (STAGE == 0 && MERGED == 0 && FIX == 0) ? P.label : nullptr;
     const int my_pred_depth = CUTILS ? P.pred_depth : P.tree_pred;
     const bool any_pred = STAGE == 0 ? my_pred_depth >= 0 : true;
     const bool nh_in_lds = nh_lds != nullptr && any_pred;

@@ -26,7 +26,7 @@ STATE_NAMES = ("row", "col", "dir", "state", "malf", "nmalf", "scount", "saved",
 # every symbol include/flatland_hip.h declares
 SYMBOLS = ("fl_last_error", "fl_version", "fl_device_count", "fl_create", "fl_destroy", "fl_set_stream", "fl_sync",
            "fl_load_env", "fl_reserve", "fl_commit", "fl_set_rng", "fl_get_rng", "fl_reset", "fl_reset_dev", "fl_step", "fl_step_synth", "fl_step_obs", "fl_check",
-           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_policy", "fl_obs_cutils_handles", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
+           "fl_metrics", "fl_scores", "fl_info", "fl_obs_cutils", "fl_obs_cutils_policy", "fl_obs_cutils_handles", "fl_obs_cutils_tree", "fl_obs_tree", "fl_obs_tree_handles", "fl_obs_set_mode", "fl_policy_pack", "fl_get_state", "fl_get_state_aux", "fl_set_state", "fl_motion_check", "fl_distance_map", "fl_distance_map_rebuild", "fl_distance_map_rebuild_masked", "fl_positions_map",
            "fl_algorithmic_bytes_per_agent_step")
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
         L.fl_scores.argtypes = [vp, vp, i32]
         L.fl_obs_cutils.argtypes = [vp, i32, i32] + [vp] * 7
         L.fl_obs_tree.argtypes = [vp, i32, i32, vp]
+        if hasattr(L, "fl_obs_tree_handles"):
+            L.fl_obs_tree_handles.argtypes = [vp, i32, i32, vp, i32, vp]
         if hasattr(L, "fl_obs_cutils_policy"):
             L.fl_obs_cutils_policy.argtypes = [vp, i32, i32] + [vp] * 7
         if hasattr(L, "fl_obs_cutils_handles"):
@@ -346,6 +348,8 @@ class BatchedRailEnv:
         hold every agent's rows, the trees computed against the predictions of the listed agents only."""
         o = self._obs_buffers()
         if handles is not None:
+            if not hasattr(lib(), "fl_obs_cutils_handles"):
+                raise FlatlandHipError(1, "the loaded library has no fl_obs_cutils_handles (an older build loaded through --lib?)")
             hs = np.ascontiguousarray(handles, dtype=np.int32)
             _chk(lib().fl_obs_cutils_handles(self.h, self.max_nodes, self.pred_depth, _p(hs), len(hs), o["agent_attr"].data_ptr(),
                                              o["forest"].data_ptr(), o["adjacency"].data_ptr(), o["node_order"].data_ptr(),
@@ -373,6 +377,8 @@ class BatchedRailEnv:
     def keep_tree_rows(self, on=True):
         """FL_OBS_KEEP_TREE_ROWS: the upstream-tree tensor this object hands out is its own buffer, the same from call to call -- as long
         as the caller does not write into it, the builder only updates the rows that change (no -inf pre-fill of the slab per call)."""
+        if not hasattr(lib(), "fl_obs_set_mode"):
+            raise FlatlandHipError(1, "the loaded library has no fl_obs_set_mode (an older build loaded through --lib?)")
         _chk(lib().fl_obs_set_mode(self.h, 1 if on else 0))
 
     def policy_inputs(self, obs=None):
@@ -409,13 +415,22 @@ class BatchedRailEnv:
                                     no.data_ptr(), eo.data_ptr(), o["valid_actions"].data_ptr(), o["props"].data_ptr()))
         return o["agent_attr"], o["forest"], adj, no, eo
 
-    def obs_tree(self, max_depth=2, pred_depth=30):
-        """upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense tensor."""
+    def obs_tree(self, max_depth=2, pred_depth=30, handles=None):
+        """upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)) as a dense tensor.  handles: get_many(handles)
+        with a list (a permutation of 0 .. n-1, the same for every env; fl_obs_tree_handles): every agent's rows, the trees computed against
+        the predictions of the listed agents only, by list position (observations.py:72-83, 337-366)."""
         n = (4 ** (max_depth + 1) - 1) // 3
         key = (max_depth,)
         if key not in self._tree:
             self._tree[key] = self.torch.zeros((self.B, self.A, n, 12), dtype=self.torch.float64, device=self.device)
         out = self._tree[key]
+        if handles is not None:
+            L = lib()
+            if not hasattr(L, "fl_obs_tree_handles"):
+                raise FlatlandHipError(1, "the loaded library has no fl_obs_tree_handles (an older build loaded through --lib?)")
+            hs = np.ascontiguousarray(handles, dtype=np.int32)
+            _chk(L.fl_obs_tree_handles(self.h, max_depth, pred_depth, _p(hs), len(hs), out.data_ptr()))
+            return out
         _chk(lib().fl_obs_tree(self.h, max_depth, pred_depth, out.data_ptr()))
         return out
 

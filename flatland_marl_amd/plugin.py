@@ -25,7 +25,8 @@ The env's own `distance_map` is not read: the reference's is the BFS of `env.rai
 `handles`: `RailEnv` always passes every handle (rail_env.py:665).  With a strict subset the flatland_cutils builder of the reference
 keeps only the listed agents' predictions, indexed by list position (treeobs.cpp:50-62): reproduced (fl_obs_cutils_handles;
 goldens from the reference in tests/golden/subset_cfg2.npz); lists for which the reference's behaviour is undefined -- a handle >=
-len(handles), tool.h:428-434 -- raise ValueError.  The upstream builder computes with every agent and returns the listed rows.
+len(handles), tool.h:428-434 -- raise ValueError.  The upstream builder does the same since round 6 (fl_obs_tree_handles: observations.py:72-83,
+337-366; a handle >= len(handles) is the reference's IndexError).
 
 Cost of a call (tools/plugin_latency.py, profiles/r05_plugin_latency.json): the per-call host work is the reference's own -- one
 pass over the agents' attributes -- and nothing that grows with the map: the grid is read and hashed at reset() only, the per-call
@@ -242,12 +243,18 @@ class TreeObsUpstream(_re.TreeObsUpstream):
         b = self._bind
         b.push_dynamic(self.env)
         pred = -1 if self.predictor is None else int(self.predictor.max_depth)
-        t = b.batch.obs_tree(self.max_depth, pred)
+        hs = None if handles is None else list(handles)
+        n = len(self.env.agents)
+        # a handle list: the reference's semantics (the listed agents' predictions only, by list position: observations.py:72-83, 337-366)
+        t = b.batch.obs_tree(self.max_depth, pred, _re.upstream_handle_list(hs, n, pred >= 0) if hs else None)
         b.batch.check()
         arr = t[0].cpu().numpy()
-        return {h: arr[h] for h in (range(arr.shape[0]) if handles is None else handles)}   # (the dense form is this library's own: None = every agent)
+        return {h: arr[h] for h in (range(arr.shape[0]) if hs is None else hs)}   # (the dense form is this library's own: None = every agent)
 
     def get_many(self, handles=None):
         if handles is None:
             return {}                            # observations.py:66-67: None -> no handles, no observations
         return {h: _re.nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}
+
+    def get(self, handle=0):                     # (see rail_env.TreeObsUpstream.get: the agent's node of get_many(every handle))
+        return self.get_many(list(range(len(self.env.agents))))[handle]

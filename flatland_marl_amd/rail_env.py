@@ -179,11 +179,27 @@ def cutils_handle_list(handles, n_agents):
     fl_obs_cutils_handles -- a strict subset makes the reference's conflict test work on list POSITIONS (treeobs.cpp:50-62, 393-465),
     which is only defined when the list is a permutation of 0 .. n-1 (tool.h:428-434 erases position `handle`)."""
     h = [int(x) for x in handles]
-    if h == list(range(n_agents)):
-        return None
-    if not h or sorted(h) != list(range(len(h))):
+    if h == list(range(n_agents)) or not h:     # ([]: the reference's `assert((!handles.empty(), "Input Error"))` is a comma expression that never
+        return None                             # fires, treeobs.cpp:33 -- it returns every agent's attribute rows and an empty forest)
+    if sorted(h) != list(range(len(h))):
         raise ValueError("get_many(handles=%r): the reference's behaviour is undefined for this list -- its conflict test erases list position "
                          "`handle` (flatland_cutils tool.h:428-434), so a strict subset has to be a permutation of 0 .. len(handles)-1" % (h,))
+    return h
+
+
+def upstream_handle_list(handles, n_agents, has_predictor=True):
+    """get_many(handles) of the upstream builder: None for "every agent in order" (or no predictor: no conflict test, the list does not
+    matter), else the list for fl_obs_tree_handles -- predicted_pos / predicted_dir hold the listed handles' predictions in list order
+    (observations.py:72-83) and the conflict test deletes list position `handle` (np.delete, :337): a handle >= len(handles) is an IndexError
+    in the reference, raised here too; lists with repeated handles are not reproduced (ValueError)."""
+    h = [int(x) for x in handles]
+    if not has_predictor or h == list(range(n_agents)):
+        return None
+    if h and max(h) >= len(h):
+        raise IndexError("index %d is out of bounds for axis 0 with size %d (get_many(handles=%r): the reference's conflict test deletes list "
+                         "position `handle`, observations.py:337)" % (max(h), len(h), h))
+    if not h or sorted(h) != list(range(len(h))):
+        raise ValueError("get_many(handles=%r): lists with repeated handles are not reproduced" % (h,))
     return h
 
 
@@ -291,16 +307,21 @@ class TreeObsUpstream(ObservationBuilder):
         self.observation_dim = 11                         # observations.py:46
 
     def get_many_dense(self, handles=None):
-        t = self.env._batch.obs_tree(self.max_depth, self.pred_depth)
+        handles = list(range(self.env.get_num_agents())) if handles is None else list(handles)
+        t = self.env._batch.obs_tree(self.max_depth, self.pred_depth, upstream_handle_list(handles, self.env.get_num_agents(), self.pred_depth >= 0) if handles else None)
         self.env._batch.check()
         arr = t[0].cpu().numpy()
-        handles = range(self.env.get_num_agents()) if handles is None else handles
         return {h: arr[h] for h in handles}
 
     def get_many(self, handles=None):
         if handles is None:
             return {}                 # observations.py:66-67: None -> no handles, no observations (get_many_dense(None): every agent)
         return {h: nodes_from_dense(a, self.max_depth) for h, a in self.get_many_dense(handles).items()}
+
+    def get(self, handle=0):
+        """observations.py:117-254 computes ONE agent's tree against the predictions the last get_many() prepared -- RailEnv's call with
+        every handle (rail_env.py:665): the agent's node of get_many(every handle), not get_many([handle]) (a one-entry prediction list)"""
+        return self.get_many(list(range(len(self.env.agents))))[handle]
 
 
 class _FromDescription:

@@ -198,6 +198,12 @@ int fl_obs_cutils_policy(fl_batch *h, int max_nodes, int pred_depth, float *attr
 /* upstream TreeObsForRailEnv(max_depth, ShortestPathPredictorForRailEnv(pred_depth)); pred_depth < 0: no predictor.
  * out f64[B][A][(4^(max_depth+1)-1)/3][12], DFS pre-order (node, L, F, R, B); missing subtree = -inf. */
 int fl_obs_tree(fl_batch *h, int max_depth, int pred_depth, double *out_dev);
+/* TreeObsForRailEnv.get_many(handles) of the upstream builder with a handle list (observations.py:60-115): predicted_pos / predicted_dir hold
+ * the LISTED handles' predictions in list order (:72-83), the conflict test deletes list position `handle` and reads
+ * env.agents[position].state (:337-366); reproduced as it is.  handles: host int32[n_handles], the same list for every env; a permutation
+ * of 0 .. n_handles-1 (a listed handle >= len(handles) is an IndexError in the reference: FL_ERR_ARG).  The output holds the rows of ALL
+ * agents (row i = agent i; the reference returns the listed handles' nodes: the caller picks them). */
+int fl_obs_tree_handles(fl_batch *h, int max_depth, int pred_depth, const int32_t *handles, int n_handles, double *out_dev);
 /* Opt-in modes of the observation launches of this handle (flags: OR of the values below, 0 = defaults).
  * FL_OBS_KEEP_TREE_ROWS: the caller promises that the upstream-tree output buffer handed to fl_obs_tree / fl_obs_cutils_tree /
  *   fl_step_obs is the buffer of the previous such call with the same max_depth, NOT modified in between.  The builder then stops

@@ -661,12 +661,25 @@ static double *py_branch(const OrcEnv *e, const CellMaps *m, const Pred *p, int 
 }
 
 int orc_obs_pytree(OrcEnv *e, int max_depth, int pred_depth, double *out) {
+    return orc_obs_pytree_handles(e, max_depth, pred_depth, NULL, 0, out);
+}
+
+/* TreeObsForRailEnv.get_many(handles) (observations.py:60-115): handles == NULL: every agent.  With a list, predicted_pos[t] /
+ * predicted_dir[t] hold the LISTED handles' predictions in list order (:75-83); the conflict test deletes list position `handle`
+ * (np.delete(..., handle, 0), :337) and reads env.agents[list position].state (:344) -- defined for permutations of 0 .. n-1 (any
+ * other list: IndexError in the reference).  Rows of ALL agents are returned (row i = agent i; the reference returns the listed ones). */
+int orc_obs_pytree_handles(OrcEnv *e, int max_depth, int pred_depth, const int32_t *handles, int n_handles, double *out) {
     int A = e->A, i, N = py_subtree_size(0, max_depth);
     Pred p, *pp = NULL;
     CellMaps m;
+    if (handles) {
+        int j;
+        if (n_handles < 1 || n_handles > A) return ORC_ERR_ARG;
+        for (j = 0; j < n_handles; j++) if (handles[j] < 0 || handles[j] >= n_handles) return ORC_ERR_ARG;
+    }
     if (pred_depth >= 0) {
         p.depth = pred_depth; p.T = pred_depth + 1;
-        p.n = 0; p.list = NULL;
+        p.n = handles ? n_handles : 0; p.list = handles;
         p.pos = (int *)malloc(sizeof(int) * (size_t)p.T * A);
         p.dir = (int *)malloc(sizeof(int) * (size_t)p.T * A);
         py_predict(e, &p);

@@ -45,6 +45,7 @@ def lib():
         _lib.orc_motion_check.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_obs_cutils_reset.argtypes = [C.c_void_p]
         _lib.orc_obs_cutils.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        _lib.orc_obs_pytree_handles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib.orc_obs_cutils_handles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7
         _lib.orc_obs_pytree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_mt_seed_by_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -146,10 +147,16 @@ class OracleEnv:
             raise RuntimeError("orc_obs_cutils rc=%d %s" % (rc, lib().orc_last_error().decode()))
         return out
 
-    def obs_pytree(self, max_depth, pred_depth):
+    def obs_pytree(self, max_depth, pred_depth, handles=None):
+        """handles: get_many(handles) of the upstream builder with a list (a permutation of 0 .. n-1, observations.py:60-115): the trees of
+        ALL agents (row i = agent i) against the predictions of the listed handles only"""
         n = (4 ** (max_depth + 1) - 1) // 3
         out = np.zeros((self.A, n, 12), dtype=np.float64)
-        rc = lib().orc_obs_pytree(self.h, max_depth, pred_depth, _p(out))
+        if handles is not None:
+            hs = np.ascontiguousarray(handles, dtype=np.int32)
+            rc = lib().orc_obs_pytree_handles(self.h, max_depth, pred_depth, _p(hs), len(hs), _p(out))
+        else:
+            rc = lib().orc_obs_pytree(self.h, max_depth, pred_depth, _p(out))
         if rc != 0:
             raise RuntimeError("orc_obs_pytree rc=%d" % rc)
         return out

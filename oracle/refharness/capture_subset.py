@@ -3,7 +3,10 @@
 predicted_pos / predicted_dir then hold one entry per listed handle, in list order; the conflict test works on list positions).
 Only lists that are a permutation of 0 .. n-1 are defined behaviour in the reference (get_possible_conflicting erases position
 `agent.handle` of the list, tool.h:428-434); the real reference is run here on a dense shortest-path-following episode and asked,
-at a few steps, for several such lists -> tests/golden/subset_cfg2.npz (agent states at those steps + handles + the returned forest)."""
+at a few steps, for several such lists -> tests/golden/subset_cfg2.npz (agent states at those steps + handles + the returned forest).
+Round 6: the UPSTREAM builder's get_many(handles) on the same lists at the same steps (observations.py:60-115: predicted_pos / predicted_dir
+hold the listed handles' predictions in list order, the conflict test deletes list position `handle` and reads env.agents[position].state,
+:337-366) -> pytree_<k> f64[snapshots, len(handles), 21, 12] (depth 2, predictor depth 30), rows in list order."""
 import os
 import sys
 
@@ -26,6 +29,10 @@ def main():
     perm = rng.permutation(12).tolist()
     lists.append(perm)
     snaps, steps, actions = [], [], []
+    up = cg.PyTreeObs(max_depth=2, predictor=cg.ShortestPathPredictorForRailEnv(30))
+    up.set_env(env)
+    up.reset()
+    pytrees = {k: [] for k in range(len(lists))}
     t = 0
     forests = {k: [] for k in range(len(lists))}
     adjs = {k: [] for k in range(len(lists))}
@@ -50,6 +57,13 @@ def main():
                 forests[k].append(np.array(nodes, dtype=np.float32))
                 adjs[k].append(np.array(adj, dtype=np.int32))
                 attrs[k].append(np.array(attr, dtype=np.float32))
+                got = up.get_many(hs)                 # (pure reads of the env: the cutils builder's sticky flags are not involved)
+                rows = []
+                for h in hs:
+                    o = []
+                    cg.flatten_pytree(got[h], 0, 2, o)
+                    rows.append(o)
+                pytrees[k].append(np.array(rows, dtype=np.float64))
             _, props, _ = env.obs_builder.get_properties()
             out.setdefault("deadlocked", []).append(np.array(props["deadlocked"], dtype=np.int32))
     out["sig"] = np.stack(out["sig"]); out["deadlocked"] = np.stack(out["deadlocked"])
@@ -62,10 +76,14 @@ def main():
         out["forest_%d" % k] = np.stack(forests[k])
         out["adjacency_%d" % k] = np.stack(adjs[k])
         out["attr_%d" % k] = np.stack(attrs[k])
+        out["pytree_%d" % k] = np.stack(pytrees[k])
     path = os.path.join(cg.GOLD, "subset_cfg2.npz")
     np.savez_compressed(path, **out)
     on = (out["snaps"][:, :, 0] >= 0).sum(1)
     diff = [int((out["forest_%d" % k][:, :len(hs)] != out["forest_0"][:, hs]).any(axis=(2, 3)).sum()) for k, hs in enumerate(lists)]
+    full = out["pytree_0"]
+    diff_py = [int((out["pytree_%d" % k] != full[:, hs]).any(axis=(2, 3)).sum()) for k, hs in enumerate(lists)]
+    print("upstream trees that differ from the full-list call per list:", diff_py)
     print("subset_cfg2: A=%d snapshots at %s, on-map %s, trees that differ from the full-list call per list: %s -> %.0f KB" % (A, steps, on.tolist(), diff, os.path.getsize(path) / 1024))
 
 

@@ -88,7 +88,11 @@ def test_upstream_tree_builder_and_positions_map(depth):
         assert ch == -np.inf or (isinstance(ch, Node) and (set(ch.childs) == {"L", "F", "R", "B"} if depth > 1 else ch.childs == {}))
     one = env.obs_builder.get(2)
     assert isinstance(one, Node)
-    np.testing.assert_array_equal(env.obs_builder.get_many_dense([2])[2], dense_from_nodes(one, depth))
+    # get(handle) is the agent's node of get_many(every handle) (the predictions the last get_many prepared, observations.py:117-254);
+    # get_many([2]) alone is a ONE-entry prediction list in the reference, whose conflict test then deletes position 2 of it: IndexError
+    np.testing.assert_array_equal(env.obs_builder.get_many_dense(None)[2], dense_from_nodes(one, depth))
+    with pytest.raises(IndexError, match="out of bounds"):
+        env.obs_builder.get_many_dense([2])
     np.testing.assert_array_equal(env.agent_positions, env._batch.positions_map(0))
     pm = env.agent_positions
     exp = np.full((env.height, env.width), -1, dtype=np.int32)

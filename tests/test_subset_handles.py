@@ -18,13 +18,14 @@ def test_oracle_reproduces_the_reference_on_handle_subsets():
     fx = util.load("subset_cfg2")
     e = orc.OracleEnv(fx)
     snap = {int(t): k for k, t in enumerate(fx["snap_steps"])}
-    n_diff = 0
+    n_diff = n_diff_py = 0
     for t, a in enumerate(fx["actions"]):
         e.step(a)
         full = e.obs_cutils(31, 500)           # (every step: the deadlock flags are sticky)
         if t + 1 not in snap:
             continue
         k = snap[t + 1]
+        full_py = e.obs_pytree(2, 30)
         np.testing.assert_array_equal(e.state(), fx["snaps"][k], err_msg=f"state at step {t + 1}")
         for j, hs in enumerate(_lists(fx)):
             o = full if hs == list(range(e.A)) else e.obs_cutils(31, 500, handles=hs)
@@ -32,7 +33,11 @@ def test_oracle_reproduces_the_reference_on_handle_subsets():
             np.testing.assert_array_equal(o["adjacency"][hs], fx["adjacency_%d" % j][k], err_msg=f"step {t + 1} list {hs} adjacency")
             np.testing.assert_array_equal(o["attr"], fx["attr_%d" % j][k], err_msg=f"step {t + 1} list {hs} attr (all agents)")
             n_diff += int((o["forest"][hs] != full["forest"][hs]).any())
-    assert n_diff >= 10            # the subsets do change the trees
+            # round 6: the UPSTREAM builder on the same list (observations.py:60-115; depth 2, predictor depth 30), rows in list order
+            py = e.obs_pytree(2, 30) if hs == list(range(e.A)) else e.obs_pytree(2, 30, handles=hs)
+            np.testing.assert_array_equal(py[hs], fx["pytree_%d" % j][k], err_msg=f"step {t + 1} list {hs} upstream tree")
+            n_diff_py += int((py[hs] != full_py[hs]).any()) if hs != list(range(e.A)) else 0
+    assert n_diff >= 10 and n_diff_py >= 10            # the subsets do change the trees
 
 
 @pytest.mark.gpu
@@ -62,3 +67,42 @@ def test_plugin_get_many_with_handle_subsets_matches_the_reference():
     for bad in ([5], [0, 2], [1, 1], [0, 1, A]):
         with pytest.raises(ValueError, match="undefined"):
             b.get_many(bad)
+
+
+@pytest.mark.gpu
+def test_upstream_plugin_get_many_with_handle_lists_matches_the_reference():
+    """round 6: the UPSTREAM builder's get_many(handles) with a list (observations.py:60-115, 337-366) through the plug-in on a caller-owned
+    env -- the reference's nodes for every captured list (depth 2, predictor depth 30), an IndexError where the reference raises one"""
+    from flatland_marl_amd.plugin import TreeObsUpstream
+    from flatland_marl_amd import rail_env as _re
+    fx = util.load("subset_cfg2")
+    class _Fx(dict):
+        files = property(lambda self: list(self))
+    st = {k: fx[k] for k in ("grid", "init_pos", "init_dir", "target", "speed", "earliest", "latest", "T")}
+    env = util.DuckEnv(_Fx(st, **{"s_" + k: fx["snaps"][:, :, i] for i, k in enumerate(util.STATE_NAMES)}))
+    class _Pred:                                  # (what the builder reads of ShortestPathPredictorForRailEnv: max_depth; set_env)
+        max_depth = 30
+        def set_env(self, env): pass
+    b = TreeObsUpstream(2, _Pred())
+    b.set_env(env)
+    b.reset()
+    A = env.get_num_agents()
+    n_diff = 0
+    for k, T in enumerate(fx["snap_steps"]):
+        env.goto(k + 1)
+        env._elapsed_steps = int(T)
+        full = b.get_many_dense(list(range(A)))
+        for j, hs in enumerate(_lists(fx)):
+            got = b.get_many_dense(hs)
+            assert list(got) == hs
+            np.testing.assert_array_equal(np.stack([got[h] for h in hs]), fx["pytree_%d" % j][k], err_msg=f"T={T} list {hs} upstream tree")
+            n_diff += int(any((got[h] != full[h]).any() for h in hs))
+            nodes = b.get_many(hs)                # ... and as the reference's Node namedtuples
+            assert list(nodes) == hs and nodes[hs[0]].dist_min_to_target == got[hs[0]][0][6]
+        assert b.get(3).dist_min_to_target == full[3][0][6]          # get(handle): the agent's node of get_many(every handle)
+    assert n_diff >= 10
+    for bad in ([5], [0, 2], [0, 1, A]):
+        with pytest.raises(IndexError, match="out of bounds"):
+            b.get_many(bad)
+    with pytest.raises(ValueError, match="repeated"):
+        b.get_many([1, 1])
