@@ -307,6 +307,11 @@ int fl_load_env(fl_batch *h, int b, const uint16_t *grid, const int32_t *init_po
                 ut.size(), rail_cells, h->d.Ucap, h->d.Rcap);
         return FL_ERR_CAPACITY;
     }
+    {   // another map or other unique targets than the staged ones: whatever env b's slabs hold is stale, whatever its content key says
+        bool same = h->h_loaded[b] && h->h_U[b] == (int)ut.size() && memcmp(&h->h_grid[b * HW], grid, HW * 2) == 0;
+        for (size_t u = 0; same && u < ut.size(); u++) same = h->h_ut[(size_t)b * A + u] == ut[u];
+        if (!same) h->h_built[b] = 0;
+    }
     memcpy(&h->h_grid[b * HW], grid, HW * 2);
     for (int i = 0; i < A; i++) {
         const size_t g = (size_t)b * A + i;
@@ -383,10 +388,8 @@ static int share_tables(fl_batch *h) {
         }
         i = j;
     }
-    for (int b = 0; b < B; b++) {
-        h->h_need[b] = h->h_tab[b] == b && h->h_built[b] != h->h_key[b];
-        if (h->h_need[b]) h->h_built[b] = h->h_key[b];
-    }
+    // (h_built is set by fl_commit once the table kernels of the h_need envs have run: a commit that fails half way rebuilds them)
+    for (int b = 0; b < B; b++) h->h_need[b] = h->h_tab[b] == b && h->h_built[b] != h->h_key[b];
     HIPCHK(hipMemcpyAsync(h->d.tab, h->h_tab.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->need_dev, h->h_need.data(), B, hipMemcpyHostToDevice, h->stream));
     return FL_OK;
@@ -488,6 +491,8 @@ int fl_commit(fl_batch *h) {
     fl_launch_reset(d, mask, 1, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < B; b++)
+        if (h->h_need[b]) h->h_built[b] = h->h_key[b];   // the owners' slabs hold their content now
     std::fill(h->h_dirty.begin(), h->h_dirty.end(), 0);
     h->committed = true;
     return fl_check(h);
@@ -603,7 +608,8 @@ int fl_check(fl_batch *h) {
             const char *msg = e == FL_ERR_EPISODE_DONE ? "Episode is done, cannot call step()"
                               : e == FL_ERR_STATE_SYNC ? "agent state / position desync"
                               : e == FL_ERR_ZERO_TRANSITION ? "WRONG CELL TYPE detected in tree-search (0 transitions possible)"
-                              : e == FL_ERR_CAPACITY ? "internal capacity exceeded" : "kernel error";
+                              : e == FL_ERR_CAPACITY ? "internal capacity exceeded"
+                              : e == FL_ERR_ARG ? "FL_OBS_KEEP_TREE_ROWS: the tree buffer is not the previous launch's, or was modified in between (FL_OBS_KEEP_VERIFY)" : "kernel error";
             set_err("env %d: %s", b, msg);
             return e;
         }

@@ -85,6 +85,30 @@ __global__ __launch_bounds__(1024) void k_env_order(int B, const uint32_t *__res
     for (int b = tid; b < B; b += 1024) order[atomicAdd(&hist[1023u - (unsigned int)((unsigned long long)cost[b] * 1023ull / top)], 1u)] = b;
 }
 
+// FL_OBS_KEEP_VERIFY (diagnostic): FL_OBS_KEEP_TREE_ROWS rests on the caller's promise that the tree buffer is the previous launch's, untouched
+// -- a buffer that was freed and re-allocated at the same address, or a tensor modified in place (-inf replaced before a network), breaks it
+// silently.  With the switch set, every launch that skips the pre-fill first checks the promise: a row the masks call constant must still be
+// -inf, a row they call real must not be; a violation latches FL_ERR_ARG for the env (fl_check: "tree buffer modified").
+__global__ void k_keep_verify(int B, int A, int n_rows, const double *__restrict__ out, const uint4 *__restrict__ rowmask, int *__restrict__ err) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)B * A * n_rows) return;
+    const long long g = k / n_rows;
+    const int row = (int)(k % n_rows);
+    const uint4 m = rowmask[g];
+    if (!m.w) return;
+    const uint32_t w = row < 32 ? m.x : row < 64 ? m.y : m.z;
+    const bool real = (w >> (row & 31)) & 1u;
+    const double v = out[k * 12];
+    const bool ninf = isinf(v) && v < 0;
+    if (real == ninf) atomicCAS(&err[g / A], 0, FL_ERR_ARG);
+}
+static void obs_keep_verify(const FlDev &d, const ObsArgs &P, const uint4 *rowmask, hipStream_t s) {
+    static const bool verify = getenv("FL_OBS_KEEP_VERIFY") != nullptr;
+    if (!verify || !P.keep_rows || !rowmask || P.n_tree_nodes > 96) return;
+    const long long n = (long long)d.B * d.A * P.n_tree_nodes;
+    hipLaunchKernelGGL(k_keep_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.B, d.A, P.n_tree_nodes, P.tree_out, rowmask, d.err);
+}
+
 #ifndef OBS_ROUND16_DEFAULT
 #define OBS_ROUND16_DEFAULT 0   // rounds of 16 agents on 512 threads, two workgroups a CU (MODE 5) for envs of more than 32 agents
 #endif
@@ -165,17 +189,14 @@ static bool obs_fits_bin(const FlDev &d, ObsArgs &P, const ObsOptions &own, ObsL
 }
 // an exact class's SPLIT launch (its body for the envs that fit, the runtime carving for the few larger maps) goes before a bin class for the
 // whole batch when at least half the envs fit the exact class
-static bool g_fix_allowed;
 template <int FIX>
 static bool exact_split_covers_most(const FlDev &d, ObsArgs &P, const ObsLayout &L) {
     static const bool no_split = getenv("FL_OBS_NO_SPLIT") != nullptr;
     if (no_split || !P.h_R) return false;
     const ObsLayout keep = P.L;
-    const bool keep_allowed = g_fix_allowed;
     P.L = L;
     const int n = obs_split_fits<FIX>(d, P, P.h_R);
     P.L = keep;
-    g_fix_allowed = keep_allowed;
     return 2 * n >= d.B;
 }
 static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o, ObsLayout &L, bool allowed) {
@@ -214,7 +235,7 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
     else if (obs_fits_bin<16>(d, P, o, L)) P.fix = 16;
 }
 
-// (defined above) g_fix_allowed: the last configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
+// (ObsArgs::fix_allowed: this launch's configuration was chosen without the diagnostic overrides that rule the fixed launch classes out)
 // A batch whose LARGEST map exceeds a class's rail cells still has the class's kind of envs in it (the levels of a Round-2 test differ
 // by a few per cent in rail cells; the classes are the BASELINE maps' own sizes): when everything but the rail-cell capacity matches
 // -- agents, builder parameters, and the runtime configuration just chosen for the batch runs the class's MODE and VAR -- the launch
@@ -238,7 +259,7 @@ static int obs_split_fits(const FlDev &d, const ObsArgs &P, const int *h_R) {
 }
 static int obs_take_split_class(const FlDev &d, ObsArgs &P, const int *h_R) {
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr, no_split = getenv("FL_OBS_NO_SPLIT") != nullptr;   // diagnostic
-    if (no_fix || no_split || !g_fix_allowed) return 0;
+    if (no_fix || no_split || !P.fix_allowed) return 0;
     if (P.fix == 14 || P.fix == 19) {
         // the larger large-map bin (no LDS successor table) was taken because of the batch's largest map: the envs that fit the smaller class
         // (with the table) run ITS body, the others the bin's -- one kernel, every env on a compile-time carving (split 2)
@@ -265,7 +286,7 @@ static int obs_take_split_class(const FlDev &d, ObsArgs &P, const int *h_R) {
     return n;
 }
 
-static ObsOptions g_last_options;   // diagnostic (FL_OBS_VERBOSE): the options of the last configuration obs_pick_config chose
+static thread_local ObsOptions g_last_options;   // diagnostic (FL_OBS_VERBOSE): the options of the last configuration obs_pick_config chose
 
 // Choose what lives in LDS so that the workgroup fits 160 KiB.
 static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
@@ -355,8 +376,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
             P.wl_occ_div = d.A <= 32 ? OBS_WL_OCC_DIV : 3;
             // small envs: 4-step buckets (same-box A/B on cfg2: 54.8 us against 55.1 with 2-step and 56.9 with 8-step buckets)
             P.tshift = force_tshift >= 0 ? force_tshift : (d.A <= 31 ? 2 : OBS_TSHIFT);
-            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
-            obs_take_fixed_class(d, P, oo, L, g_fix_allowed);
+            P.fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
+            obs_take_fixed_class(d, P, oo, L, P.fix_allowed != 0);
             P.L = L;
         };
         for (int pk = 0; pk < n_prefs; pk++) {
@@ -429,8 +450,8 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
                             // 2-step buckets where the traffic is and one catch-all bucket for late times (8-step buckets over the
                             // whole horizon measured slower on every map size)
                             P.tshift = force_tshift >= 0 ? force_tshift : OBS_TSHIFT;
-                            g_fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
-                            obs_take_fixed_class(d, P, o, L, g_fix_allowed);
+                            P.fix_allowed = !force_nt && lds_limit == (size_t)160 * 1024 && force_tshift < 0;
+                            obs_take_fixed_class(d, P, o, L, P.fix_allowed != 0);
                             P.L = L;
                             return true;
                         }
@@ -530,6 +551,7 @@ int fl_launch_obs_both(FlObsScratch &o, const FlDev &d, int max_nodes, int pred_
     const int n_split = obs_take_split_class(d, P, o.h_R);
     o.last_fix = P.fix; o.last_split = P.split; o.last_fit = P.split ? n_split : P.fix ? d.B : 0;
     obs_verbose(P);
+    obs_keep_verify(d, P, rowmask, s);
     FlObsScratch u = o;
     if (P.merged == 1) u.order = nullptr;   // small envs, one round: workgroup k builds env k
     else u = fl_obs_env_order(o, d, s);
@@ -579,6 +601,7 @@ int fl_launch_obs_tree(FlObsScratch &o, const FlDev &d, int max_depth, int pred_
     struct Restore { FlObsScratch &o; uint4 *m; ~Restore() { o.rowmask = m; } } restore{o, rowmask};
     o.last_fix = 0; o.last_split = 0; o.last_fit = 0;
     obs_verbose(P);
+    obs_keep_verify(d, P, rowmask, s);
     return fl_obs_launch_m1(obs_var(P), d, fl_obs_env_order(o, d, s), P, s);
 }
 

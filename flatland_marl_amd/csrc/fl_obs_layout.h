@@ -415,6 +415,7 @@ struct ObsArgs {
                        // the policy network takes them (fl_obs_cutils_policy; cutils_rows_orders)
     int cutils_alone;  // host side: a launch of the flatland_cutils builder alone may take the one-pass kernels (MODE 6 / 7 / 8, classes 6 .. 10)
     int wide;          // the batch has several envs per CU (host side: obs_pick_config then prefers workgroups that fit two a CU for small envs)
+    int fix_allowed;   // host side: the configuration was chosen without the diagnostic overrides that rule the fixed launch classes out
     const int *h_R;    // host side: the envs' rail cells (FlObsScratch::h_R; null: unknown) -- an exact class's split launch goes before the bin classes
     int split;         // (2: as 1, but the envs that do not fit run the larger bin class 14 / 19 -- every env on a compile-time carving.)  1: fix != 0 and the batch's capacities exceed the class's rail cells: the class serves the envs that fit it (d.R[b] <=
                        // ObsFixed<fix>::dims.Rcap, decided per workgroup), every other env of the launch runs the same kernel's runtime-carving

@@ -376,7 +376,10 @@ class BatchedRailEnv:
 
     def keep_tree_rows(self, on=True):
         """FL_OBS_KEEP_TREE_ROWS: the upstream-tree tensor this object hands out is its own buffer, the same from call to call -- as long
-        as the caller does not write into it, the builder only updates the rows that change (no -inf pre-fill of the slab per call)."""
+        as the caller does not write into it, the builder only updates the rows that change (no -inf pre-fill of the slab per call).
+        HAZARD: obs_tree / obs_both / step_obs hand out that very tensor; an in-place op on it (replacing -inf before a network, say) breaks
+        the promise silently -- clone it first.  FL_OBS_KEEP_VERIFY=1 (environment, diagnostic) checks the promise before every such launch
+        and latches an error for check() when a constant row is no longer -inf or a real row is."""
         if not hasattr(lib(), "fl_obs_set_mode"):
             raise FlatlandHipError(1, "the loaded library has no fl_obs_set_mode (an older build loaded through --lib?)")
         _chk(lib().fl_obs_set_mode(self.h, 1 if on else 0))
