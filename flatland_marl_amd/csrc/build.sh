@@ -7,7 +7,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${OUT:-$HERE/libflatland_hip.so}"
 OBJDIR="${OBJDIR:-$HERE/build}"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-UNITS=(fl_obs_s4b fl_obs_f16 fl_obs_f20 fl_obs_f14 fl_obs_s9b fl_obs_f19 fl_obs_f15 fl_obs_f13 fl_obs_f12 fl_obs_f18 fl_obs_f17 fl_obs_f11 fl_obs_f5 fl_obs_f10 fl_obs_f9 fl_obs_s9 fl_obs_f8 fl_obs_f7 fl_obs_m7 fl_obs_m8 fl_obs_m6 fl_obs_f6 fl_obs_s4 fl_obs_s3 fl_obs_s2 fl_obs_m2 fl_obs_m4 fl_obs_m5 fl_obs_f4 fl_obs_f3 fl_obs_f2 fl_obs_m3 fl_obs_m0 fl_obs_m1 fl_obs_f1 fl_host fl_step fl_dmap fl_obs)
+UNITS=(fl_obs_s4b fl_obs_f21 fl_obs_f16 fl_obs_f20 fl_obs_f14 fl_obs_s9b fl_obs_f19 fl_obs_f15 fl_obs_f13 fl_obs_f12 fl_obs_f18 fl_obs_f17 fl_obs_f11 fl_obs_f5 fl_obs_f10 fl_obs_f9 fl_obs_s9 fl_obs_f8 fl_obs_f7 fl_obs_m7 fl_obs_m8 fl_obs_m6 fl_obs_f6 fl_obs_s4 fl_obs_s3 fl_obs_s2 fl_obs_m2 fl_obs_m4 fl_obs_m5 fl_obs_f4 fl_obs_f3 fl_obs_f2 fl_obs_m3 fl_obs_m0 fl_obs_m1 fl_obs_f1 fl_host fl_step fl_dmap fl_obs)
 # -disable-machine-licm: the observation kernel sits at its 128-VGPR / 102-SGPR ceiling (1024 threads a workgroup); hoisting
 # loop invariants out of the loops over the rounds of trees only adds spills (same-box A/B: cfg3 / cfg4 / cfg5 2.4 - 3.2 % faster
 # without it, cfg2 unchanged)

@@ -210,7 +210,9 @@ static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o
         else if (obs_fits_fixed<8>(d, P, o, L)) P.fix = 8;
         else if (obs_fits_fixed<9>(d, P, o, L)) P.fix = 9;
         else if (obs_fits_fixed<10>(d, P, o, L)) P.fix = 10;
+        else if (obs_fits_fixed<21>(d, P, o, L)) P.fix = 21;
         else if (no_bins || !P.cutils_alone) return;   // (FL_OBS_NO_CUTILS_MERGE: the stand-alone kernel as it ran before round 6)
+        else if (obs_fits_bin<21>(d, P, o, L)) P.fix = 21;
         else if (obs_fits_bin<17>(d, P, o, L)) P.fix = 17;
         else if (obs_fits_bin<8>(d, P, o, L)) P.fix = 8;
         else if (obs_fits_bin<18>(d, P, o, L)) P.fix = 18;
@@ -338,7 +340,11 @@ static bool obs_pick_config(const FlDev &d, ObsArgs &P) {
     // env per CU the 512-thread workgroup alone takes 75 us against 53 (profiles/r05_cfg2_bsweep.json).  FL_OBS_ROUND16=2 forces it
     // for any batch, =0 rules it out.
     const bool r16_small = d.A <= 32 && (round16_env >= 0 ? round16_env == 2 : P.wide != 0);
-    const bool r16 = (r16_small || (d.A > 32 && (round16_env >= 0 ? round16_env != 0 : OBS_ROUND16_DEFAULT != 0))) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
+    // ... and, round 6, envs of more than 32 agents when the builder runs ALONE on small maps (cfg3's kind) in a wide batch: without the second index
+    // and the upstream tables its LDS lists and items fit 80 KB (class 21; same box at 1 024 cfg3 envs, runtime carving: 0.467 -> 0.419 ms)
+    // (only where class 21 holds the batch: beyond its capacities the one-a-CU bin classes are the better choice)
+    const bool r16_alone = !up && P.cutils_alone && d.A > 32 && P.wide != 0 && d.Rcap <= ObsFixed<21>::dims.Rcap && d.A <= ObsFixed<21>::dims.A;
+    const bool r16 = (r16_small || (d.A > 32 && (round16_env >= 0 ? round16_env != 0 : (OBS_ROUND16_DEFAULT != 0 || r16_alone)))) && (!force_nt || force_nt == 512) && ok(force.nt, 512);
     const int merged_nt = r16 ? 512 : OBS_NT;
     const size_t merged_limit = r16 ? std::min(lds_limit, (size_t)80 * 1024) : lds_limit;
     if (!no_merge && merge_ok && P.compact_t && d.rkey == nullptr && (r16 || ((!force_nt || force_nt == OBS_NT) && ok(force.nt, OBS_NT))) &&
@@ -517,6 +523,7 @@ int fl_launch_obs_cutils(FlObsScratch &o, const FlDev &d, int max_nodes, int pre
     case 18: return fl_obs_launch_f18(d, u, P, s);
     case 19: return fl_obs_launch_f19(d, u, P, s);
     case 20: return fl_obs_launch_f20(d, u, P, s);
+    case 21: return fl_obs_launch_f21(d, u, P, s);
     case 6: return fl_obs_launch_f6(d, u, P, s);
     case 7: return fl_obs_launch_f7(d, u, P, s);
     case 8: return fl_obs_launch_f8(d, u, P, s);

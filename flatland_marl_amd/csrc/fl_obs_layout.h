@@ -191,7 +191,10 @@ __host__ __device__ constexpr ObsLayout obs_layout_c(const ObsDims &d, const Obs
 #define OBS_FIX4_RCAP 2816   // classes 4 / 9 (round 6: bins): cfg5 (2 680 rail cells) and, with the LDS successor table still fitting, Test_12 (2 745) and
 #define OBS_FIX4_A 432       // the first level of Test_14 (2 807 cells, 425 agents)
 #define OBS_FIX3_WL_HEAD (10 * 1024)
-#define OBS_WL_HEAD_MAX (16 * 1024)   // LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
+#ifndef OBS_WL_HEAD_MAX
+#define OBS_WL_HEAD_MAX (32 * 1024)   // (round 6: 16 -> 32 KB, the builder alone at cfg4 0.243 -> 0.240 ms same box; both builders never have that much left)
+#endif
+// LDS head of HBM work lists: whatever the carving leaves, in KB steps, at most this, at least OBS_WL_HEAD_MIN
 #define OBS_WL_HEAD_MIN (4 * 1024)
 #define OBS_ALONE_LDS_LISTS_RCAP 320   // the flatland_cutils builder alone, rounds of 32 agents: LDS work lists up to this many rail cells, HBM lists with an LDS head beyond
 template <int FIX> struct ObsFixed;
@@ -314,6 +317,17 @@ template <> struct ObsFixed<14> {   // both builders, two stages, no LDS success
     static constexpr ObsDims dims = {OBS_FIXB_RCAP, OBS_FIXB_A, 0, 0};
     static constexpr ObsShape shape = {0, N_WORDS_C * OBS_CAP_C, N_WORDS_T * OBS_CAP_T_COMPACT, 4, 30};
     static constexpr ObsOptions opt = {OBS_NT, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
+};
+// 21: class 7's envs (the builder alone, at most 80 agents / 232 rail cells) in rounds of 16 agents on 512 threads and at most 80 KB of LDS, TWO
+// workgroups a CU, for batches of several envs per CU (obs_batch_is_wide) -- the builder alone leaves the LDS that the two-a-CU kernel of both
+// builders lacked (round 4: cfg3 0.715 -> 0.81 ms): same box, runtime carving both sides, cfg3 at 1 024 envs 0.467 -> 0.419 ms
+template <> struct ObsFixed<21> {
+    static constexpr int max_nodes = 31, pred_depth = 500, max_depth = 0;
+    static constexpr int agents = 0;
+    static constexpr ObsDims dims = {232, 80, 0, 0};
+    static constexpr ObsShape shape = {3, N_WORDS_C * OBS_CAP_C, 0, 0, 0};
+    static constexpr ObsOptions opt = {512, 16 * 1024, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 1, 4096, 0};
     static constexpr ObsLayout L = obs_layout_c(dims, shape, opt);
 };
 // 15 / 18: rounds of 32 agents on maps beyond class 3's: at most 100 agents / 1 344 rail cells (Test_10: 1 265 / 1 319), HBM work lists with an
@@ -457,6 +471,7 @@ int fl_obs_launch_f15(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, h
 int fl_obs_launch_f18(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f16(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f20(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
+int fl_obs_launch_f21(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f17(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_f19(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);
 int fl_obs_launch_s4b(const FlDev &d, const FlObsScratch &o, const ObsArgs &P, hipStream_t s);

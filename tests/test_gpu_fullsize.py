@@ -239,12 +239,13 @@ def test_other_launch_paths_give_the_same_bytes():
 
 # ---- the flatland_cutils builder ALONE (what the reference's solution launches: solution/eval_env.py:15-17 builds TreeCutils(31, 500) only):
 # fl_obs_cutils on the one-pass kernels without the upstream builder (MODE 6 / 7 / 8) and their fixed launch classes 6 .. 10
-CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2816, 10: 256}
+CUTILS_ALONE_CAP = {6: 256, 7: 232, 8: 680, 9: 2816, 10: 256, 21: 232}
 
 
 @pytest.mark.parametrize("workload,B,steps,picks,shadow,distinct,klass", [
     ("cfg2", 256, 100, (0, 101, 255), (3, 5, 254), 0, (6, 0)),            # the bench's cfg2_cutils launch: k_obs<6,0,6>, one env per CU
-    ("cfg3", 1024, 48, (0, 766, 1023), (3, 1022), 10, (7, 0)),           # k_obs<7,0,7>
+    ("cfg3", 256, 48, (0, 101, 255), (3, 254), 10, (7, 0)),              # one env per CU: k_obs<7,0,7>
+    ("cfg3", 1024, 48, (0, 766, 1023), (3, 1022), 10, (21, 0)),          # four envs per CU: k_obs<8,0,21>, rounds of 16 agents, two workgroups a CU
     ("cfg4", 512, 40, (0, 256, 511), (3, 510), 4, (8, 0)),               # k_obs<7,0,8> with k_env_order
     ("cfg5", 256, 32, (0, 85, 255), (3, 254), 0, (9, 0)),                # k_obs<0,2,9>: the stand-alone kernel with its carving compiled in
     ("cfg5", 256, 32, (0, 85, 255), (3, 254), 2, (9, 2)),                # two levels of the row: k_obs_split<0,2,9,19>, both class bodies

@@ -125,7 +125,7 @@ def test_upstream_plugin_inside_the_real_reference_railenv(cap, monkeypatch):
     _Recorder.made.clear()
     import torch
     A_box = []
-    _Recorder.obs_tree = lambda self, d, p: A_box.append((d, p)) or torch.full((1, self.A, (4 ** (d + 1) - 1) // 3, 12), -np.inf, dtype=torch.float64)
+    _Recorder.obs_tree = lambda self, d, p, handles=None: A_box.append((d, p)) or torch.full((1, self.A, (4 ** (d + 1) - 1) // 3, 12), -np.inf, dtype=torch.float64)
     try:
         builder = plugin.TreeObsUpstream(2, ShortestPathPredictorForRailEnv(30))
         env, mp = cap.make_env(cap.csv_row("Test_0", "Level_0"), obs=builder)
