@@ -19,12 +19,12 @@ MODES = {"default": {}, "one_a_cu": {"FL_OBS_ROUND16": "0"}, "two_a_cu": {"FL_OB
          "nofix_two_a_cu": {"FL_OBS_NO_FIX": "1", "FL_OBS_ROUND16": "2"}}
 
 
-def child(workload, bs, depth, steps):
+def child(workload, bs, depth, steps, pack=0):
     sys.path.insert(0, ROOT)
     import bench
     out = {}
     for B in bs:
-        r = bench.run_workload(workload, depth, 30, B, steps, 20, 0, 1, 0, event_steps=32)
+        r = bench.run_workload(workload, depth, 30, B, steps, 20, 0, 1, 0, event_steps=32, pack=pack)
         out[str(B)] = dict(value=r["value"], ms_per_step=r["ms_per_step"], kernel_ms=r["kernel_ms"], on_map=r["on_map_agents_per_env"], launch_class=r.get("launch_class"))
         print("B=%d %.1f M agent-steps/s, %.3f ms/step, kernels %s" % (B, r["value"] / 1e6, r["ms_per_step"], r["kernel_ms"]), file=sys.stderr, flush=True)
     print("RESULT " + json.dumps(out))
@@ -37,17 +37,18 @@ def main():
     ap.add_argument("--modes", default="one_a_cu,two_a_cu,default")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--pack", type=int, default=0, help="1 with --depth 0: the consumer's path (the flatland_cutils builder alone writing the policy's tensors)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--child", default=None)
     a = ap.parse_args()
     bs = [int(x) for x in a.bs.split(",")]
     if a.child:
-        return child(a.workload, bs, a.depth, a.steps)
-    res = {"workload": a.workload, "tree_depth": a.depth, "steps": a.steps, "modes": {}}
+        return child(a.workload, bs, a.depth, a.steps, a.pack)
+    res = {"workload": a.workload, "tree_depth": a.depth, "pack": a.pack, "steps": a.steps, "modes": {}}
     for m in a.modes.split(","):
         env = dict(os.environ, **MODES[m])
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", m, "--workload", a.workload, "--bs", a.bs,
-                            "--depth", str(a.depth), "--steps", str(a.steps)], env=env, capture_output=True, text=True)
+                            "--depth", str(a.depth), "--steps", str(a.steps), "--pack", str(a.pack)], env=env, capture_output=True, text=True)
         sys.stderr.write(p.stderr[-3000:])
         if p.returncode != 0:
             res["modes"][m] = {"error": p.stderr[-500:]}

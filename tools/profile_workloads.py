@@ -9,7 +9,8 @@ and pmc_traffic.json (per workload and kernel: mean FETCH_SIZE / WRITE_SIZE per 
 upper bound for narrow gathers -- stamped with the sha of the kernel sources).  Copy what is to be judged into profiles/.
 
   python tools/profile_workloads.py r02 [cfg2:2 cfg3:3 cfg4:2 cfg5:3:rebuild cfg4:2:distinct4 cfg5:3:rebuild:distinct2]
-(":distinctK": K distinct generated maps instead of the committed base envs -- key <W>_d<D>_distinctK)
+(":distinctK": K distinct generated maps instead of the committed base envs -- key <W>_d<D>_distinctK; ":pack" with depth 0: the flatland_cutils
+builder alone writing the policy's tensors -- key <W>_d0; ":keeprows": FL_OBS_KEEP_TREE_ROWS -- key ..._keeprows)
 """
 import collections
 import csv
@@ -24,9 +25,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha only; nothing touches the GPU at import)
 
-NAMES = {"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs<2": "k_obs<cutils+tree>", "k_obs<3": "k_obs<cutils+tree>", "k_obs<4": "k_obs<cutils+tree>",
-         "k_obs<5": "k_obs<cutils+tree>", "k_obs_split<": "k_obs<cutils+tree>", "k_step<": "k_step<synth>",
-         "k_distance_map": "k_distance_map", "k_hop8": "k_hop8", "k_nexthop": "k_nexthop", "k_segments": "k_segments"}
+TABLES = {"k_step<": "k_step<synth>", "k_distance_map": "k_distance_map", "k_hop8": "k_hop8", "k_nexthop": "k_nexthop", "k_segments": "k_segments", "k_policy_pack": "k_policy_pack"}
+
+
+def names_of(pack):
+    """kernel-name prefix -> the stage name bench.py looks the stored traffic up under"""
+    n = dict(TABLES)
+    if pack:      # the flatland_cutils builder alone writing the policy's tensors: MODE 0 / 6 / 7 / 8 and the large-map split kernels
+        n.update({"k_obs<%d" % m: "k_obs<cutils,i64>" for m in (0, 6, 7, 8)})
+        n["k_obs_split<0"] = "k_obs<cutils,i64>"
+    else:
+        n.update({"k_obs<0": "k_obs<cutils>", "k_obs<1": "k_obs<tree>", "k_obs_split<": "k_obs<cutils+tree>"})
+        n.update({"k_obs<%d" % m: "k_obs<cutils+tree>" for m in (2, 3, 4, 5)})
+    return n
+
+
+NAMES = names_of(False)
 tag = sys.argv[1]
 specs = sys.argv[2:] or ["cfg2:2", "cfg3:3", "cfg4:2", "cfg5:3:rebuild"]
 out_dir = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
@@ -45,7 +59,7 @@ def run(args, bench_args, tmp):
     return p
 
 
-def pmc_mean(tmp, counter):
+def pmc_mean(tmp, counter, NAMES):
     acc, n = collections.defaultdict(list), collections.Counter()
     for path in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
@@ -61,13 +75,19 @@ for spec in specs:
     parts = spec.split(":")
     w, depth, rebuild = parts[0], int(parts[1]), "rebuild" in parts[2:]
     distinct = next((int(x[len("distinct"):]) for x in parts[2:] if x.startswith("distinct")), 0)
-    key = "%s_d%d" % (w, depth) + ("_distinct%d" % distinct if distinct else "")
+    pack, keeprows = "pack" in parts[2:], "keeprows" in parts[2:]      # (pack: depth 0, fl_obs_cutils_policy; keeprows: FL_OBS_KEEP_TREE_ROWS)
+    NAMES = names_of(pack)
+    key = "%s_d%d" % (w, depth) + ("_distinct%d" % distinct if distinct else "") + ("_keeprows" if keeprows else "")
     steps = {"cfg2": 300, "cfg3": 100, "cfg4": 100, "cfg5": 60}[w]
     bargs = ["--no-cpu-baseline", "--no-extra-workloads", "--workload", w, "--tree-depth", str(depth), "--steps", str(steps), "--warmup", "20"]
     if rebuild:
         bargs.append("--dm-rebuild")
     if distinct:
         bargs += ["--distinct-maps", str(distinct)]
+    if pack:
+        bargs += ["--pack", "1"]
+    if keeprows:
+        bargs.append("--keep-rows")
     tmp = "/tmp/prof_%s_%d" % (key, os.getpid())
     p = run(["--kernel-trace", "--stats", "--output-format", "csv"], bargs, tmp)
     stats = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
@@ -78,9 +98,9 @@ for spec in specs:
     except Exception:
         pass
     run(["--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv"], bargs, tmp)
-    f, nf = pmc_mean(tmp, "FETCH_SIZE")
+    f, nf = pmc_mean(tmp, "FETCH_SIZE", NAMES)
     run(["--pmc", "WRITE_SIZE", "--kernel-trace", "--output-format", "csv"], bargs, tmp)
-    wv, nw = pmc_mean(tmp, "WRITE_SIZE")
+    wv, nw = pmc_mean(tmp, "WRITE_SIZE", NAMES)
     shutil.rmtree(tmp, ignore_errors=True)
     import flatland_marl_amd.workload as wl
     traffic[key] = {k: dict(envs=wl.WORKLOADS[w]["B"], tag=tag, kernel_source_sha=sha, launches=min(nf[k], nw.get(k, 0)),
@@ -91,4 +111,5 @@ for spec in specs:
     if os.path.exists(kept):
         for row in list(csv.DictReader(open(kept)))[:6]:
             print("   ", row.get("Name", "")[:40], row.get("Calls"), row.get("AverageNs"), flush=True)
-json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# (several GPU-box calls fill one directory -- a call is limited to 20 minutes --, each with its own file: tools/install_artefacts.py merges them)
+json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic%s.json" % ("_" + os.environ["PART"] if os.environ.get("PART") else "")), "w"), indent=1, sort_keys=True)

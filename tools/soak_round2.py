@@ -2,9 +2,10 @@
 """Soak of the NON-BASELINE shapes: one level of every test of the Round-2 parameter table (Test_0 ... Test_14, fifteen shapes) as one
 MixedBatch, stepped for hundreds of steps on the on-device SHORTEST-PATH-FOLLOWING action stream (kind 2: the large maps fill up,
 agents arrive, queues and deadlocks form) and shadowed by the CPU oracle on every step: state, rewards, dones, the flatland_cutils
-observation every step and the upstream depth-2 tree every fourth.  13 of the 15 shapes run the runtime-carving kernels.
+observation every step, the upstream depth-2 / depth-3 tree and the flatland_cutils builder alone every fourth each.  Round 6: every shape runs
+a launch class (the BASELINE shapes their exact classes, the others bin classes).
 
-  python tools/soak_round2.py [steps=320] [level=1] [out=profiles/r05_soak_round2.txt]"""
+  python tools/soak_round2.py [steps=320] [level=1] [out=profiles/r06_soak_round2.txt]"""
 import os
 import sys
 import time
@@ -35,13 +36,20 @@ def main():
     tc = [0] * n
     stat = [dict(max_on_map=0, arrived=0, max_deadlocked=0, episodes=0, conflicts=0) for _ in range(n)]
     t_start = time.time()
+    cls_both, cls_alone = {}, None
     for t in range(steps):
         acts = []
         for i, o in enumerate(oracles):
             s = o.state()
             acts.append(synth.spfollow_actions(seed, mb.stream_of(i), tc[i], s[:, 3], s[:, 0:2], s[:, 2], np.asarray(envs[i]["grid"]), *dms[i]))
         res = mb.step_synth(seed, kind=2, auto_reset=True)
-        both = mb.obs_both(2, 30)
+        depth = 3 if t % 4 == 1 else 2
+        both = mb.obs_both(depth, 30)
+        if t < 2:
+            cls_both[depth] = [g.last_obs_class() for g in mb.groups]
+        alone = mb.obs_cutils() if t % 4 == 2 else None       # the flatland_cutils builder alone: its own kernels and classes, same tensors
+        if t == 2:
+            cls_alone = [g.last_obs_class() for g in mb.groups]
         for i, o in enumerate(oracles):
             r_o, d_o, da = o.step(acts[i])
             tc[i] += 1
@@ -53,8 +61,10 @@ def main():
             exp = o.obs_cutils(31, 500)
             for key, okey in CUTILS:
                 assert np.array_equal(cut[key].cpu().numpy(), exp[okey], equal_nan=True), (tests[i], t, key)
-            if t % 4 == 3:
-                assert np.array_equal(tree.cpu().numpy(), o.obs_pytree(2, 30), equal_nan=True), (tests[i], t, "depth-2 tree")
+                if alone is not None:
+                    assert np.array_equal(mb.pick(i, alone)[key].cpu().numpy(), exp[okey], equal_nan=True), (tests[i], t, key, "builder alone")
+            if t % 4 in (1, 3):
+                assert np.array_equal(tree.cpu().numpy(), o.obs_pytree(depth, 30), equal_nan=True), (tests[i], t, "depth-%d tree" % depth)
             s = stat[i]
             s["max_on_map"] = max(s["max_on_map"], int((st[:, 0] >= 0).sum()))
             s["max_deadlocked"] = max(s["max_deadlocked"], int(exp["props"][:, 1].sum()))
@@ -70,14 +80,15 @@ def main():
             print("step %d / %d ok (%.0f s)" % (t + 1, steps, time.time() - t_start), flush=True)
     mb.check()
     lines = ["soak of the Round-2 table, level %d of every test: %d steps of shortest-path-following actions, every env shadowed by the oracle on every step "
-             "(state, rewards, dones, cutils observation; depth-2 tree every 4th): all equal" % (level, steps),
-             "%-8s %5s %9s %6s %6s %11s %8s %10s %9s %s" % ("test", "agents", "grid", "rails", "on-map", "deadlocked", "arrived", "episodes", "conflicts", "launch class (class, split, envs on it)")]
+             "(state, rewards, dones, cutils observation; depth-2 / depth-3 tree and the builder alone every 4th each): all equal" % (level, steps),
+             "%-8s %5s %9s %6s %6s %11s %8s %10s %9s %s" % ("test", "agents", "grid", "rails", "on-map", "deadlocked", "arrived", "episodes", "conflicts", "launch class (class, split, envs on it): both builders depth 2 | depth 3 | the builder alone")]
     for i, e in enumerate(envs):
         g, b = mb.where[i]
         H, W = np.asarray(e["grid"]).shape
         s = stat[i]
         lines.append("%-8s %5d %9s %6d %6d %11d %8d %10d %9d %s" % (tests[i], len(e["init_dir"]), "%dx%d" % (H, W), int((np.asarray(e["grid"]) != 0).sum()),
-                                                                  s["max_on_map"], s["max_deadlocked"], s["arrived"], s["episodes"], s["conflicts"], mb.groups[g].last_obs_class()))
+                                                                  s["max_on_map"], s["max_deadlocked"], s["arrived"], s["episodes"], s["conflicts"],
+                                                                  "%s | %s | %s" % (cls_both[2][g], cls_both[3][g], cls_alone[g])))
     txt = "\n".join(lines)
     print(txt)
     if out:
