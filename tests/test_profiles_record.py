@@ -10,14 +10,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-WORKLOADS = ("cfg2_d2", "cfg3_d3", "cfg4_d2", "cfg5_d3", "cfg2_d2_distinct10", "cfg3_d3_distinct10", "cfg4_d2_distinct4", "cfg5_d3_distinct2")   # the last four: distinct generated maps
-TAG = "r05"
+# (workload key, the stage the bench line prices: both builders in one launch / the flatland_cutils builder alone writing the policy's tensors)
+WORKLOADS = (("cfg2_d2", "k_obs<cutils+tree>"), ("cfg3_d3", "k_obs<cutils+tree>"), ("cfg4_d2", "k_obs<cutils+tree>"), ("cfg5_d3", "k_obs<cutils+tree>"),
+             ("cfg2_d2_distinct10", "k_obs<cutils+tree>"), ("cfg3_d3_distinct10", "k_obs<cutils+tree>"), ("cfg4_d2_distinct4", "k_obs<cutils+tree>"),
+             ("cfg5_d3_distinct2", "k_obs<cutils+tree>"),                         # distinct generated maps
+             ("cfg2_d0", "k_obs<cutils,i64>"), ("cfg3_d0", "k_obs<cutils,i64>"), ("cfg4_d0", "k_obs<cutils,i64>"), ("cfg5_d0", "k_obs<cutils,i64>"),   # the consumer's path
+             ("cfg3_d3_keeprows", "k_obs<cutils+tree>"), ("cfg5_d3_keeprows", "k_obs<cutils+tree>"))     # FL_OBS_KEEP_TREE_ROWS
+TAG = "r06"
 
 
 def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
     traffic = json.load(open(os.path.join(P, "pmc_traffic.json")))
     stamps = set()
-    for w in WORKLOADS:
+    for w, stage in WORKLOADS:
         rows = list(csv.DictReader(open(os.path.join(P, f"{TAG}_{w}_kernel_stats.csv"))))
         obs = [r for r in rows if "k_obs" in r["Name"]]
         assert len(obs) == 1 and int(obs[0]["Calls"]) >= 100 and float(obs[0]["AverageNs"]) > 0
@@ -27,9 +32,10 @@ def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
         # the event-timed launch of the bench line and the trace average of the same run agree (events add a few microseconds)
         ev_ms, tr_ms = line["roofline"]["kernel_ms"], float(obs[0]["AverageNs"]) / 1e6
         assert 0.9 * tr_ms < ev_ms < 1.15 * tr_ms + 0.005, (w, ev_ms, tr_ms)
-        t = traffic[w]["k_obs<cutils+tree>"]
+        t = traffic[w][stage]
+        assert line["roofline"]["kernel"] == stage, (w, line["roofline"]["kernel"])
         assert t["tag"] == TAG and t["fetch_size_kib"] > 0 and t["write_size_kib"] > 0
-        # the kernel writes at least its outputs
+        # the kernel writes at least its outputs (the keep-rows mode's algorithmic bytes count the REAL rows it writes; a row that turns constant is written too)
         assert t["write_size_kib"] * 1024 > 0.9 * line["roofline"]["algorithmic_bytes_per_launch"]
         stamps.add(t["kernel_source_sha"])
     assert len(stamps) == 1, stamps
@@ -40,7 +46,9 @@ def test_every_workload_has_trace_bench_line_and_traffic_from_one_build():
 
 
 def test_default_bench_line_of_record_keeps_the_contract():
-    d = json.load(open(os.path.join(P, f"{TAG}_bench_default.json")))
+    raw = open(os.path.join(P, f"{TAG}_bench_default.json")).read()
+    assert len(raw.encode()) < 8192 and raw.count("\n") <= 1          # ONE line the driver can capture whole (round 5's was 24 958 bytes)
+    d = json.loads(raw)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -53,6 +61,13 @@ def test_default_bench_line_of_record_keeps_the_contract():
     assert c["cores"] == c["physical_cores"] <= c["threads"]      # one worker per PHYSICAL core is the stated figure
     # whole-job throughput and time per step belong together: B * A agent-steps per step
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 256 * 20) < 1.0
+    # every sub-workload of the default run, compact; the consumer's path among them; the complete objects in the detail file of record
+    w = d["workloads"]
+    for k in ("cfg3_d3", "cfg4_d2", "cfg5_d3_dmrebuild", "cfg2_cutils", "cfg3_cutils", "cfg4_cutils", "cfg5_cutils", "cfg3_d3_keeprows"):
+        assert w[k]["value"] > 0 and w[k]["roofline"]["frac"] > 0 and w[k]["launch_class"][0] != 0, k
+        assert w[k]["roofline"]["traffic_ratio"] is not None and w[k]["roofline"]["traffic_ratio"] >= 0.9, k     # a stored PMC measurement for every one
+    full = json.load(open(os.path.join(P, f"{TAG}_bench_detail.json")))
+    assert abs(full["value"] / d["value"] - 1) < 1e-5 and set(full["workloads"]) == set(w)
 
 
 def test_sq_counters_of_record_are_this_tree_s_and_consistent():
