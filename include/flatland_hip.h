@@ -16,6 +16,12 @@
  *                                         (flatland_cutils/src/main.cpp:17-22, treeobs.cpp:30-108, 612-640)
  *   fl_obs_tree                           flatland.envs.observations.TreeObsForRailEnv.get_many()
  *                                         (flatland/envs/observations.py:60-115)
+ *   fl_obs_cutils_policy                  ... the same with adjacency / node_order / edge_order written as the POLICY takes them: int64, the
+ *                                         adjacency modified (solution/plfActor.py:48-74 casts, solution/nn/net_tree.py:105-116) -- the one
+ *                                         call of the reference's solution (solution/eval_env.py:15-17 builds this builder only)
+ *   fl_obs_cutils_handles / fl_obs_tree_handles
+ *                                         get_many(handles) with a handle list: the listed agents' predictions only, by list position
+ *                                         (flatland_cutils/src/treeobs.cpp:50-62, 393-465; flatland/envs/observations.py:72-83, 337-366)
  *   fl_step_obs                           RailEnv.step() incl. the observations it returns (rail_env.py:634 -> :660-666)
  *   fl_obs_cutils_tree                    both observation builders above in one launch
  *   fl_info                               RailEnv.get_info_dict / action_required (rail_env.py:243-258, 452-468),
