@@ -597,6 +597,10 @@ class MixedBatch:
     def obs_both(self, max_depth=2, pred_depth=30):
         return self._each(lambda g: g.obs_both(max_depth, pred_depth))
 
+    def obs_policy(self):
+        """the consumer's call per group (fl_obs_cutils_policy): the adjacency of group k is offset over ITS (env, agent) flattening"""
+        return self._each(lambda g: g.obs_policy())
+
     def state(self, i):
         g, b = self.where[i]
         st, el = self.groups[g].state()
