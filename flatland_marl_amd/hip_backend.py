@@ -391,7 +391,7 @@ class BatchedRailEnv:
         t = self.torch
         o = obs if obs is not None else self.obs_cutils()
         B, A, E = o["adjacency"].shape[:3]
-        if not hasattr(self, "_pol"):
+        if not hasattr(self, "_pol") or self._pol[2].shape[-1] != E:
             self._pol = (t.empty((B, A, E, 3), dtype=t.int64, device=self.device),
                          t.empty((B, A, E + 1), dtype=t.int64, device=self.device),
                          t.empty((B, A, E), dtype=t.int64, device=self.device))
@@ -407,7 +407,7 @@ class BatchedRailEnv:
         t = self.torch
         o = self._obs_buffers()
         B, A, N = self.B, self.A, self.max_nodes
-        if not hasattr(self, "_pol64"):
+        if not hasattr(self, "_pol64") or self._pol64[1].shape[-1] != N:       # (max_nodes may be set anew by a builder's set_env)
             self._pol64 = (t.empty((B, A, N - 1, 3), dtype=t.int64, device=self.device), t.empty((B, A, N), dtype=t.int64, device=self.device),
                            t.empty((B, A, N - 1), dtype=t.int64, device=self.device))
         adj, no, eo = self._pol64

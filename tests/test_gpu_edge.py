@@ -37,6 +37,11 @@ def test_cutils_other_sizes_match_oracle(max_nodes, pred_depth):
         for g, e in (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency"), ("node_order", "node_order"),
                      ("edge_order", "edge_order"), ("valid_actions", "valid")):
             _same(got[g][0], exp[e], f"t={t} {g} N={max_nodes} P={pred_depth}")
+        if t % 16 == 5:      # the policy's int64 tensors from the launch itself (fl_obs_cutils_policy) at this tree size == fl_policy_pack of the int32 ones
+            import torch
+            ref = [x.clone() for x in env.policy_inputs(env._obs)[2:]]
+            for x, y in zip(env.obs_policy()[2:], ref):
+                assert x.shape == y.shape and torch.equal(x, y), (t, max_nodes)
     env.check()
 
 
