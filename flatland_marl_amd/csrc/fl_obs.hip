@@ -201,7 +201,13 @@ static bool exact_split_covers_most(const FlDev &d, ObsArgs &P, const ObsLayout 
 }
 static void obs_take_fixed_class(const FlDev &d, ObsArgs &P, const ObsOptions &o, ObsLayout &L, bool allowed) {
     static const bool no_fix = getenv("FL_OBS_NO_FIX") != nullptr;   // diagnostic: the runtime carving for every batch
-    static const bool no_bins = getenv("FL_OBS_NO_BINS") != nullptr;  // diagnostic: exact classes only (the launcher of rounds 4 and 5)
+    // diagnostic: exact classes only (the launcher of rounds 4 and 5).  A bin class REPLACES the batch's own options, so the switches that shape those options
+    // (what a same-box experiment wants to measure) rule the bins out as well; an exact class only ever matches options it dominates.
+    static const bool no_bins = [] {
+        for (const char *v : {"FL_OBS_NO_BINS", "FL_OBS_FORCE", "FL_OBS_NO_FB", "FL_OBS_NO_BK", "FL_OBS_NO_OWN_FILTER", "FL_OBS_NO_MERGE", "FL_OBS_NO_TAB", "FL_OBS_ROUND16"})
+            if (getenv(v) != nullptr) return true;
+        return false;
+    }();
     P.fix = 0; P.split = 0;
     if (no_fix || !allowed) return;
     if (P.tw_t == 0) {   // the flatland_cutils builder alone: classes 6 .. 10 (the counterparts of 1 .. 5)
