@@ -15,6 +15,8 @@ CUTILS = (("agent_attr", "attr"), ("forest", "forest"), ("adjacency", "adjacency
 @pytest.mark.parametrize("test,depth,klass_both,klass_alone,steps", [
     ("Test_1", 3, (11, 0), (6, 0), 60),        # 10 agents: class 1's bin twin at depth 3
     ("Test_3", 2, (16, 0), (20, 0), 60),       # 50 agents on a map TALLER than wide: the two-stage bins with compact prediction keys
+    ("Test_4", 2, (12, 0), (7, 0), 50),        # 80 agents at depth 2: class 2's bin twin (the builder alone: the exact class 7)
+    ("Test_4/60", 3, (12, 0), (17, 0), 50),    # Test_4's map with 60 agents: fewer than the exact classes' 80 -- bins 12 and 17
     ("Test_5", 3, (13, 0), (8, 0), 50),        # 80 agents, 239 / 324 rail cells: class 3's bin twin at depth 3, class 8
     ("Test_10", 2, (15, 0), (18, 0), 40),      # 100 agents, 1 265 / 1 319 rail cells: rounds of 32 agents with HBM lists
     ("Test_11", 3, (4, 0), (9, 0), 30),        # 200 agents: the large-map classes as bins
@@ -24,7 +26,20 @@ def test_bin_classes_on_batches_match_the_oracle(test, depth, klass_both, klass_
     from flatland_marl_amd import synth, workload as wl
     from flatland_marl_amd.hip_backend import BatchedRailEnv
     from oracle import orc
-    levels = [wl.generate_level(test, lv) for lv in (1, 2)]
+    if "/" in test:      # a Round-2 row with another number of agents (native host generators, as workload.generate_level)
+        from flatland_marl_amd import generators as gen
+        name, n_agents = test.split("/")
+        p = wl.round2_params(name)
+        levels = []
+        for lv in (1, 2):
+            rg = gen.sparse_rail_generator(max_num_cities=p["n_cities"], grid_mode=p["grid_mode"], max_rails_between_cities=p["max_rails_between_cities"],
+                                           max_rail_pairs_in_city=p["max_rail_pairs_in_city"])
+            lg = gen.sparse_line_generator(dict(zip(p["speed_values"], p["speed_probs"])))
+            st0 = gen.np_random(p["seeds"][lv]).get_state()
+            levels.append(gen.generate_env(p["width"], p["height"], int(n_agents), rg, lg, st0[1], st0[2], 1.0 / p["malfunction_interval"],
+                                           p["malfunction_duration_min"], p["malfunction_duration_max"]))
+    else:
+        levels = [wl.generate_level(test, lv) for lv in (1, 2)]
     B = 24
     envs = []
     for b in range(B):
